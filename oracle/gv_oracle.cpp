@@ -1,0 +1,667 @@
+// gv_oracle.cpp -- CPU restatement of the gVAMP linear-model hot path (see gv_oracle.hpp header:
+// TEST INFRASTRUCTURE ONLY; parity status stated there).  Plain C++17 + libstdc++ <random>
+// (the reference's RNG streams are libstdc++'s, so the same library reproduces them).
+#include "gv_oracle.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <random>
+#include <stdexcept>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace gvo {
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ================================ utilities.cpp ===============================================
+
+// utilities.cpp:259-291 -- contiguous marker blocks, remainder to the low ranks.
+void divide_work(int Mt, int nranks, int rank, int* M, int* S, int* Mm) {
+    const int modu = Mt % nranks;
+    const int size = Mt / nranks;
+    int cum = 0, m = 0, s = 0;
+    for (int i = 0; i < nranks; i++) {
+        int len = i < modu ? size + 1 : size;
+        if (i == rank) { m = len; s = cum; }
+        cum += len;
+    }
+    assert(cum == Mt);
+    *M = m; *S = s;
+    if (Mm) *Mm = modu != 0 ? size + 1 : size;
+}
+
+// utilities.cpp:48-73 -- one draw: fresh mt19937{seed}, one uniform, then (if slab) one normal.
+static double generate_mixture_gaussians(int K_grp, const std::vector<double>& eta,
+                                         const std::vector<double>& pi, unsigned long seed) {
+    std::mt19937 generator{seed};
+    std::uniform_real_distribution<double> unif(0.0, 1.0);
+    double u = unif(generator);
+    double c_sum = 0, out_val = 0;
+    for (int j = 0; j < K_grp; j++) {
+        c_sum += pi[j];
+        if (u <= c_sum) {
+            if (eta[j] != 0) {
+                std::normal_distribution<double> gauss_beta_gen(0.0, sqrt(eta[j]));
+                out_val = gauss_beta_gen(generator);
+            } else
+                out_val = 0;
+            break;
+        }
+    }
+    return out_val;
+}
+
+// utilities.cpp:77-88
+std::vector<double> simulate(int M, const std::vector<double>& eta, const std::vector<double>& pi,
+                             unsigned long seed) {
+    int K_grp = (int)eta.size();
+    std::vector<double> signal(M, 0.0);
+    for (int i = 0; i < M; i++) signal[i] = generate_mixture_gaussians(K_grp, eta, pi, seed + i);
+    return signal;
+}
+
+// utilities.cpp:91-140 -- default 23-component prior (only when neither probs nor vars given).
+void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int N, int Mt) {
+    if (probs.size() != 0 || vars.size() != 0) return;
+    int num_mix = 23;
+    double probs_1 = std::min(50000.0 / Mt, 1.0) / (2 - 1.0 / pow(2, 21));
+    if (Mt <= 50000) throw std::invalid_argument("No probabilities or variances were specified and Mt < 50,000.");
+    double curr_prob = probs_1;
+    probs.push_back(1 - 50000.0 / Mt);
+    for (int i0 = 0; i0 < num_mix - 1; i0++) {
+        probs.push_back(curr_prob);
+        curr_prob /= 2;
+    }
+    double start_var = 1e-5, stop_var = 1e2, temp_var = start_var;
+    double c_var = pow(10, log10(stop_var / start_var) / (num_mix - 1 - 1));
+    vars.push_back(0);
+    for (int i0 = 0; i0 < num_mix - 1; i0++) {
+        vars.push_back(temp_var);
+        temp_var *= c_var;
+    }
+    for (size_t i0 = 0; i0 < vars.size(); i0++) vars[i0] /= N;
+}
+
+// utilities.cpp:190-210 -- sequential sum (the reference's OpenMP reduction is order-free anyway).
+double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync, Comm* c) {
+    double accum = 0;
+    for (size_t i = 0; i < u.size(); i++) accum += u[i] * v[i];
+    if (sync == 1 && c) c->allreduce_sum(&accum, 1);
+    return accum;
+}
+double l2_norm2(const std::vector<double>& u, int sync, Comm* c) { return inner_prod(u, u, sync, c); }
+
+// utilities.cpp:235-257 with sync = 0
+double calc_stdev(const std::vector<double>& vec) {
+    double sum = std::accumulate(vec.begin(), vec.end(), 0.0);
+    double sq_sum = std::inner_product(vec.begin(), vec.end(), vec.begin(), 0.0);
+    int vec_len = (int)vec.size();
+    double mean = sum / vec_len;
+    return std::sqrt((sq_sum - vec_len * mean * mean) / (vec_len - 1));
+}
+
+// ================================ data.cpp ======================================================
+
+// data.cpp:86-100 -- vector-phenotype ctor: every individual present, pad bits of the last nibble cleared.
+void Data::init_full_mask() {
+    mbytes = (N % 4) ? (size_t)N / 4 + 1 : (size_t)N / 4;
+    mask4.assign(mbytes, 0x0F);
+    int m4 = N % 4;
+    if (m4 != 0)
+        for (int i = m4; i < 4; i++) mask4[N / 4] &= ~(0b1 << i);
+    nonas = N;
+}
+
+// data.cpp:128-192 (read_phen) after tokenising: NA -> DBL_MAX + mask bit cleared; values scaled by
+// sqrt((nonas-1)/sum((y-avg)^2)) but NOT centred (:172-182); DBL_MAX entries are scaled too (-> inf).
+void Data::set_phen_file_semantics(const std::vector<double>& raw, const std::vector<uint8_t>& is_na) {
+    assert((int)raw.size() == N);
+    mbytes = (N % 4) ? (size_t)N / 4 + 1 : (size_t)N / 4;
+    mask4.clear();
+    phen.clear();
+    double sum = 0.0;
+    int nas = 0;
+    nonas = 0;
+    for (int line_n = 0; line_n < N; line_n++) {
+        int m4 = line_n % 4;
+        if (m4 == 0) mask4.push_back(0x0F);
+        if (is_na[line_n]) {
+            nas += 1;
+            phen.push_back(std::numeric_limits<double>::max());
+            mask4[line_n / 4] &= ~(0b1 << m4);
+        } else {
+            nonas += 1;
+            phen.push_back(raw[line_n]);
+            sum += raw[line_n];
+        }
+    }
+    const int m4 = N % 4;
+    if (m4 != 0)
+        for (int i = m4; i < 4; i++) mask4[N / 4] &= ~(0b1 << i);
+    double avg = sum / double(nonas);
+    double sqn = 0.0;
+    for (size_t i = 0; i < phen.size(); i++)
+        if (phen[i] != std::numeric_limits<double>::max()) sqn += (phen[i] - avg) * (phen[i] - avg);
+    sqn = sqrt(double(nonas - 1) / sqn);
+    for (size_t i = 0; i < phen.size(); i++) phen[i] *= sqn;
+}
+
+// data.cpp:451-484 -- scalar (non-MANVECT) path: masked sums, sumb==0 and sumsqr==0 guards, alpha_scale.
+void Data::compute_markers_statistics() {
+    mave.assign(M, 0.0);
+    msig.assign(M, 0.0);
+    const int im4 = (int)mbytes;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int i = 0; i < M; i++) {
+        const uint8_t* bedm = &bed[size_t(i) * mbytes];
+        double suma = 0.0, sumb = 0.0;
+        for (int j = 0; j < im4; j++)
+            for (int k = 0; k < 4; k++) {
+                suma += lut_a(bedm[j], k) * lut_na(mask4[j], k);
+                sumb += lut_b(bedm[j], k) * lut_na(mask4[j], k);
+            }
+        if (sumb != 0) mave[i] = suma / sumb;
+        else mave[i] = 0.0;
+        double sumsqr = 0.0;
+        for (int j = 0; j < im4; j++)
+            for (int k = 0; k < 4; k++) {
+                double val = (lut_a(bedm[j], k) - mave[i]) * lut_b(bedm[j], k) * lut_na(mask4[j], k);
+                sumsqr += val * val;
+            }
+        if (sumsqr != 0) {
+            if (alpha_scale == 1.0) msig[i] = 1.0 / sqrt(sumsqr / (double(nonas) - 1.0));
+            else msig[i] = 1.0 / pow(sqrt(sumsqr / (double(nonas) - 1.0)), alpha_scale);
+        } else
+            msig[i] = 1.0;
+    }
+}
+
+// data.cpp:951-1007 -- scalar path: out[4j+k] += (a - ave) * (msig*x) * b * na, markers in order,
+// MPI_Allreduce(SUM) over ranks (:995), then * 1/sqrt(N) (:998-1005).  Threads split the byte columns
+// j, so every out[n] sees the markers in the same order as the serial loop: result independent of nthreads.
+std::vector<double> Data::Ax(const double* x) {
+    n_ax++;
+    std::vector<double> out(4 * mbytes, 0.0);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        int tid = 0, nt = 1;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+        nt = omp_get_num_threads();
+#endif
+        // column blocks of 2048 bytes (64 KiB of doubles) so the accumulators stay in L1/L2
+        const size_t BLK = 2048;
+        size_t nblk = (mbytes + BLK - 1) / BLK;
+        for (size_t b = tid; b < nblk; b += nt) {
+            size_t j0 = b * BLK, j1 = std::min(mbytes, j0 + BLK);
+            for (int i = 0; i < M; i++) {
+                const uint8_t* bedm = &bed[size_t(i) * mbytes];
+                double ave = mave[i];
+                double sig_phen_i = msig[i] * x[i];
+                double val[4];
+                for (int c = 0; c < 4; c++) val[c] = (lut_a(c, 0) - ave) * sig_phen_i * lut_b(c, 0);
+                for (size_t j = j0; j < j1; j++) {
+                    unsigned byte = bedm[j], nib = mask4[j];
+                    for (int k = 0; k < 4; k++) out[4 * j + k] += val[(byte >> (2 * k)) & 3u] * lut_na(nib, k);
+                }
+            }
+        }
+    }
+    if (comm) comm->allreduce_sum(out.data(), out.size());
+    double scale = 1.0 / sqrt(N);
+    for (size_t i = 0; i < out.size(); i++) out[i] *= scale;
+    return out;
+}
+
+// data.cpp:810-835 (ATx) over :758-779 (scalar dot_product): sigma * (sum a*p - mu * sum b*p), * 1/sqrt(N).
+// No mask: relies on p == 0 at NA / pad positions, as the reference does.
+std::vector<double> Data::ATx(const double* p) {
+    n_atx++;
+    std::vector<double> out(M, 0.0);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int mloc = 0; mloc < M; mloc++) {
+        const uint8_t* bedm = &bed[size_t(mloc) * mbytes];
+        double dpa = 0.0, dpb = 0.0;
+        for (size_t i = 0; i < mbytes; i++) {
+            unsigned byte = bedm[i];
+            for (int j = 0; j < 4; j++) {
+                dpa += lut_a(byte, j) * p[i * 4 + j];
+                dpb += lut_b(byte, j) * p[i * 4 + j];
+            }
+        }
+        out[mloc] = msig[mloc] * (dpa - mave[mloc] * dpb);
+    }
+    double scale = 1.0 / sqrt(N);
+    for (int mloc = 0; mloc < M; mloc++) out[mloc] *= scale;
+    return out;
+}
+
+// data.cpp:1065-1079 -- length N (the reference hands y.data() to ATx, which reads 4*mbytes doubles:
+// out of bounds when N%4 != 0).  The restatement pads with zeros to 4*mbytes instead.
+std::vector<double> Data::filter_pheno() const {
+    std::vector<double> y(4 * mbytes, 0.0);
+    for (int i = 0; i < N; i++) y[i] = phen[i];
+    for (size_t j = 0; j < mbytes; j++)
+        for (int k = 0; k < 4; k++)
+            if ((int)(4 * j + k) < N)
+                if (lut_na(mask4[j], k) == 0) y[4 * j + k] = 0;
+    return y;
+}
+
+// ================================ vamp.cpp ======================================================
+
+static const double gamma_min = 1e-11, gamma_max = 1e11;   // vamp.hpp:31-32
+static const int auto_var_max_iter = 5;                    // vamp.hpp:37
+
+// vamp.cpp:32-82 (ctor 1) / :89-139 (ctor 2): state initialisation; initialize_prior at :78/:136.
+Vamp::Vamp(Data* d_, const VampOpts& o_) : N(d_->N), M(d_->M), Mt(d_->Mt), o(o_), d(d_), comm(d_->comm) {
+    gam1 = o.gam1;
+    gamw = o.gamw;
+    rho = o.rho;
+    probs = o.probs;
+    vars = o.vars;
+    x1_hat.assign(M, 0.0);
+    x2_hat.assign(M, 0.0);
+    r1.assign(M, 0.0);
+    r2.assign(M, 0.0);
+    if (o.true_signal.empty()) o.true_signal.assign(M, 0.0);
+    initialize_prior(probs, vars, N, Mt);
+}
+
+// vamp.cpp:805-834
+double Vamp::g1(double y, double gam1) const {
+    double sigma = 1 / gam1;
+    double eta_max = *(std::max_element(vars.begin(), vars.end()));
+    double pk = 0, pkd = 0, val;
+    if (sigma < 1e-10 && sigma > -1e-10) return y;
+    for (size_t i = 0; i < probs.size(); i++) {
+        double expe_sum = -0.5 * pow(y, 2) * (eta_max - vars[i]) / (vars[i] + sigma) / (eta_max + sigma);
+        double z = probs[i] / sqrt(vars[i] + sigma) * exp(expe_sum);
+        pk = pk + z;
+        z = z / (vars[i] + sigma) * y;
+        pkd = pkd - z;
+    }
+    val = (y + sigma * pkd / pk);
+    return val;
+}
+
+// vamp.cpp:836-869
+double Vamp::g1d(double y, double gam1) const {
+    double sigma = 1 / gam1;
+    double eta_max = *std::max_element(vars.begin(), vars.end());
+    double pk = 0, pkd = 0, pkdd = 0;
+    if (sigma < 1e-10 && sigma > -1e-10) return 1;
+    for (size_t i = 0; i < probs.size(); i++) {
+        double expe_sum = -0.5 * pow(y, 2) * (eta_max - vars[i]) / (vars[i] + sigma) / (eta_max + sigma);
+        double z = probs[i] / sqrt(vars[i] + sigma) * exp(expe_sum);
+        pk = pk + z;
+        z = z / (vars[i] + sigma) * y;
+        pkd = pkd - z;
+        double z2 = z / (vars[i] + sigma) * y;
+        pkdd = pkdd - probs[i] / pow(vars[i] + sigma, 1.5) * exp(expe_sum) + z2;
+    }
+    return (1 + sigma * (pkdd / pk - pow(pkd / pk, 2)));
+}
+
+// vamp.cpp:929-1072 -- EM for mixture weights / variances, then merge of close variances.
+void Vamp::updatePrior(int verbose) {
+    double noise_var = 1 / gam1;
+    double lambda = 1 - probs[0];
+    std::vector<double> omegas = probs;
+    for (size_t j = 1; j < omegas.size(); j++) omegas[j] /= lambda;
+    int it;
+    for (it = 0; it < o.EM_max_iter; it++) {
+        double max_sigma = *std::max_element(vars.begin(), vars.end());
+        std::vector<double> probs_prev = probs, vars_prev = vars;
+        const size_t Lm1 = probs.size() - 1;
+        std::vector<double> beta(size_t(M) * Lm1), gammas(size_t(M) * Lm1), pin(M, 0.0), v;
+        for (int i = 0; i < M; i++) {
+            double sum_of_elems = 0;
+            for (size_t j = 1; j < probs.size(); j++) {
+                double num = lambda * omegas[j] *
+                             exp(-pow(r1[i], 2) / 2 * (max_sigma - vars[j]) / (vars[j] + noise_var) / (max_sigma + noise_var)) /
+                             sqrt(vars[j] + noise_var) / sqrt(2 * M_PI);
+                double num_gammas = gam1 * r1[i] / (1 / vars[j] + gam1);
+                beta[i * Lm1 + j - 1] = num;
+                gammas[i * Lm1 + j - 1] = num_gammas;
+                sum_of_elems += num;      // std::accumulate in index order (:970)
+            }
+            for (size_t j = 0; j < Lm1; j++) beta[i * Lm1 + j] /= sum_of_elems;
+            pin[i] = 1 / (1 + (1 - lambda) / sqrt(2 * M_PI * noise_var) *
+                                  exp(-pow(r1[i], 2) / 2 * max_sigma / noise_var / (noise_var + max_sigma)) / sum_of_elems);
+        }
+        for (size_t j = 1; j < probs.size(); j++) v.push_back(1.0 / (1.0 / vars[j] + gam1));
+        lambda = std::accumulate(pin.begin(), pin.end(), 0.0);
+        double lambda_total = lambda;
+        if (comm) comm->allreduce_sum(&lambda_total, 1);
+        lambda = lambda_total / Mt;
+        for (int i = 0; i < M; i++)
+            for (size_t j = 0; j < Lm1; j++)
+                gammas[i * Lm1 + j] = beta[i * Lm1 + j] * (gammas[i * Lm1 + j] * gammas[i * Lm1 + j] + v[j]);
+        double sum_of_pin = lambda_total;
+        for (size_t j = 0; j < Lm1; j++) {
+            double res = 0, res_gammas = 0;
+            for (int i = 0; i < M; i++) {
+                res += beta[i * Lm1 + j] * pin[i];
+                res_gammas += gammas[i * Lm1 + j] * pin[i];
+            }
+            double tot[2] = {res_gammas, res};
+            if (comm) comm->allreduce_sum(tot, 2);
+            if (o.learn_vars == 1) vars[j + 1] = tot[0] / tot[1];
+            omegas[j + 1] = tot[1] / sum_of_pin;
+            probs[j + 1] = lambda * omegas[j + 1];
+        }
+        probs[0] = 1 - lambda;
+        double distance_probs = 0, norm_probs = 0, distance_vars = 0, norm_vars = 0;
+        for (size_t j = 0; j < probs.size(); j++) {
+            distance_probs += (probs[j] - probs_prev[j]) * (probs[j] - probs_prev[j]);
+            norm_probs += probs[j] * probs[j];
+            distance_vars += (vars[j] - vars_prev[j]) * (vars[j] - vars_prev[j]);
+            norm_vars += vars[j] * vars[j];
+        }
+        double dist_probs = sqrt(distance_probs / norm_probs);
+        double dist_vars = sqrt(distance_vars / norm_vars);
+        if (verbose == 1 && o.verbose && (!comm || comm->rank == 0))
+            printf("it = %d: dist_probs = %g & dist_vars = %g\n", it, dist_probs, dist_vars);
+        if (dist_probs < o.EM_err_thr && dist_vars < o.EM_err_thr) break;
+    }
+    // merging close variances (:1054-1071)
+    for (size_t j = 0; j < vars.size(); j++) {
+        for (size_t k = j + 1; k < vars.size(); k++) {
+            double denom;
+            if (vars[j] != 0) denom = std::min(vars[j], vars[k]);
+            else denom = 1e-7;
+            if (std::abs(vars[j] - vars[k]) / denom < 5e-1) {
+                double sum2probs = probs[j] + probs[k];
+                vars.erase(vars.begin() + k);
+                probs.erase(probs.begin() + k);
+                probs[j] = sum2probs;
+                k--;
+            }
+        }
+    }
+}
+
+// vamp.cpp:1074-1118 (red == 0 branch).  The all-zero shortcut (:1079) is kept: A*0 == 0 either way.
+std::vector<double> Vamp::lmmse_mult(const std::vector<double>& v, double tau) {
+    if (v == std::vector<double>(M, 0.0)) return std::vector<double>(M, 0.0);
+    std::vector<double> res_temp = d->Ax(v.data());
+    std::vector<double> res = d->ATx(res_temp.data());
+    for (int i = 0; i < M; i++) {
+        res[i] *= tau;
+        res[i] += gam2 * v[i];
+    }
+    return res;
+}
+
+// vamp.cpp:1130-1229
+std::vector<double> Vamp::precondCG_solver(const std::vector<double>& v, const std::vector<double>& mu_start,
+                                           double tau, int denoiser) {
+    std::vector<double> diag(M, 1.0);
+    for (int j = 0; j < M; j++) diag[j] = tau * (N - 1) / N + gam2;
+    std::vector<double> mu = mu_start;
+    std::vector<double> dvec;
+    std::vector<double> r = lmmse_mult(mu, tau);
+    for (int i0 = 0; i0 < M; i0++) r[i0] = v[i0] - r[i0];
+    std::vector<double> z(M, 0.0);
+    for (int j = 0; j < M; j++) z[j] = r[j] / diag[j];
+    std::vector<double> p = z;
+    std::vector<double> Apalpha(M, 0.0), palpha(M, 0.0);
+    double alpha, beta, prev_onsager = 0;
+    std::vector<double> relres;
+    int iters = 0;
+    for (int i = 0; i < o.CG_max_iter; i++) {
+        iters = i + 1;
+        dvec = lmmse_mult(p, tau);
+        alpha = inner_prod(r, z, 1, comm) / inner_prod(dvec, p, 1, comm);
+        for (int j = 0; j < M; j++) palpha[j] = alpha * p[j];
+        for (int j = 0; j < M; j++) mu[j] = mu[j] + palpha[j];
+        if (denoiser == 0) {
+            double onsager = gam2 * inner_prod(v, mu, 1, comm);
+            double rel_err;
+            if (onsager != 0) rel_err = std::abs((onsager - prev_onsager) / onsager);
+            else rel_err = 1;
+            if (rel_err < 1e-8) break;
+            prev_onsager = onsager;
+            if (o.verbose && (!comm || comm->rank == 0))
+                printf("[CG onsager] it = %d: relative error for onsager is %.10g\n", i, rel_err);
+        }
+        for (int j = 0; j < M; j++) Apalpha[j] = dvec[j] * alpha;
+        beta = pow(inner_prod(r, z, 1, comm), -1);
+        for (int j = 0; j < M; j++) r[j] = r[j] - Apalpha[j];
+        for (int j = 0; j < M; j++) z[j] = r[j] / diag[j];
+        beta *= inner_prod(r, z, 1, comm);
+        for (int j = 0; j < M; j++) p[j] = z[j] + beta * p[j];
+        double norm_v = sqrt(l2_norm2(v, 1, comm));
+        double norm_z = sqrt(l2_norm2(z, 1, comm));
+        double rel_err = sqrt(l2_norm2(r, 1, comm)) / norm_v;
+        double norm_mu = sqrt(l2_norm2(mu, 1, comm));
+        double err_tol = 1e-5;
+        relres.push_back(rel_err);
+        if (o.verbose && (!comm || comm->rank == 0))
+            printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g, ||x_it|| = %.10g, ||z|| / ||RHS|| = %.10g\n", i, rel_err,
+                   norm_mu, norm_z / norm_v);
+        if (rel_err < err_tol) break;
+    }
+    last_cg_iters = iters;
+    cg_relres.push_back(relres);
+    if (denoiser == 1) mu_CG_last = mu;
+    return mu;
+}
+
+// vamp.cpp:871-889 -- Hutchinson probe u in {+-1/sqrt(Mt)}^M from mt19937{seed + S} + bernoulli(0.5).
+double Vamp::g2d_onsager(double gam2_, double tau) {
+    std::mt19937 rd{o.seed + (unsigned long)d->S};
+    std::bernoulli_distribution bern(0.5);
+    bern_vec = std::vector<double>(M, 0.0);
+    for (int i = 0; i < M; i++) bern_vec[i] = (2 * bern(rd) - 1) / sqrt(Mt);
+    invQ_bern_vec = precondCG_solver(bern_vec, std::vector<double>(M, 0.0), tau, 0);
+    return gam2_ * inner_prod(bern_vec, invQ_bern_vec, 1, comm);
+}
+
+// vamp.cpp:892-927
+void Vamp::updateNoisePrec() {
+    y = d->filter_pheno();
+    std::vector<double> temp = d->Ax(x2_hat.data());
+    for (int i = 0; i < N; i++) temp[i] -= y[i];
+    double temp_norm2 = l2_norm2(temp, 0, comm);
+    std::vector<double> trace_corr_vec_N = d->Ax(invQ_bern_vec.data());
+    std::vector<double> trace_corr_vec_M = d->ATx(trace_corr_vec_N.data());
+    double trace_corr = inner_prod(bern_vec, trace_corr_vec_M, 1, comm) * Mt;
+    if (o.verbose && (!comm || comm->rank == 0)) {
+        printf("l2_norm2(temp) / N = %.10g\n", temp_norm2 / N);
+        printf("trace_correction / N = %.10g\n", trace_corr / N);
+    }
+    gamw = (double)N / (temp_norm2 + trace_corr);
+}
+
+// vamp.cpp:1232-1318 (redglob == 0): only R2trains feeds back into outputs; the Ax call for ind == 2
+// (:1301) is kept because it is part of the per-iteration matvec count.
+void Vamp::err_measures(int ind) {
+    y = d->filter_pheno();
+    std::vector<double> Axest;
+    if (ind == 1) {
+        if (z1.size() > 0) Axest = z1;
+        else Axest = d->Ax(x1_hat.data());
+    } else
+        Axest = d->Ax(x2_hat.data());
+    std::vector<double> tempNest(4 * d->mbytes, 0.0);
+    for (int i = 0; i < N; i++) tempNest[i] = -Axest[i] + y[i];
+    double l2_pred_err = sqrt(l2_norm2(tempNest, 0, comm) / l2_norm2(y, 0, comm));
+    double R2 = 1 - l2_pred_err * l2_pred_err;
+    R2trains.push_back(R2);
+    if (o.verbose && (!comm || comm->rank == 0)) printf("R2 = %.10g\n", R2);
+}
+
+static void store_bin(const std::string& path, const std::vector<double>& v, int S) {
+    // utilities.cpp:293-301 -- raw native doubles at byte offset S*8 of a shared file.
+    FILE* f = fopen(path.c_str(), "r+b");
+    if (!f) f = fopen(path.c_str(), "w+b");
+    if (!f) return;
+    fseek(f, (long)S * 8, SEEK_SET);
+    fwrite(v.data(), 8, v.size(), f);
+    fclose(f);
+}
+
+// vamp.cpp:149-183 (infere: vars *= N, model dispatch) + :190-803 (infere_linear; no restart, no
+// init_est, no freeze, no cross-val, reverse == 0).  Statement order follows the reference line by line.
+std::vector<double> Vamp::infere() {
+    y = d->phen;
+    for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;
+
+    std::vector<double> x1_hat_d(M, 0.0), x1_hat_stored(M, 0.0), x1_hat_prev(M, 0.0);
+    alpha1 = 0;
+    alpha2 = 0;   // uninitialised member in the reference (read at :501 before :631); SURVEY App. B
+    std::vector<double> y = d->filter_pheno();
+    r1 = std::vector<double>(M, 0.0);
+    const int rank0 = (!comm || comm->rank == 0);
+
+    for (int it = 1; it <= o.iterations; it++) {
+        double t_start = now_s();
+        long ax0 = d->n_ax, atx0 = d->n_atx;
+        IterTrace tr;
+        memset(&tr, 0, sizeof(tr));
+        x1_hat_prev = x1_hat;
+        double alpha1_prev = alpha1;
+        double gam1_reEst_prev;
+        int it_revar = 1;
+        for (; it_revar <= auto_var_max_iter; it_revar++) {            // :289-338
+            for (int i = 0; i < M; i++) x1_hat[i] = g1(r1[i], gam1);
+            std::vector<double> x1_hat_m_r1 = x1_hat;
+            for (size_t i0 = 0; i0 < x1_hat_m_r1.size(); i0++) x1_hat_m_r1[i0] = x1_hat_m_r1[i0] - r1[i0];
+            double sum_d = 0;
+            for (int i = 0; i < M; i++) {
+                x1_hat_d[i] = g1d(r1[i], gam1);
+                sum_d += x1_hat_d[i];
+            }
+            alpha1 = sum_d;
+            if (comm) comm->allreduce_sum(&alpha1, 1);
+            alpha1 /= Mt;
+            eta1 = gam1 / alpha1;
+            if (it <= 1) break;
+            gam1_reEst_prev = gam1;
+            gam1 = std::min(std::max(1.0 / (1.0 / eta1 + l2_norm2(x1_hat_m_r1, 1, comm) / Mt), gamma_min), gamma_max);
+            updatePrior(0);
+            if (o.verbose && rank0) printf("[old] it_revar = %d: gam1 = %.10g\n", it_revar, gam1);
+            if (std::abs(gam1 - gam1_reEst_prev) < 1e-3) break;
+        }
+        gam1s.push_back(gam1);
+        tr.gam1_denoise = gam1;
+        tr.revar_rounds = std::max(it_revar - 1, 1);
+
+        if (it > 1) {                                                   // :348-423
+            for (int i = 0; i < M; i++) x1_hat[i] = rho * x1_hat[i] + (1 - rho) * x1_hat_prev[i];
+            alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
+        }
+        z1 = d->Ax(x1_hat.data());                                      // :429
+
+        double scale = sqrt(N);
+        for (size_t i0 = 0; i0 < x1_hat_stored.size(); i0++) x1_hat_stored[i0] = x1_hat[i0] / scale;
+        std::vector<double> r1_stored = r1;
+        for (size_t i0 = 0; i0 < r1_stored.size(); i0++) r1_stored[i0] = r1[i0] / scale;
+        x1_hist.push_back(x1_hat_stored);
+        r1_hist.push_back(r1_stored);
+        if (!o.out_prefix.empty()) {
+            store_bin(o.out_prefix + "_it_" + std::to_string(it) + ".bin", x1_hat_stored, d->S);
+            store_bin(o.out_prefix + "_r1_it_" + std::to_string(it) + ".bin", r1_stored, d->S);
+        }
+
+        gam_before = gam2;
+        gam2 = std::min(std::max(eta1 - gam1, gamma_min), gamma_max);   // :472
+        r2_prev = r2;                                                   // :483
+        for (int i = 0; i < M; i++) r2[i] = (eta1 * x1_hat[i] - gam1 * r1[i]) / gam2;
+        if (o.use_lmmse_damp == 1) {                                    // :488-498
+            double xi = std::min(2 * rho, 1.0);
+            if (it > 1) gam2 = 1.0 / pow(xi / sqrt(gam2) + (1 - xi) / sqrt(gam_before), 2);
+        }
+        double xi = std::min(2 * std::min(alpha1, alpha2), 1.0);        // :501-502
+        rho = std::max(rho, xi);
+        tr.alpha1 = alpha1;
+        tr.eta1 = eta1;
+        tr.gam2 = gam2;
+        tr.rho = rho;
+        if (o.verbose && rank0) printf("eta1 = %.10g\ngam2 = %.10g\n", eta1, gam2);
+
+        if (auto_var_max_iter == 0 || it <= 1) updatePrior(1);          // :518-519
+        err_measures(1);                                                // :525
+
+        if (!o.out_prefix.empty()) {
+            std::vector<double> r2_stored = r2;
+            for (size_t i0 = 0; i0 < r2_stored.size(); i0++) r2_stored[i0] = r2[i0] / scale;
+            store_bin(o.out_prefix + "_r2_it_" + std::to_string(it) + ".bin", r2_stored, d->S);
+        }
+
+        // ---- LMMSE step (:584-596)
+        std::vector<double> v = d->ATx(y.data());
+        for (int i = 0; i < M; i++) v[i] = gamw * v[i] + gam2 * r2[i];
+        if (it == 1) x2_hat = precondCG_solver(v, std::vector<double>(M, 0.0), gamw, 1);
+        else x2_hat = precondCG_solver(v, mu_CG_last, gamw, 1);
+        tr.cg_iters = last_cg_iters;
+        std::vector<double> x2_hat_stored = x2_hat;
+        for (size_t i0 = 0; i0 < x2_hat_stored.size(); i0++) x2_hat_stored[i0] = x2_hat[i0] / scale;
+        x2_hist.push_back(x2_hat_stored);
+        if (!o.out_prefix.empty())
+            store_bin(o.out_prefix + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat_stored, d->S);
+
+        alpha2 = g2d_onsager(gam2, gamw);                               // :631
+        tr.onsager_iters = last_cg_iters;
+        tr.alpha2 = alpha2;
+        if (o.verbose && rank0) printf("alpha2 = %.10g\n", alpha2);
+
+        if (it > 1) {
+            // :646-681 "polynomial onsager" diagnostics: printed only, but they cost 3 Ax per iteration,
+            // which belongs to the reference's per-iteration work.
+            std::vector<double> Xr2 = d->Ax(r2.data());
+            std::vector<double> Xx2hat_m_y = d->Ax(x2_hat.data());
+            std::vector<double> Xx2b = d->Ax(x2_hat.data());
+            (void)Xr2; (void)Xx2hat_m_y; (void)Xx2b;
+        }
+        eta2 = gam2 / alpha2;                                           // :682
+        std::vector<double> x2_hat_m_r2 = x2_hat;
+        for (size_t i0 = 0; i0 < x2_hat_m_r2.size(); i0++) x2_hat_m_r2[i0] = x2_hat_m_r2[i0] - r2[i0];
+        if (auto_var_max_iter >= 1 && it > 2)
+            gam2 = std::min(std::max(1 / (1 / eta2 + l2_norm2(x2_hat_m_r2, 1, comm) / Mt), gamma_min), gamma_max);
+        gam2s.push_back(gam2);
+        tr.eta2 = eta2;
+        tr.gam2_reest = gam2;
+        gam1 = std::min(std::max(eta2 - gam2, gamma_min), gamma_max);   // :702
+        for (int i = 0; i < M; i++) r1[i] = (eta2 * x2_hat[i] - gam2 * r2[i]) / gam1;
+        tr.gam1_next = gam1;
+        if (o.verbose && rank0) printf("gam2 re-est = %.10g\ngam1 = %.10g\n", gam2, gam1);
+
+        updateNoisePrec();                                              // :726
+        tr.gamw = gamw;
+        err_measures(2);                                                // :731
+        if (o.verbose && rank0) printf("gamw = %.10g\n", gamw);
+
+        tr.L_after = (int)probs.size();
+        tr.n_ax = d->n_ax - ax0;
+        tr.n_atx = d->n_atx - atx0;
+        tr.seconds = now_s() - t_start;
+        trace.push_back(tr);
+
+        std::vector<double> x1_hat_diff = x1_hat;                       // :741-749
+        for (size_t i0 = 0; i0 < x1_hat_diff.size(); i0++) x1_hat_diff[i0] = x1_hat_prev[i0] - x1_hat_diff[i0];
+        if (it > 1 && sqrt(l2_norm2(x1_hat_diff, 1, comm) / l2_norm2(x1_hat_prev, 1, comm)) < o.stop_criteria_thr) break;
+    }
+    return x1_hat_stored;
+}
+
+}  // namespace gvo
