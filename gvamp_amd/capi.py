@@ -1,0 +1,319 @@
+"""ctypes binding of libgvamp.so (include/gvamp.h) -- what tests/ and bench.py drive.
+
+This module is plumbing only: every method forwards to one C-ABI entry point.  It never computes on the
+CPU and never imports oracle/.  If the library or a GPU is missing it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgvamp.so")
+_LIB = None
+
+SPACE_M, SPACE_N = 0, 1
+
+EXPORTS = [
+    "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
+    "gv_upload_bed", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
+    "gv_ax", "gv_atx", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
+    "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
+    "gv_ax_dev", "gv_atx_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_denoise", "gv_prior_estep",
+    "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
+]
+
+
+class GvError(RuntimeError):
+    pass
+
+
+class CgStats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("rel_res", C.c_double), ("onsager", C.c_double),
+                ("n_ax", C.c_int), ("n_atx", C.c_int), ("n_relres", C.c_int)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_ax", C.c_int64), ("n_atx", C.c_int64), ("ms_ax", C.c_double), ("ms_atx", C.c_double),
+                ("ms_allreduce", C.c_double)]
+
+
+def load():
+    """dlopen libgvamp.so.  Raises if it has not been built (python gvamp_amd/build.py)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise GvError("libgvamp.so is not built: run `python gvamp_amd/build.py` (needs hipcc)")
+    L = C.CDLL(LIB_PATH)
+    vp, dp, up = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
+    i64 = C.c_int64
+    L.gv_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.gv_destroy.argtypes = [vp]
+    L.gv_destroy.restype = None
+    L.gv_last_error.argtypes = [vp]
+    L.gv_last_error.restype = C.c_char_p
+    L.gv_synchronize.argtypes = [vp]
+    L.gv_set_dims.argtypes = [vp, i64, i64, i64, i64]
+    L.gv_mbytes.argtypes = [vp]
+    L.gv_mbytes.restype = i64
+    L.gv_upload_bed.argtypes = [vp, up, C.c_size_t]
+    L.gv_synth_bed.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.gv_download_bed.argtypes = [vp, up, C.c_size_t]
+    L.gv_set_mask.argtypes = [vp, up, i64]
+    L.gv_marker_stats.argtypes = [vp, C.c_double]
+    L.gv_get_marker_stats.argtypes = [vp, dp, dp]
+    L.gv_ax.argtypes = [vp, dp, dp]
+    L.gv_atx.argtypes = [vp, dp, dp]
+    L.gv_set_kernel_mode.argtypes = [vp, C.c_int]
+    L.gv_get_kernel_mode.argtypes = [vp]
+    L.gv_vec_alloc.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.gv_vec_free.argtypes = [vp, vp]
+    L.gv_vec_free.restype = None
+    L.gv_vec_len.argtypes = [vp]
+    L.gv_vec_len.restype = i64
+    L.gv_vec_upload.argtypes = [vp, vp, dp]
+    L.gv_vec_download.argtypes = [vp, vp, dp]
+    L.gv_vec_fill.argtypes = [vp, vp, C.c_double]
+    L.gv_vec_copy.argtypes = [vp, vp, vp]
+    L.gv_vec_axpby.argtypes = [vp, vp, C.c_double, vp, C.c_double, vp]
+    L.gv_vec_dot.argtypes = [vp, vp, vp, C.c_int, dp]
+    L.gv_vec_dots.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, dp]
+    L.gv_ax_dev.argtypes = [vp, vp, vp]
+    L.gv_atx_dev.argtypes = [vp, vp, vp]
+    L.gv_set_phen.argtypes = [vp, vp, dp]
+    L.gv_lmmse_mult.argtypes = [vp, vp, C.c_double, C.c_double, vp]
+    L.gv_cg_solve.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.POINTER(CgStats), dp]
+    L.gv_denoise.argtypes = [vp, vp, C.c_double, dp, dp, C.c_int, vp, vp, dp]
+    L.gv_prior_estep.argtypes = [vp, vp, C.c_double, C.c_double, dp, dp, C.c_int, dp]
+    L.gv_allreduce_host.argtypes = [vp, dp, C.c_int]
+    L.gv_comm_unique_id.argtypes = [C.c_void_p]
+    L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.gv_comm_rank.argtypes = [vp]
+    L.gv_comm_size.argtypes = [vp]
+    L.gv_set_timing.argtypes = [vp, C.c_int]
+    L.gv_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.gv_reset_counters.argtypes = [vp]
+    L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * 128)()
+    if load().gv_comm_unique_id(buf):
+        raise GvError(load().gv_last_error(None).decode())
+    return bytes(buf)
+
+
+class Vec:
+    """Device-resident fp64 vector (gv_vec)."""
+
+    def __init__(self, shard, space):
+        self.shard = shard
+        h = C.c_void_p()
+        shard._ck(shard.L.gv_vec_alloc(shard.h, space, C.byref(h)))
+        self.h = h
+        self.space = space
+        self.n = shard.L.gv_vec_len(h)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.n, (a.size, self.n)
+        self.shard._ck(self.shard.L.gv_vec_upload(self.shard.h, self.h, _dp(a)))
+        return self
+
+    def download(self):
+        out = np.empty(self.n)
+        self.shard._ck(self.shard.L.gv_vec_download(self.shard.h, self.h, _dp(out)))
+        return out
+
+    def fill(self, v):
+        self.shard._ck(self.shard.L.gv_vec_fill(self.shard.h, self.h, float(v)))
+        return self
+
+    def free(self):
+        if self.h:
+            self.shard.L.gv_vec_free(self.shard.h, self.h)
+            self.h = None
+
+
+class Shard:
+    """One marker shard resident on one GPU: the device side of the reference's `class data`
+    (data.hpp:93-140).  Method names follow the reference (Ax, ATx, compute_markers_statistics...)."""
+
+    def __init__(self, N, M, Mt=None, S=0, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        if self.L.gv_create(device, C.byref(h)):
+            raise GvError(self.L.gv_last_error(None).decode())
+        self.h = h
+        self.N, self.M, self.Mt, self.S = N, M, (M if Mt is None else Mt), S
+        self._ck(self.L.gv_set_dims(h, N, M, self.Mt, S))
+        self.mbytes = self.L.gv_mbytes(h)
+
+    def _ck(self, rc):
+        if rc:
+            raise GvError(self.L.gv_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.gv_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- dataset -------------------------------------------------------------------------------------
+    def upload_bed(self, bed):
+        bed = np.ascontiguousarray(bed, dtype=np.uint8)
+        self._ck(self.L.gv_upload_bed(self.h, _up(bed), bed.size))
+
+    def synth_bed(self, seed, miss_ppm=5000):
+        self._ck(self.L.gv_synth_bed(self.h, seed, miss_ppm))
+
+    def download_bed(self):
+        out = np.empty(self.M * self.mbytes, dtype=np.uint8)
+        self._ck(self.L.gv_download_bed(self.h, _up(out), out.size))
+        return out
+
+    def set_mask(self, mask4, nonas):
+        m = np.ascontiguousarray(mask4, dtype=np.uint8)
+        assert m.size == self.mbytes
+        self._ck(self.L.gv_set_mask(self.h, _up(m), nonas))
+
+    def compute_markers_statistics(self, alpha_scale=1.0):
+        self._ck(self.L.gv_marker_stats(self.h, alpha_scale))
+
+    def marker_stats(self):
+        mave, msig = np.empty(self.M), np.empty(self.M)
+        self._ck(self.L.gv_get_marker_stats(self.h, _dp(mave), _dp(msig)))
+        return mave, msig
+
+    def set_kernel_mode(self, mode):
+        self._ck(self.L.gv_set_kernel_mode(self.h, mode))
+
+    # ---- host-signature matvecs (data::Ax / data::ATx) ---------------------------------------------------
+    def Ax(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.M
+        out = np.empty(4 * self.mbytes)
+        self._ck(self.L.gv_ax(self.h, _dp(x), _dp(out)))
+        return out
+
+    def ATx(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert p.size == 4 * self.mbytes
+        out = np.empty(self.M)
+        self._ck(self.L.gv_atx(self.h, _dp(p), _dp(out)))
+        return out
+
+    # ---- device vectors -------------------------------------------------------------------------------
+    def vec(self, space, data=None):
+        v = Vec(self, space)
+        if data is not None:
+            v.upload(data)
+        return v
+
+    def vecM(self, data=None):
+        return self.vec(SPACE_M, data)
+
+    def vecN(self, data=None):
+        return self.vec(SPACE_N, data)
+
+    def set_phen(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.size == self.N
+        v = Vec(self, SPACE_N)
+        self._ck(self.L.gv_set_phen(self.h, v.h, _dp(y)))
+        return v
+
+    def ax_dev(self, x, out):
+        self._ck(self.L.gv_ax_dev(self.h, x.h, out.h))
+
+    def atx_dev(self, p, out):
+        self._ck(self.L.gv_atx_dev(self.h, p.h, out.h))
+
+    def axpby(self, out, a, x, b=0.0, y=None):
+        self._ck(self.L.gv_vec_axpby(self.h, out.h, a, x.h, b, y.h if y is not None else None))
+
+    def copy(self, dst, src):
+        self._ck(self.L.gv_vec_copy(self.h, dst.h, src.h))
+
+    def dot(self, x, y, sync=1):
+        out = C.c_double()
+        self._ck(self.L.gv_vec_dot(self.h, x.h, y.h, sync, C.byref(out)))
+        return out.value
+
+    def dots(self, pairs, sync=1):
+        n = len(pairs)
+        xs = (C.c_void_p * n)(*[p[0].h for p in pairs])
+        ys = (C.c_void_p * n)(*[p[1].h for p in pairs])
+        out = np.empty(n)
+        self._ck(self.L.gv_vec_dots(self.h, n, xs, ys, sync, _dp(out)))
+        return out
+
+    def lmmse_mult(self, v, tau, gam2, out):
+        self._ck(self.L.gv_lmmse_mult(self.h, v.h, tau, gam2, out.h))
+
+    def cg_solve(self, v, mu_start, tau, gam2, denoiser, max_iter, mu_out):
+        st = CgStats()
+        rr = np.zeros(max(max_iter, 1))
+        self._ck(self.L.gv_cg_solve(self.h, v.h, mu_start.h if mu_start is not None else None, tau, gam2, denoiser,
+                                    max_iter, mu_out.h, C.byref(st), _dp(rr)))
+        return st, rr[:st.n_relres].copy()
+
+    def denoise(self, r1, gam1, probs, vars_scaled, x1_out, d_out=None):
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        vs = np.ascontiguousarray(vars_scaled, dtype=np.float64)
+        sums = np.empty(2)
+        self._ck(self.L.gv_denoise(self.h, r1.h, gam1, _dp(probs), _dp(vs), probs.size, x1_out.h,
+                                   d_out.h if d_out is not None else None, _dp(sums)))
+        return sums
+
+    def prior_estep(self, r1, gam1, lam, omegas, vars_scaled):
+        om = np.ascontiguousarray(omegas, dtype=np.float64)
+        vs = np.ascontiguousarray(vars_scaled, dtype=np.float64)
+        sums = np.empty(1 + 2 * (om.size - 1))
+        self._ck(self.L.gv_prior_estep(self.h, r1.h, gam1, lam, _dp(om), _dp(vs), om.size, _dp(sums)))
+        return sums
+
+    def allreduce_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self._ck(self.L.gv_allreduce_host(self.h, _dp(a), a.size))
+        return a
+
+    # ---- communicator / instrumentation --------------------------------------------------------------------
+    def comm_init(self, nranks, rank, uid):
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        self._ck(self.L.gv_comm_init(self.h, nranks, rank, buf))
+
+    def set_timing(self, on):
+        self._ck(self.L.gv_set_timing(self.h, int(on)))
+
+    def counters(self, reset=False):
+        c = Counters()
+        self._ck(self.L.gv_get_counters(self.h, C.byref(c)))
+        if reset:
+            self._ck(self.L.gv_reset_counters(self.h))
+        return dict(n_ax=c.n_ax, n_atx=c.n_atx, ms_ax=c.ms_ax, ms_atx=c.ms_atx, ms_allreduce=c.ms_allreduce)
+
+    def synchronize(self):
+        self._ck(self.L.gv_synchronize(self.h))
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        out = C.c_double()
+        self._ck(self.L.gv_copy_bandwidth(self.h, nbytes, reps, C.byref(out)))
+        return out.value

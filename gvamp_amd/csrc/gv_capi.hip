@@ -1,0 +1,626 @@
+// gv_capi.hip -- the C ABI of include/gvamp.h over the gfx950 kernels.  No CPU fallback anywhere: every
+// compute entry point launches HIP kernels on the context's stream or fails.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gv_internal.h"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(gv_ctx* c, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return 1;
+}
+
+#define HIPCHK(c, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCHK(c, call)                                                                     \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(c) HIPCHK(c, hipGetLastError())
+#define NEED(c, cond, msg)                 \
+    do {                                   \
+        if (!(cond)) return fail(c, msg);  \
+    } while (0)
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+int vec_new(gv_ctx* c, int space, gv_vec** out) {
+    NEED(c, c->N > 0, "gv_set_dims must be called first");
+    gv_vec* v = new gv_vec();
+    v->ctx = c;
+    v->space = space;
+    v->len = (space == GV_SPACE_M) ? c->M : 4 * c->mbytes;
+    v->cap = (space == GV_SPACE_M) ? (c->M > 0 ? c->M : 1) : c->npad;
+    v->d = nullptr;
+    hipError_t e = hipMalloc(&v->d, sizeof(double) * v->cap);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(c, "hipMalloc(%lld doubles) failed: %s", (long long)v->cap, hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(v->d, 0, sizeof(double) * v->cap, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(v->d);
+        delete v;
+        return fail(c, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    *out = v;
+    return 0;
+}
+
+int ensure_work(gv_ctx* c) {
+    if (!c->w_n) {
+        if (vec_new(c, GV_SPACE_N, &c->w_n)) return 1;
+        if (vec_new(c, GV_SPACE_M, &c->cg_r)) return 1;
+        if (vec_new(c, GV_SPACE_M, &c->cg_z)) return 1;
+        if (vec_new(c, GV_SPACE_M, &c->cg_p)) return 1;
+        if (vec_new(c, GV_SPACE_M, &c->cg_d)) return 1;
+    }
+    return 0;
+}
+
+// read K scalars produced by a reduction launcher back to the host (one sync)
+int read_scalars(gv_ctx* c, int K, double* out) {
+    HIPCHK(c, hipMemcpyAsync(c->host_pin, c->red_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->host_pin, sizeof(double) * K);
+    return 0;
+}
+
+// MPI_Allreduce(SUM, MPI_DOUBLE) of K host scalars (utilities.cpp:203): device round trip through RCCL
+int allreduce_scalars(gv_ctx* c, double* buf, int K) {
+    if (!c->comm || c->nranks == 1) return 0;
+    NEED(c, K <= RED_MAXK, "allreduce_scalars: too many scalars");
+    memcpy(c->host_pin, buf, sizeof(double) * K);
+    HIPCHK(c, hipMemcpyAsync(c->red_out, c->host_pin, sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->red_out, c->red_out, K, ncclDouble, ncclSum, c->comm, c->stream));
+    return read_scalars(c, K, buf);
+}
+
+struct Timer {
+    gv_ctx* c;
+    double* acc;
+    bool on;
+    Timer(gv_ctx* c_, double* acc_) : c(c_), acc(acc_), on(c_->timing != 0) {
+        if (on) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    void stop() {
+        if (!on) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        *acc += ms;
+        on = false;
+    }
+};
+
+// data::Ax on device pointers.  x: M doubles, out: npad doubles.
+int ax_device(gv_ctx* c, const double* x, double* out) {
+    NEED(c, c->bed && c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
+    const double scale = 1.0 / sqrt((double)c->N);
+    const bool multi = c->comm && c->nranks > 1;
+    {
+        Timer t(c, &c->cnt.ms_ax);
+        gvk::ax_table(c->stream, x, c->mave, c->msig, c->M, c->t3);
+        gvk::ax_f64(c->stream, c->bed, c->M, c->pitch, c->t3, c->ax_chunks, c->ax_partial, c->npad);
+        gvk::ax_reduce(c->stream, c->ax_partial, c->ax_chunks, c->npad, c->mask2, multi ? 1.0 : scale, out);
+        KCHK(c);
+        t.stop();
+    }
+    c->cnt.n_ax++;
+    if (multi) {   // data.cpp:995 MPI_Allreduce, then the 1/sqrt(N) of :998-1005
+        Timer t(c, &c->cnt.ms_allreduce);
+        NCCLCHK(c, ncclAllReduce(out, out, c->npad, ncclDouble, ncclSum, c->comm, c->stream));
+        gvk::scale_vec(c->stream, out, c->npad, scale);
+        KCHK(c);
+        t.stop();
+    }
+    return 0;
+}
+
+// data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
+int atx_device(gv_ctx* c, const double* p, double* out) {
+    NEED(c, c->bed && c->have_stats, "ATx: bed and marker statistics must be set first");
+    Timer t(c, &c->cnt.ms_atx);
+    gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
+    KCHK(c);
+    t.stop();
+    c->cnt.n_atx++;
+    return 0;
+}
+
+int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out) {
+    if (ensure_work(c)) return 1;
+    if (ax_device(c, v, c->w_n->d)) return 1;
+    if (atx_device(c, c->w_n->d, out)) return 1;
+    gvk::axpby(c->stream, out, tau, out, gam2, v, c->M);   // res = tau * A^T A v + gam2 v  (vamp.cpp:1112-1115)
+    KCHK(c);
+    return 0;
+}
+
+void free_dataset(gv_ctx* c) {
+    auto F = [](auto*& p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial);
+    for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d})
+        if (*v) {
+            (void)hipFree((*v)->d);
+            delete *v;
+            *v = nullptr;
+        }
+    c->have_stats = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gv_abi_version(void) { return GV_ABI_VERSION; }
+
+int gv_create(int device, gv_ctx** out) {
+    if (!out) return fail(nullptr, "gv_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, "gv_create: no HIP device available (%s); libgvamp has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, "gv_create: device %d out of range (0..%d)", device, ndev - 1);
+    gv_ctx* c = new gv_ctx();
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        fail(nullptr, "gv_create: %s failed: %s", what, hipGetErrorString(err));
+        delete c;
+        return 1;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(&c->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&c->red_out, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc(&c->host_pin, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipHostMalloc", e);
+    *out = c;
+    return 0;
+}
+
+void gv_destroy(gv_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    free_dataset(c);
+    if (c->red_partial) (void)hipFree(c->red_partial);
+    if (c->red_out) (void)hipFree(c->red_out);
+    if (c->host_pin) (void)hipHostFree(c->host_pin);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gv_last_error(const gv_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gv_synchronize(gv_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
+    NEED(c, N > 0 && M >= 0 && Mt >= M && S >= 0 && S + M <= Mt, "gv_set_dims: need N > 0, 0 <= M, S + M <= Mt");
+    HIPCHK(c, hipSetDevice(c->device));
+    free_dataset(c);
+    c->N = N; c->M = M; c->Mt = Mt; c->S = S;
+    c->mbytes = (N + 3) / 4;
+    c->pitch = align_up(c->mbytes, 64);
+    c->npad = 4 * c->pitch;
+    c->nonas = N;
+    const int64_t Mal = M > 0 ? M : 1;
+    HIPCHK(c, hipMalloc(&c->mave, sizeof(double) * Mal));
+    HIPCHK(c, hipMalloc(&c->msig, sizeof(double) * Mal));
+    HIPCHK(c, hipMalloc(&c->t3, sizeof(double) * 3 * Mal));
+    int64_t col_tiles = (c->pitch / 4 + 255) / 256;
+    int64_t chunks = (2048 + col_tiles - 1) / col_tiles;
+    if (chunks > 256) chunks = 256;
+    if (chunks > M) chunks = M > 0 ? M : 1;
+    if (chunks < 1) chunks = 1;
+    c->ax_chunks = (int)chunks;
+    HIPCHK(c, hipMalloc(&c->ax_partial, sizeof(double) * c->ax_chunks * c->npad));
+    return gv_set_mask(c, nullptr, N);
+}
+
+int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
+
+int gv_upload_bed(gv_ctx* c, const uint8_t* bed, size_t nbytes) {
+    NEED(c, c->N > 0, "gv_upload_bed: gv_set_dims must be called first");
+    NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_upload_bed: nbytes != M * ceil(N/4)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(c->M > 0 ? c->M : 1) * c->pitch));
+    HIPCHK(c, hipMemsetAsync(c->bed, 0, (size_t)(c->M > 0 ? c->M : 1) * c->pitch, c->stream));
+    if (c->M > 0)
+        HIPCHK(c, hipMemcpy2DAsync(c->bed, c->pitch, bed, c->mbytes, c->mbytes, c->M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_stats = false;
+    return 0;
+}
+
+int gv_synth_bed(gv_ctx* c, uint64_t seed, uint32_t miss_ppm) {
+    NEED(c, c->N > 0, "gv_synth_bed: gv_set_dims must be called first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(c->M > 0 ? c->M : 1) * c->pitch));
+    uint32_t thr = (uint32_t)(((uint64_t)miss_ppm << 32) / 1000000ull);
+    gvk::synth_bed(c->stream, c->bed, c->M, c->S, c->N, c->pitch, seed, thr);
+    KCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_stats = false;
+    return 0;
+}
+
+int gv_download_bed(gv_ctx* c, uint8_t* bed, size_t nbytes) {
+    NEED(c, c->bed, "gv_download_bed: no bed resident");
+    NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_download_bed: nbytes != M * ceil(N/4)");
+    if (c->M > 0)
+        HIPCHK(c, hipMemcpy2DAsync(bed, c->mbytes, c->bed, c->pitch, c->mbytes, c->M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gv_set_mask(gv_ctx* c, const uint8_t* mask4, int64_t nonas) {
+    NEED(c, c->N > 0, "gv_set_mask: gv_set_dims must be called first");
+    const int64_t P4 = c->pitch / 4;
+    std::vector<uint32_t> m2(P4, 0u);
+    for (int64_t n = 0; n < c->N; n++) {
+        bool present = mask4 ? ((mask4[n >> 2] >> (n & 3)) & 1u) : true;
+        if (present) m2[n >> 4] |= 3u << (2 * (n & 15));
+    }
+    if (!c->mask2) HIPCHK(c, hipMalloc(&c->mask2, sizeof(uint32_t) * P4));
+    HIPCHK(c, hipMemcpyAsync(c->mask2, m2.data(), sizeof(uint32_t) * P4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nonas = nonas;
+    c->have_stats = false;
+    return 0;
+}
+
+int gv_marker_stats(gv_ctx* c, double alpha_scale) {
+    NEED(c, c->bed && c->mask2, "gv_marker_stats: bed and mask must be set first");
+    gvk::marker_stats(c->stream, c->bed, c->mask2, c->M, c->pitch, (double)c->nonas, alpha_scale, c->mave, c->msig);
+    KCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_stats = true;
+    return 0;
+}
+
+int gv_get_marker_stats(gv_ctx* c, double* mave, double* msig) {
+    NEED(c, c->have_stats, "gv_get_marker_stats: gv_marker_stats has not run");
+    HIPCHK(c, hipMemcpyAsync(mave, c->mave, sizeof(double) * c->M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(msig, c->msig, sizeof(double) * c->M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gv_set_kernel_mode(gv_ctx* c, int mode) {
+    NEED(c, mode == 0, "gv_set_kernel_mode: only mode 0 (fp64 VALU) is built in this version");
+    c->kernel_mode = mode;
+    return 0;
+}
+int gv_get_kernel_mode(const gv_ctx* c) { return c->kernel_mode; }
+
+// ---- vectors --------------------------------------------------------------------------------------------
+int gv_vec_alloc(gv_ctx* c, int space, gv_vec** out) {
+    NEED(c, space == GV_SPACE_M || space == GV_SPACE_N, "gv_vec_alloc: bad space");
+    HIPCHK(c, hipSetDevice(c->device));
+    return vec_new(c, space, out);
+}
+void gv_vec_free(gv_ctx* c, gv_vec* v) {
+    if (!v) return;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(v->d);
+    delete v;
+}
+int64_t gv_vec_len(const gv_vec* v) { return v->len; }
+int gv_vec_upload(gv_ctx* c, gv_vec* v, const double* src) {
+    if (v->len > 0) HIPCHK(c, hipMemcpyAsync(v->d, src, sizeof(double) * v->len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gv_vec_download(gv_ctx* c, const gv_vec* v, double* dst) {
+    if (v->len > 0) HIPCHK(c, hipMemcpyAsync(dst, v->d, sizeof(double) * v->len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gv_vec_fill(gv_ctx* c, gv_vec* v, double value) {
+    gvk::fill(c->stream, v->d, v->len, value);
+    KCHK(c);
+    return 0;
+}
+int gv_vec_copy(gv_ctx* c, gv_vec* dst, const gv_vec* src) {
+    NEED(c, dst->space == src->space, "gv_vec_copy: space mismatch");
+    HIPCHK(c, hipMemcpyAsync(dst->d, src->d, sizeof(double) * src->cap, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int gv_vec_axpby(gv_ctx* c, gv_vec* out, double a, const gv_vec* x, double b, const gv_vec* y) {
+    NEED(c, out->space == x->space && (!y || y->space == x->space), "gv_vec_axpby: space mismatch");
+    NEED(c, y || b == 0.0, "gv_vec_axpby: y is NULL but b != 0");
+    gvk::axpby(c->stream, out->d, a, x->d, b, y ? y->d : nullptr, x->len);
+    KCHK(c);
+    return 0;
+}
+int gv_vec_dots(gv_ctx* c, int n, const gv_vec* const* x, const gv_vec* const* y, int sync, double* out) {
+    NEED(c, n >= 1 && n <= 8, "gv_vec_dots: 1 <= n <= 8");
+    const double *xs[8], *ys[8];
+    for (int k = 0; k < n; k++) {
+        NEED(c, x[k]->space == x[0]->space && y[k]->space == x[0]->space, "gv_vec_dots: space mismatch");
+        xs[k] = x[k]->d;
+        ys[k] = y[k]->d;
+    }
+    gvk::dots(c->stream, n, xs, ys, x[0]->len, c->red_partial, c->red_out);
+    KCHK(c);
+    if (sync && c->comm && c->nranks > 1)
+        NCCLCHK(c, ncclAllReduce(c->red_out, c->red_out, n, ncclDouble, ncclSum, c->comm, c->stream));
+    return read_scalars(c, n, out);
+}
+int gv_vec_dot(gv_ctx* c, const gv_vec* x, const gv_vec* y, int sync, double* out) {
+    return gv_vec_dots(c, 1, &x, &y, sync, out);
+}
+
+int gv_ax_dev(gv_ctx* c, const gv_vec* x, gv_vec* out) {
+    NEED(c, x->space == GV_SPACE_M && out->space == GV_SPACE_N, "gv_ax_dev: x must be M-space, out N-space");
+    return ax_device(c, x->d, out->d);
+}
+int gv_atx_dev(gv_ctx* c, const gv_vec* p, gv_vec* out) {
+    NEED(c, p->space == GV_SPACE_N && out->space == GV_SPACE_M, "gv_atx_dev: p must be N-space, out M-space");
+    return atx_device(c, p->d, out->d);
+}
+
+int gv_ax(gv_ctx* c, const double* x, double* out) {
+    if (ensure_work(c)) return 1;
+    HIPCHK(c, hipMemcpyAsync(c->cg_d->d, x, sizeof(double) * c->M, hipMemcpyHostToDevice, c->stream));
+    if (ax_device(c, c->cg_d->d, c->w_n->d)) return 1;
+    HIPCHK(c, hipMemcpyAsync(out, c->w_n->d, sizeof(double) * 4 * c->mbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gv_atx(gv_ctx* c, const double* p, double* out) {
+    if (ensure_work(c)) return 1;
+    // pad slots of w_n beyond 4*mbytes stay 0 (allocated zeroed, Ax writes 0 there)
+    HIPCHK(c, hipMemcpyAsync(c->w_n->d, p, sizeof(double) * 4 * c->mbytes, hipMemcpyHostToDevice, c->stream));
+    if (atx_device(c, c->w_n->d, c->cg_d->d)) return 1;
+    if (c->M > 0) HIPCHK(c, hipMemcpyAsync(out, c->cg_d->d, sizeof(double) * c->M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int gv_set_phen(gv_ctx* c, gv_vec* y_out, const double* y_host) {
+    NEED(c, y_out->space == GV_SPACE_N, "gv_set_phen: y_out must be N-space");
+    if (ensure_work(c)) return 1;
+    std::vector<double> tmp(c->npad, 0.0);
+    memcpy(tmp.data(), y_host, sizeof(double) * c->N);
+    HIPCHK(c, hipMemcpyAsync(c->w_n->d, tmp.data(), sizeof(double) * c->npad, hipMemcpyHostToDevice, c->stream));
+    gvk::mask_copy(c->stream, y_out->d, c->w_n->d, c->mask2, c->npad);
+    KCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- solver ---------------------------------------------------------------------------------------------
+int gv_lmmse_mult(gv_ctx* c, const gv_vec* v, double tau, double gam2, gv_vec* out) {
+    NEED(c, v->space == GV_SPACE_M && out->space == GV_SPACE_M && v != out, "gv_lmmse_mult: M-space, no aliasing");
+    return lmmse_device(c, v->d, tau, gam2, out->d);
+}
+
+// vamp::precondCG_solver (vamp.cpp:1130-1229).  Deviations, all result-neutral: <r,z> and ||v||
+// are computed once per step instead of three times / every step; lmmse_mult's all-zero shortcut (:1079) is
+// replaced by "mu_start == NULL"; the scalar reductions of one step travel in packed all-reduces.
+int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int denoiser,
+                int max_iter, gv_vec* mu_out, gv_cg_stats* st, double* relres) {
+    NEED(c, v->space == GV_SPACE_M && mu_out->space == GV_SPACE_M, "gv_cg_solve: M-space vectors required");
+    NEED(c, mu_out != v && mu_out != mu_start, "gv_cg_solve: mu_out must not alias v or mu_start");
+    if (ensure_work(c)) return 1;
+    const int64_t M = c->M;
+    hipStream_t s = c->stream;
+    double *r = c->cg_r->d, *z = c->cg_z->d, *p = c->cg_p->d, *d = c->cg_d->d, *mu = mu_out->d;
+    const bool multi = c->comm && c->nranks > 1;
+    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
+    const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
+    double sc[4];
+
+    if (mu_start) {
+        HIPCHK(c, hipMemcpyAsync(mu, mu_start->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+        if (lmmse_device(c, mu, tau, gam2, r)) return 1;
+        gvk::axpby(s, r, 1.0, v->d, -1.0, r, M);          // r = v - Q mu   (:1142-1145)
+    } else {
+        gvk::fill(s, mu, M, 0.0);
+        HIPCHK(c, hipMemcpyAsync(r, v->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+    }
+    // alpha = 0 pass: z = r / diag (:1152) and red_out = <r,z>, <z,z>, <r,r>, <mu,mu>
+    gvk::cg_step_b(s, r, d, 0.0, diag, z, mu, M, c->red_partial, c->red_out);
+    KCHK(c);
+    if (read_scalars(c, 4, sc)) return 1;
+    double rz = sc[0];
+    const double* vv[1] = {v->d};
+    gvk::dots(s, 1, vv, vv, M, c->red_partial, c->red_out);
+    KCHK(c);
+    double vn2;
+    if (read_scalars(c, 1, &vn2)) return 1;
+    if (multi) {
+        double pk[2] = {rz, vn2};
+        if (allreduce_scalars(c, pk, 2)) return 1;
+        rz = pk[0];
+        vn2 = pk[1];
+    }
+    const double norm_v = sqrt(vn2);
+    HIPCHK(c, hipMemcpyAsync(p, z, sizeof(double) * M, hipMemcpyDeviceToDevice, s));   // p = z (:1154)
+
+    double prev_onsager = 0, onsager = 0, rel_err = 0;
+    int iters = 0, converged = 0, n_relres = 0;
+    for (int i = 0; i < max_iter; i++) {
+        iters = i + 1;
+        if (lmmse_device(c, p, tau, gam2, d)) return 1;                   // d = Q p (:1165)
+        const double* xs[1] = {d};
+        const double* ys[1] = {p};
+        gvk::dots(s, 1, xs, ys, M, c->red_partial, c->red_out);
+        KCHK(c);
+        double dp;
+        if (read_scalars(c, 1, &dp)) return 1;
+        if (multi && allreduce_scalars(c, &dp, 1)) return 1;
+        const double alpha = rz / dp;                                      // :1167
+        gvk::cg_step_a(s, mu, p, alpha, v->d, M, c->red_partial, c->red_out);   // mu += alpha p (:1169-1172)
+        KCHK(c);
+        if (denoiser == 0) {                                               // :1174-1193
+            double vm;
+            if (read_scalars(c, 1, &vm)) return 1;
+            if (multi && allreduce_scalars(c, &vm, 1)) return 1;
+            onsager = gam2 * vm;
+            double oerr = (onsager != 0) ? fabs((onsager - prev_onsager) / onsager) : 1.0;
+            if (oerr < 1e-8) {
+                converged = 1;
+                break;
+            }
+            prev_onsager = onsager;
+        }
+        gvk::cg_step_b(s, r, d, alpha, diag, z, mu, M, c->red_partial, c->red_out);   // :1195-1216
+        KCHK(c);
+        if (read_scalars(c, 4, sc)) return 1;
+        if (multi && allreduce_scalars(c, sc, 4)) return 1;
+        const double beta = sc[0] / rz;                                    // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
+        rz = sc[0];
+        gvk::axpby(s, p, 1.0, z, beta, p, M);                              // p = z + beta p (:1209-1210)
+        KCHK(c);
+        rel_err = sqrt(sc[2]) / norm_v;                                    // :1215
+        if (relres) relres[i] = rel_err;
+        n_relres = i + 1;
+        if (rel_err < 1e-5) {                                              // :1217,:1222
+            converged = 1;
+            break;
+        }
+    }
+    if (st) {
+        st->iters = iters;
+        st->converged = converged;
+        st->rel_res = rel_err;
+        st->onsager = onsager;
+        st->n_ax = (int)(c->cnt.n_ax - ax0);
+        st->n_atx = (int)(c->cnt.n_atx - atx0);
+        st->n_relres = n_relres;
+    }
+    return 0;
+}
+
+// ---- denoiser side ------------------------------------------------------------------------------------------
+static int fill_prior(gv_ctx* c, gv_prior& pr, const double* probs, const double* vars, int L) {
+    NEED(c, L >= 1 && L <= GV_LMAX, "prior: 1 <= L <= 32");
+    pr.L = L;
+    for (int i = 0; i < GV_LMAX; i++) {
+        pr.probs[i] = i < L ? probs[i] : 0.0;
+        pr.vars[i] = i < L ? vars[i] : 0.0;
+    }
+    return 0;
+}
+
+int gv_denoise(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+               gv_vec* x1_out, gv_vec* d_out, double* sums2) {
+    NEED(c, r1->space == GV_SPACE_M && x1_out->space == GV_SPACE_M, "gv_denoise: M-space vectors required");
+    gv_prior pr;
+    if (fill_prior(c, pr, probs, vars, L)) return 1;
+    gvk::denoise(c->stream, r1->d, c->M, gam1, pr, x1_out->d, d_out ? d_out->d : nullptr, c->red_partial, c->red_out);
+    KCHK(c);
+    return read_scalars(c, 2, sums2);
+}
+
+int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                   const double* vars, int L, double* sums) {
+    NEED(c, r1->space == GV_SPACE_M, "gv_prior_estep: M-space vector required");
+    NEED(c, L >= 2, "gv_prior_estep: L >= 2");
+    gv_prior pr;
+    if (fill_prior(c, pr, omegas, vars, L)) return 1;
+    gvk::prior_estep(c->stream, r1->d, c->M, gam1, lambda, pr, c->red_partial, c->red_out);
+    KCHK(c);
+    return read_scalars(c, 1 + 2 * (L - 1), sums);
+}
+
+int gv_allreduce_host(gv_ctx* c, double* buf, int n) {
+    for (int off = 0; off < n; off += RED_MAXK) {
+        int k = n - off < RED_MAXK ? n - off : RED_MAXK;
+        if (allreduce_scalars(c, buf + off, k)) return 1;
+    }
+    return 0;
+}
+
+// ---- communicator ---------------------------------------------------------------------------------------------
+int gv_comm_unique_id(void* id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+    memcpy(id128, &id, 128);
+    return 0;
+}
+int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
+    NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init: bad rank / nranks");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) {
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->rank = rank;
+    c->nranks = nranks;
+    if (nranks == 1) return 0;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    return 0;
+}
+int gv_comm_rank(const gv_ctx* c) { return c->rank; }
+int gv_comm_size(const gv_ctx* c) { return c->nranks; }
+
+// ---- instrumentation ----------------------------------------------------------------------------------------------
+int gv_set_timing(gv_ctx* c, int timing) {
+    c->timing = timing;
+    return 0;
+}
+int gv_get_counters(gv_ctx* c, gv_counters* out) {
+    *out = c->cnt;
+    return 0;
+}
+int gv_reset_counters(gv_ctx* c) {
+    c->cnt = gv_counters{};
+    return 0;
+}
+int gv_copy_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {
+    double *a = nullptr, *b = nullptr;
+    int64_t n = (int64_t)(nbytes / 16) * 2;
+    HIPCHK(c, hipMalloc(&a, n * 8));
+    HIPCHK(c, hipMalloc(&b, n * 8));
+    HIPCHK(c, hipMemsetAsync(a, 1, n * 8, c->stream));
+    gvk::copy_bw(c->stream, a, b, n);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; i++) gvk::copy_bw(c->stream, a, b, n);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *gbps = 2.0 * n * 8 * reps / (ms * 1e-3) / 1e9;
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// gv_internal.h -- context layout and kernel-launch prototypes shared by the libgvamp translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "gvamp.h"
+
+struct gv_vec {
+    gv_ctx* ctx;
+    int space;      // GV_SPACE_M / GV_SPACE_N
+    int64_t len;    // logical length (M or 4*mbytes)
+    int64_t cap;    // allocated doubles (M or npad); the tail beyond len is kept at 0
+    double* d;
+};
+
+struct gv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // dataset ------------------------------------------------------------------------------------
+    int64_t N = 0, M = 0, Mt = 0, S = 0;
+    int64_t mbytes = 0;   // ceil(N/4)
+    int64_t pitch = 0;    // bytes per marker row in HBM (multiple of 64)
+    int64_t npad = 0;     // 4 * pitch : device length of every N-space vector
+    uint8_t* bed = nullptr;     // M * pitch, marker-major 2-bit, pad bytes 0
+    uint32_t* mask2 = nullptr;  // pitch/4 words: bits 2q and 2q+1 set iff individual 16j+q has a phenotype
+    int64_t nonas = 0;
+    double* mave = nullptr;
+    double* msig = nullptr;
+    bool have_stats = false;
+    int kernel_mode = 0;
+
+    // workspaces ---------------------------------------------------------------------------------
+    double* t3 = nullptr;          // 3*M: per-marker Ax table {(2-mu)c, (1-mu)c, (0-mu)c}
+    double* ax_partial = nullptr;  // ax_chunks * npad
+    int ax_chunks = 0;
+    double* red_partial = nullptr; // RED_BLOCKS * RED_MAXK block partials
+    double* red_out = nullptr;     // RED_MAXK device scalars
+    double* host_pin = nullptr;    // pinned, RED_MAXK doubles
+    gv_vec *w_n = nullptr;                                   // N-space scratch (lmmse_mult)
+    gv_vec *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_d = nullptr;  // CG work vectors
+
+    // communicator ---------------------------------------------------------------------------------
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    // instrumentation ------------------------------------------------------------------------------
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    gv_counters cnt{};
+};
+
+constexpr int RED_BLOCKS = 1024;
+constexpr int RED_MAXK = 80;   // >= 1 + 2*(LMAX-1) with LMAX = 32
+constexpr int GV_LMAX = 32;
+
+struct gv_prior {
+    int L;
+    double probs[GV_LMAX];
+    double vars[GV_LMAX];
+};
+
+// ---- kernel launchers (gv_kernels.hip) -----------------------------------------------------------
+namespace gvk {
+void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
+               uint32_t miss_thr);
+void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
+                  double alpha_scale, double* mave, double* msig);
+void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3);
+void ax_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* t3, int chunks,
+            double* partial, int64_t npad);
+void ax_reduce(hipStream_t s, const double* partial, int chunks, int64_t npad, const uint32_t* mask2, double scale,
+               double* out);
+void scale_vec(hipStream_t s, double* v, int64_t n, double a);
+void atx_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p, const double* mave,
+             const double* msig, double scale, double* out);
+void fill(hipStream_t s, double* v, int64_t n, double a);
+void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n);
+void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad);
+// K dot products <x[k], y[k]> over n elements -> red_out[0..K)
+void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
+          double* out);
+void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,
+               double* partial, double* out);                 // mu += alpha p ; out[0] = <v, mu>
+void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double diag, double* z, const double* mu,
+               int64_t n, double* partial, double* out);      // r -= alpha d ; z = r/diag ; out = <r,z>,<z,z>,<r,r>,<mu,mu>
+void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_prior& pr, double* x1, double* dd,
+             double* partial, double* out);                   // out[0] = sum g1d, out[1] = sum (x1-r1)^2
+void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& om_vars,
+                 double* partial, double* out);               // out[0..1+2(L-1))
+void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n);
+}  // namespace gvk

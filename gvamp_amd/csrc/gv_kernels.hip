@@ -1,0 +1,523 @@
+// gv_kernels.hip -- gfx950 kernels of libgvamp (fp64 VALU family + element-wise / reduction kernels).
+//
+// HBM layout of the genotype shard: marker-major rows of `pitch` bytes (pitch % 64 == 0, pad bytes 0), PLINK
+// 2-bit codes, individual 4j+k in bits 2k..2k+1 of byte j (data.cpp:201-234 keeps the same bytes, unpadded).
+// A 32-bit word of a row therefore holds 16 consecutive individuals, individual q at bits 2q..2q+1.
+// Decode (dotp_lut.hpp:3,1030): code 00 -> a=2, 10 -> a=1, 11 -> a=0, 01 -> missing (a=0, b=0).
+#include "gv_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+// block of 256 threads: sum of v over the block, valid in thread 0.  sh: 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// ---- synthetic shard (SURVEY 8d recipe, integer-only so the host generator matches bit for bit) ---------
+// marker g (global index): maf = (3277 + h % 29491) / 65536 in [0.05, 0.5); genotype ~ Binomial(2, maf);
+// missing with probability miss_thr / 2^32.  Codes: 2 -> 00, 1 -> 10, 0 -> 11, missing -> 01.
+__global__ void k_synth_bed(uint32_t* bed, int64_t M, int64_t S, int64_t N, int64_t P4, uint64_t seed,
+                            uint32_t miss_thr) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * P4) return;
+    int64_t m = idx / P4, j = idx % P4;
+    uint64_t g = (uint64_t)(S + m);
+    uint64_t hm = splitmix64(seed ^ (g * 0xD1342543DE82EF95ull));
+    uint32_t maf = 3277u + (uint32_t)(hm % 29491ull);
+    uint32_t qv = 65536u - maf;
+    uint32_t p0 = qv * qv;              // P(geno 0) * 2^32  (qv <= 62259 -> fits)
+    uint32_t p1 = 2u * maf * qv;        // P(geno 1) * 2^32
+    uint64_t base = splitmix64(hm + 0x632BE59BD9B4E019ull);
+    uint32_t w = 0;
+    for (int q = 0; q < 16; q++) {
+        int64_t n = 16 * j + q;
+        if (n >= N) break;
+        uint64_t r = splitmix64(base + (uint64_t)n);
+        uint32_t u = (uint32_t)(r >> 32), um = (uint32_t)r;
+        uint32_t code;
+        if (um < miss_thr) code = 1u;
+        else if (u < p0) code = 3u;
+        else if (u - p0 < p1) code = 2u;
+        else code = 0u;
+        w |= code << (2 * q);
+    }
+    bed[idx] = w;
+}
+
+// ---- compute_markers_statistics (data.cpp:451-484), count form ------------------------------------------
+// One wave per marker.  n2/n1/n0 = number of present individuals with a = 2/1/0 (b = 1); the masked sums of
+// the reference are then exact integers: suma = 2 n2 + n1, sumb = n0 + n1 + n2,
+// sumsqr = n2 (2-mu)^2 + n1 (1-mu)^2 + n0 mu^2.
+__global__ __launch_bounds__(256) void k_marker_stats(const uint32_t* __restrict__ bed,
+                                                      const uint32_t* __restrict__ mask2, int64_t M, int64_t P4,
+                                                      double nonas, double alpha_scale, double* __restrict__ mave,
+                                                      double* __restrict__ msig) {
+    int lane = threadIdx.x & 63;
+    int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const uint32_t* row = bed + m * P4;
+    uint32_t n2 = 0, n1 = 0, n0 = 0;
+    for (int64_t j = lane; j < P4; j += WAVE) {
+        uint32_t w = row[j], pm = mask2[j] & 0x55555555u;
+        uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+        n2 += __popc(~lo & ~hi & pm);
+        n1 += __popc(hi & ~lo & pm);
+        n0 += __popc(hi & lo & pm);
+    }
+    n2 = wave_sum_u32(n2);
+    n1 = wave_sum_u32(n1);
+    n0 = wave_sum_u32(n0);
+    if (lane == 0) {
+        double suma = 2.0 * n2 + 1.0 * n1, sumb = (double)n0 + (double)n1 + (double)n2;
+        double mu = (sumb != 0) ? suma / sumb : 0.0;
+        double sumsqr = n2 * ((2.0 - mu) * (2.0 - mu)) + n1 * ((1.0 - mu) * (1.0 - mu)) + n0 * (mu * mu);
+        double sg;
+        if (sumsqr != 0) {
+            if (alpha_scale == 1.0) sg = 1.0 / sqrt(sumsqr / (nonas - 1.0));
+            else sg = 1.0 / pow(sqrt(sumsqr / (nonas - 1.0)), alpha_scale);
+        } else
+            sg = 1.0;
+        mave[m] = mu;
+        msig[m] = sg;
+    }
+}
+
+// ---- data::Ax (data.cpp:951-1007), fp64 VALU family ------------------------------------------------------
+// per-marker table: c = msig*x ; t = {(2-mu)c, (1-mu)c, (0-mu)c} = the three non-zero values of
+// (a - ave) * sig_phen_i * b of data.cpp:972.
+__global__ void k_ax_table(const double* __restrict__ x, const double* __restrict__ mave,
+                           const double* __restrict__ msig, int64_t M, double* __restrict__ t3) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double c = msig[i] * x[i], mu = mave[i];
+    t3[3 * i + 0] = (2.0 - mu) * c;
+    t3[3 * i + 1] = (1.0 - mu) * c;
+    t3[3 * i + 2] = (0.0 - mu) * c;
+}
+
+// A thread owns one 32-bit column (16 individuals, accumulators in registers) and walks a chunk of markers;
+// consecutive threads read consecutive words of the row (coalesced 1 KiB per block per marker).
+// grid = (column tiles, marker chunks); partial sums per chunk are combined by k_ax_reduce in chunk order.
+__global__ __launch_bounds__(256) void k_ax_f64(const uint32_t* __restrict__ bed, int64_t M, int64_t P4,
+                                                const double* __restrict__ t3, int64_t mpc,
+                                                double* __restrict__ partial, int64_t npad) {
+    int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t m0 = (int64_t)blockIdx.y * mpc, m1 = m0 + mpc < M ? m0 + mpc : M;
+    if (col >= P4) return;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.0;
+    const uint32_t* colp = bed + col;
+#pragma unroll 4
+    for (int64_t m = m0; m < m1; ++m) {
+        uint32_t w = colp[m * P4];
+        double t2 = t3[3 * m], t1 = t3[3 * m + 1], t0 = t3[3 * m + 2];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            uint32_t code = (w >> (2 * q)) & 3u;
+            double v = (code == 0u) ? t2 : (code == 2u) ? t1 : (code == 3u) ? t0 : 0.0;
+            acc[q] += v;
+        }
+    }
+    double2* dst = reinterpret_cast<double2*>(partial + (int64_t)blockIdx.y * npad + col * 16);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[q] = make_double2(acc[2 * q], acc[2 * q + 1]);
+}
+
+// out[n] = mask[n] * scale * sum_chunks partial[chunk][n]   (na_lut factor of data.cpp:972; scale :998-1005
+// is applied here only when no cross-rank all-reduce follows, otherwise scale = 1 and k_scale runs after it)
+__global__ void k_ax_reduce(const double* __restrict__ partial, int chunks, int64_t npad,
+                            const uint32_t* __restrict__ mask2, double scale, double* __restrict__ out) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npad) return;
+    double s = 0.0;
+    for (int c = 0; c < chunks; c++) s += partial[(int64_t)c * npad + n];
+    uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+    out[n] = present ? s * scale : 0.0;
+}
+
+__global__ void k_scale(double* v, int64_t n, double a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= a;
+}
+
+// ---- data::ATx (data.cpp:810-835 over dot_product :758-779), fp64 VALU family ---------------------------------
+// A wave handles MW markers over the whole row: the 16 phenotype values of a lane's word are loaded once and
+// used for MW markers; per-marker partial sums stay in registers until one wave reduction at the end.
+template <int MW>
+__global__ __launch_bounds__(256) void k_atx_f64(const uint32_t* __restrict__ bed, int64_t M, int64_t P4,
+                                                 const double* __restrict__ p, const double* __restrict__ mave,
+                                                 const double* __restrict__ msig, double scale,
+                                                 double* __restrict__ out) {
+    int lane = threadIdx.x & 63;
+    int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * MW;
+    if (m0 >= M) return;
+    double sa[MW], sb[MW];
+#pragma unroll
+    for (int k = 0; k < MW; k++) sa[k] = sb[k] = 0.0;
+    for (int64_t j = lane; j < P4; j += WAVE) {
+        uint32_t w[MW];
+#pragma unroll
+        for (int k = 0; k < MW; k++) w[k] = (m0 + k < M) ? bed[(m0 + k) * P4 + j] : 0x55555555u;
+        const double2* pp = reinterpret_cast<const double2*>(p + j * 16);
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            double2 pv = pp[h];
+#pragma unroll
+            for (int k = 0; k < MW; k++) {
+                uint32_t c0 = (w[k] >> (4 * h)) & 3u, c1 = (w[k] >> (4 * h + 2)) & 3u;
+                sa[k] += (c0 == 0u) ? 2.0 * pv.x : (c0 == 2u) ? pv.x : 0.0;
+                sb[k] += (c0 == 1u) ? 0.0 : pv.x;
+                sa[k] += (c1 == 0u) ? 2.0 * pv.y : (c1 == 2u) ? pv.y : 0.0;
+                sb[k] += (c1 == 1u) ? 0.0 : pv.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MW; k++) {
+        double a = wave_sum(sa[k]), b = wave_sum(sb[k]);
+        if (lane == 0 && m0 + k < M) out[m0 + k] = msig[m0 + k] * (a - mave[m0 + k] * b) * scale;
+    }
+}
+
+// ---- element-wise ------------------------------------------------------------------------------------------
+__global__ void k_fill(double* v, int64_t n, double a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = a;
+}
+__global__ void k_axpby(double* out, double a, const double* x, double b, const double* y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (y ? a * x[i] + b * y[i] : a * x[i]);
+}
+__global__ void k_mask_copy(double* out, const double* in, const uint32_t* mask2, int64_t npad) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npad) return;
+    uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+    out[n] = present ? in[n] : 0.0;
+}
+__global__ void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, int64_t n2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) dst[i] = src[i];
+}
+
+// ---- reductions: block partials -> one ordered final pass (deterministic; SURVEY 7 parity trap d) ------------
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, int nblocks, int K,
+                                                  double* __restrict__ out) {
+    __shared__ double sh[256];
+    for (int k = 0; k < K; k++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * K + k];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = sh[0];
+        __syncthreads();
+    }
+}
+
+struct DotArgs {
+    const double* x[8];
+    const double* y[8];
+};
+__global__ __launch_bounds__(256) void k_dots(DotArgs a, int K, int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    int64_t stride = (int64_t)gridDim.x * 256;
+    for (int k = 0; k < K; k++) {
+        const double *x = a.x[k], *y = a.y[k];
+        double s = 0.0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+        s = block_sum_256(s, sh);
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * K + k] = s;
+    }
+}
+
+// vamp.cpp:1169-1176 : mu += alpha p ; partial of <v, mu>
+__global__ __launch_bounds__(256) void k_cg_a(double* __restrict__ mu, const double* __restrict__ p, double alpha,
+                                              const double* __restrict__ v, int64_t n,
+                                              double* __restrict__ partial) {
+    __shared__ double sh[4];
+    int64_t stride = (int64_t)gridDim.x * 256;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double palpha = alpha * p[i];
+        double m = mu[i] + palpha;
+        mu[i] = m;
+        s += v[i] * m;
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// vamp.cpp:1195-1216 : r -= alpha d ; z = r / diag ; partials of <r,z>, <z,z>, <r,r>, <mu,mu>
+__global__ __launch_bounds__(256) void k_cg_b(double* __restrict__ r, const double* __restrict__ d, double alpha,
+                                              double diag, double* __restrict__ z, const double* __restrict__ mu,
+                                              int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    int64_t stride = (int64_t)gridDim.x * 256;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double ri = r[i];
+        if (alpha != 0.0) ri -= d[i] * alpha;   // alpha == 0: initialisation pass (z = r/diag, norms), d unread
+        double zi = ri / diag;
+        r[i] = ri;
+        z[i] = zi;
+        double m = mu[i];
+        s0 += ri * zi;
+        s1 += zi * zi;
+        s2 += ri * ri;
+        s3 += m * m;
+    }
+    s0 = block_sum_256(s0, sh);
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    s3 = block_sum_256(s3, sh);
+    if (threadIdx.x == 0) {
+        double* o = partial + (int64_t)blockIdx.x * 4;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+    }
+}
+
+// vamp::g1 / g1d (vamp.cpp:805-869), same operation order per element
+__device__ __forceinline__ void g1_g1d(double y, double gam1, const gv_prior& pr, double eta_max, double& g1,
+                                       double& g1d) {
+    double sigma = 1 / gam1;
+    if (sigma < 1e-10 && sigma > -1e-10) {
+        g1 = y;
+        g1d = 1;
+        return;
+    }
+    double pk = 0, pkd = 0, pkdd = 0;
+    for (int i = 0; i < pr.L; i++) {
+        double vs = pr.vars[i] + sigma;
+        double expe_sum = -0.5 * (y * y) * (eta_max - pr.vars[i]) / vs / (eta_max + sigma);
+        double e = exp(expe_sum);
+        double z = pr.probs[i] / sqrt(vs) * e;
+        pk = pk + z;
+        z = z / vs * y;
+        pkd = pkd - z;
+        double z2 = z / vs * y;
+        pkdd = pkdd - pr.probs[i] / (vs * sqrt(vs)) * e + z2;
+    }
+    g1 = y + sigma * pkd / pk;
+    double q = pkd / pk;
+    g1d = 1 + sigma * (pkdd / pk - q * q);
+}
+
+// vamp.cpp:292-310 fused: x1 = g1(r1), d = g1d(r1), partials of sum d and sum (x1 - r1)^2
+__global__ __launch_bounds__(256) void k_denoise(const double* __restrict__ r1, int64_t n, double gam1, gv_prior pr,
+                                                 double* __restrict__ x1, double* __restrict__ dd,
+                                                 double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double eta_max = pr.vars[0];
+    for (int i = 1; i < pr.L; i++) eta_max = fmax(eta_max, pr.vars[i]);
+    int64_t stride = (int64_t)gridDim.x * 256;
+    double s0 = 0, s1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double y = r1[i], g, gd;
+        g1_g1d(y, gam1, pr, eta_max, g, gd);
+        x1[i] = g;
+        if (dd) dd[i] = gd;
+        s0 += gd;
+        s1 += (g - y) * (g - y);
+    }
+    s0 = block_sum_256(s0, sh);
+    s1 = block_sum_256(s1, sh);
+    if (threadIdx.x == 0) {
+        partial[(int64_t)blockIdx.x * 2] = s0;
+        partial[(int64_t)blockIdx.x * 2 + 1] = s1;
+    }
+}
+
+// vamp::updatePrior E-step (vamp.cpp:953-1013).  pr.probs[j] holds omegas[j] (j >= 1), pr.vars[j] the variances.
+// 64-thread blocks; per-thread accumulators and the num_j scratch live in LDS columns (no bank conflicts).
+__global__ __launch_bounds__(64) void k_prior_estep(const double* __restrict__ r1, int64_t n, double gam1,
+                                                    double lambda, gv_prior pr, double* __restrict__ partial) {
+    __shared__ double sh_num[GV_LMAX - 1][64];
+    __shared__ double sh_R[GV_LMAX - 1][64];
+    __shared__ double sh_G[GV_LMAX - 1][64];
+    const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
+    const double noise_var = 1 / gam1;
+    double max_sigma = pr.vars[0];
+    for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
+    for (int j = 0; j < Lm1; j++) sh_R[j][t] = sh_G[j][t] = 0.0;
+    double acc_pin = 0.0;
+    int64_t stride = (int64_t)gridDim.x * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
+        double r = r1[i], sum_of_elems = 0.0;
+        for (int j = 1; j < pr.L; j++) {
+            double num = lambda * pr.probs[j] *
+                         exp(-(r * r) / 2 * (max_sigma - pr.vars[j]) / (pr.vars[j] + noise_var) / (max_sigma + noise_var)) /
+                         sqrt(pr.vars[j] + noise_var) / sqrt(2 * M_PI);
+            sh_num[j - 1][t] = num;
+            sum_of_elems += num;
+        }
+        double pin = 1 / (1 + (1 - lambda) / sqrt(2 * M_PI * noise_var) *
+                                  exp(-(r * r) / 2 * max_sigma / noise_var / (noise_var + max_sigma)) / sum_of_elems);
+        acc_pin += pin;
+        for (int j = 1; j < pr.L; j++) {
+            double beta = sh_num[j - 1][t] / sum_of_elems;
+            double gm = gam1 * r / (1 / pr.vars[j] + gam1);
+            double vj = 1.0 / (1.0 / pr.vars[j] + gam1);
+            double gg = beta * (gm * gm + vj);
+            sh_R[j - 1][t] += beta * pin;
+            sh_G[j - 1][t] += gg * pin;
+        }
+    }
+    double* o = partial + (int64_t)blockIdx.x * K;
+    double s = wave_sum(acc_pin);
+    if (t == 0) o[0] = s;
+    for (int j = 0; j < Lm1; j++) {
+        double a = wave_sum(sh_R[j][t]), b = wave_sum(sh_G[j][t]);
+        if (t == 0) {
+            o[1 + 2 * j] = a;
+            o[2 + 2 * j] = b;
+        }
+    }
+}
+
+inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+inline int red_blocks(int64_t n, int bs) {
+    int64_t b = (n + bs - 1) / bs;
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
+
+}  // namespace
+
+namespace gvk {
+
+void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
+               uint32_t miss_thr) {
+    int64_t P4 = pitch / 4, tot = M * P4;
+    if (tot == 0) return;
+    hipLaunchKernelGGL(k_synth_bed, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (uint32_t*)bed, M, S, N, P4,
+                       seed, miss_thr);
+}
+
+void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
+                  double alpha_scale, double* mave, double* msig) {
+    if (M == 0) return;
+    hipLaunchKernelGGL(k_marker_stats, dim3(nblk(M, 4)), dim3(256), 0, s, (const uint32_t*)bed, mask2, M, pitch / 4,
+                       nonas, alpha_scale, mave, msig);
+}
+
+void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3) {
+    if (M == 0) return;
+    hipLaunchKernelGGL(k_ax_table, dim3(nblk(M, 256)), dim3(256), 0, s, x, mave, msig, M, t3);
+}
+
+void ax_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* t3, int chunks,
+            double* partial, int64_t npad) {
+    int64_t P4 = pitch / 4;
+    int64_t mpc = (M + chunks - 1) / chunks;
+    if (mpc < 1) mpc = 1;
+    hipLaunchKernelGGL(k_ax_f64, dim3(nblk(P4, 256), chunks), dim3(256), 0, s, (const uint32_t*)bed, M, P4, t3, mpc,
+                       partial, npad);
+}
+
+void ax_reduce(hipStream_t s, const double* partial, int chunks, int64_t npad, const uint32_t* mask2, double scale,
+               double* out) {
+    hipLaunchKernelGGL(k_ax_reduce, dim3(nblk(npad, 256)), dim3(256), 0, s, partial, chunks, npad, mask2, scale, out);
+}
+
+void scale_vec(hipStream_t s, double* v, int64_t n, double a) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_scale, dim3(nblk(n, 256)), dim3(256), 0, s, v, n, a);
+}
+
+void atx_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p, const double* mave,
+             const double* msig, double scale, double* out) {
+    if (M == 0) return;
+    constexpr int MW = 8;
+    hipLaunchKernelGGL(k_atx_f64<MW>, dim3(nblk(M, 4 * MW)), dim3(256), 0, s, (const uint32_t*)bed, M, pitch / 4, p,
+                       mave, msig, scale, out);
+}
+
+void fill(hipStream_t s, double* v, int64_t n, double a) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill, dim3(nblk(n, 256)), dim3(256), 0, s, v, n, a);
+}
+
+void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s, out, a, x, b, y, n);
+}
+
+void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad) {
+    hipLaunchKernelGGL(k_mask_copy, dim3(nblk(npad, 256)), dim3(256), 0, s, out, in, mask2, npad);
+}
+
+void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
+          double* out) {
+    DotArgs a{};
+    for (int k = 0; k < K; k++) {
+        a.x[k] = x[k];
+        a.y[k] = y[k];
+    }
+    int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_dots, dim3(nb), dim3(256), 0, s, a, K, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, K, out);
+}
+
+void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n, double* partial,
+               double* out) {
+    int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_cg_a, dim3(nb), dim3(256), 0, s, mu, p, alpha, v, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, out);
+}
+
+void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double diag, double* z, const double* mu,
+               int64_t n, double* partial, double* out) {
+    int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_cg_b, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, mu, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 4, out);
+}
+
+void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_prior& pr, double* x1, double* dd,
+             double* partial, double* out) {
+    int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_denoise, dim3(nb), dim3(256), 0, s, r1, n, gam1, pr, x1, dd, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 2, out);
+}
+
+void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& pr,
+                 double* partial, double* out) {
+    int nb = red_blocks(n, 64);
+    int K = 1 + 2 * (pr.L - 1);
+    hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, K, out);
+}
+
+void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n) {
+    hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, s, (const double2*)src, (double2*)dst, n / 2);
+}
+
+}  // namespace gvk

@@ -1,0 +1,140 @@
+/* gvamp.h -- C ABI of libgvamp.so: the MI355X (gfx950) engine behind gVAMP's `class data` / `class vamp`
+ * seam for the linear model.
+ *
+ * The reference has no plugin ABI; its seam is the C++ class `data` handed to `vamp` by pointer
+ * (/root/reference/vamp.hpp:85-143, data.hpp:93-140).  Each entry point below names the reference
+ * interface it replaces.  INTEGRATION.md shows the reference-side binding (a `data` subclass whose
+ * Ax/ATx forward here).
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (message via gv_last_error);
+ * no exceptions cross the ABI; all `const T*` / `T*` arguments are caller-owned HOST memory unless the
+ * parameter is a gv_vec handle (device-resident fp64 vector owned by the context).  One context = one
+ * marker shard on one GPU (the reference: one MPI rank, utilities.cpp:259-291).  Not thread-safe per
+ * context; different contexts may be driven from different threads.
+ *
+ * There is NO CPU fallback: without a usable HIP device gv_create fails.
+ */
+#ifndef GVAMP_H
+#define GVAMP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gv_ctx gv_ctx;
+typedef struct gv_vec gv_vec;
+
+#define GV_ABI_VERSION 1
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int gv_abi_version(void);
+/* device: HIP ordinal.  Replaces nothing in the reference (it has no device boundary). */
+int gv_create(int device, gv_ctx** out);
+void gv_destroy(gv_ctx* ctx);
+/* ctx may be NULL: returns the message of the last failed gv_create on this thread. */
+const char* gv_last_error(const gv_ctx* ctx);
+int gv_synchronize(gv_ctx* ctx);
+
+/* ---- dataset: `data` constructors (data.cpp:30-113) ------------------------------------------------
+ * N individuals, M local markers, Mt total markers, S first local marker (divide_work, utilities.cpp:259). */
+int gv_set_dims(gv_ctx* ctx, int64_t N, int64_t M, int64_t Mt, int64_t S);
+int64_t gv_mbytes(const gv_ctx* ctx);  /* ceil(N/4), data.cpp:40 */
+/* bed: M*mbytes bytes, marker-major PLINK 2-bit, WITHOUT the 3 magic bytes: what read_genotype_data
+ * (data.cpp:201-234) leaves in bed_data.  Copied to HBM (row pitch padded to 64 B) and kept resident. */
+int gv_upload_bed(gv_ctx* ctx, const uint8_t* bed, size_t nbytes);
+/* Synthetic shard generated on the device (bench / tests; SURVEY 8d recipe with an integer hash so that
+ * gvamp_amd.synth.synth_bed() reproduces it bit for bit on the host).  miss_ppm: missing rate in 1e-6. */
+int gv_synth_bed(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm);
+int gv_download_bed(gv_ctx* ctx, uint8_t* bed, size_t nbytes);
+/* mask4: mbytes nibbles (data.hpp:36; bit k of mask4[j] = individual 4j+k has a phenotype and 4j+k < N);
+ * NULL = every individual present (vector-phenotype ctor, data.cpp:86-100).  nonas: data.cpp:100/:150. */
+int gv_set_mask(gv_ctx* ctx, const uint8_t* mask4, int64_t nonas);
+/* compute_markers_statistics (data.cpp:392-546, scalar-path semantics :451-484). */
+int gv_marker_stats(gv_ctx* ctx, double alpha_scale);
+int gv_get_marker_stats(gv_ctx* ctx, double* mave, double* msig); /* M doubles each (data.hpp:95-98) */
+
+/* ---- matvecs with the reference's host signatures ---------------------------------------------------
+ * data::Ax (data.cpp:848-1009): x[M] -> out[4*mbytes], summed over ranks (if a communicator is attached),
+ * masked, scaled by 1/sqrt(N).  data::ATx (data.cpp:810-835): p[4*mbytes] -> out[M], scaled by 1/sqrt(N). */
+int gv_ax(gv_ctx* ctx, const double* x, double* out);
+int gv_atx(gv_ctx* ctx, const double* p, double* out);
+
+/* kernel family for Ax/ATx: 0 = fp64 VALU kernels (parity anchor), 1 = i8 MFMA fixed-point kernels. */
+int gv_set_kernel_mode(gv_ctx* ctx, int mode);
+int gv_get_kernel_mode(const gv_ctx* ctx);
+
+/* ---- device-resident vectors (the std::vector<double> temporaries of vamp.cpp live here) ------------ */
+enum { GV_SPACE_M = 0, GV_SPACE_N = 1 }; /* length M, or length 4*mbytes (padded internally) */
+int gv_vec_alloc(gv_ctx* ctx, int space, gv_vec** out);
+void gv_vec_free(gv_ctx* ctx, gv_vec* v);
+int64_t gv_vec_len(const gv_vec* v); /* logical length: M or 4*mbytes */
+int gv_vec_upload(gv_ctx* ctx, gv_vec* v, const double* src);
+int gv_vec_download(gv_ctx* ctx, const gv_vec* v, double* dst);
+int gv_vec_fill(gv_ctx* ctx, gv_vec* v, double value);
+int gv_vec_copy(gv_ctx* ctx, gv_vec* dst, const gv_vec* src);
+/* out = a*x + b*y (y may be NULL when b == 0; out may alias x or y) */
+int gv_vec_axpby(gv_ctx* ctx, gv_vec* out, double a, const gv_vec* x, double b, const gv_vec* y);
+/* inner_prod (utilities.cpp:190-210): sync != 0 adds the cross-rank all-reduce of the scalar. */
+int gv_vec_dot(gv_ctx* ctx, const gv_vec* x, const gv_vec* y, int sync, double* out);
+/* several dots in one pass and ONE all-reduce: out[k] = <x[k], y[k]> */
+int gv_vec_dots(gv_ctx* ctx, int n, const gv_vec* const* x, const gv_vec* const* y, int sync, double* out);
+int gv_ax_dev(gv_ctx* ctx, const gv_vec* x, gv_vec* out);  /* data::Ax on handles */
+int gv_atx_dev(gv_ctx* ctx, const gv_vec* p, gv_vec* out); /* data::ATx on handles */
+/* phenotype y (length N) -> N-space handle with NA / pad slots zeroed: data::filter_pheno (data.cpp:1065-1079) */
+int gv_set_phen(gv_ctx* ctx, gv_vec* y_out, const double* y_host);
+
+/* ---- solver: vamp::lmmse_mult (vamp.cpp:1074-1118), vamp::precondCG_solver (vamp.cpp:1130-1229) ------ */
+int gv_lmmse_mult(gv_ctx* ctx, const gv_vec* v, double tau, double gam2, gv_vec* out);
+typedef struct {
+    int iters;           /* CG steps executed */
+    int converged;       /* 1 if a stopping rule fired before max_iter */
+    double rel_res;      /* ||r|| / ||v|| at exit (vamp.cpp:1215) */
+    double onsager;      /* gam2 * <v, mu> at exit (denoiser == 0 only, vamp.cpp:1176) */
+    int n_ax, n_atx;     /* matvec calls made */
+    int n_relres;        /* entries written to relres (an Onsager-rule exit skips the last residual update) */
+} gv_cg_stats;
+/* mu_start may be NULL (zeros).  denoiser: 1 = LMMSE solve, 0 = Onsager probe solve (extra stopping rule).
+ * relres (may be NULL): max_iter doubles receiving ||r||/||v|| after every step. */
+int gv_cg_solve(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int denoiser,
+                int max_iter, gv_vec* mu_out, gv_cg_stats* stats, double* relres);
+
+/* ---- denoiser side (fused element-wise kernels) ------------------------------------------------------
+ * vamp::g1 / g1d over a vector (vamp.cpp:805-869; loops :292-310): x1 = g1(r1), sums[0] = sum g1d(r1) (local),
+ * sums[1] = sum (x1-r1)^2 (local).  vars already multiplied by N (vamp.cpp:154-155).  d_out may be NULL. */
+int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+               gv_vec* x1_out, gv_vec* d_out, double* sums2);
+/* one E-step of vamp::updatePrior (vamp.cpp:953-1013): sums[0] = sum_i pi_i, sums[1+2j] = sum_i beta_ij pi_i,
+ * sums[2+2j] = sum_i beta_ij (m_ij^2 + v_j) pi_i for j = 0..L-2 (local sums; caller all-reduces 1+2(L-1)). */
+int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                   const double* vars, int L, double* sums);
+/* SUM all-reduce of n host doubles over the attached communicator (identity when none): MPI_Allreduce of
+ * scalars in vamp.cpp:313,990,1012-1013 */
+int gv_allreduce_host(gv_ctx* ctx, double* buf, int n);
+
+/* ---- communicator: stands in for MPI_COMM_WORLD (data.cpp:928/:995; utilities.cpp:203) ---------------
+ * RCCL over xGMI, one process per GPU.  Rank 0 calls gv_comm_unique_id and ships the 128 bytes to the
+ * other ranks by any out-of-band channel (bench.py: torch.distributed broadcast). */
+int gv_comm_unique_id(void* id128);
+int gv_comm_init(gv_ctx* ctx, int nranks, int rank, const void* id128);
+int gv_comm_rank(const gv_ctx* ctx);
+int gv_comm_size(const gv_ctx* ctx);
+
+/* ---- instrumentation ---------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t n_ax, n_atx;          /* kernel launches of each matvec since the last reset */
+    double ms_ax, ms_atx;         /* HIP-event time spent in them (on the context's stream) */
+    double ms_allreduce;          /* HIP-event time of the N-vector all-reduces */
+} gv_counters;
+/* timing != 0 brackets every matvec with HIP events (adds a sync per call; bench/roofline only) */
+int gv_set_timing(gv_ctx* ctx, int timing);
+int gv_get_counters(gv_ctx* ctx, gv_counters* out);
+int gv_reset_counters(gv_ctx* ctx);
+/* device copy bandwidth probe: copies nbytes device->device `reps` times, returns GB/s (read+write bytes) */
+int gv_copy_bandwidth(gv_ctx* ctx, size_t nbytes, int reps, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVAMP_H */

@@ -1,0 +1,217 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle: marker statistics, data::Ax, data::ATx, CG, denoiser.
+
+Tolerances (fp64 path): the kernels sum in a different order than the oracle's serial loops, so agreement is
+to rounding -- 1e-12 relative l2 is asserted (north_star asks 1e-5 on x_hat)."""
+import numpy as np
+import pytest
+
+from gvamp_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def make_mask(N, rng, frac_na):
+    mb = (N + 3) // 4
+    present = rng.random(N) >= frac_na
+    m4 = np.zeros(mb, dtype=np.uint8)
+    for n in np.nonzero(present)[0]:
+        m4[n >> 2] |= 1 << (n & 3)
+    return m4, int(present.sum()), present
+
+
+CASES = [
+    # N, M, miss_ppm, frac_na
+    (2000, 300, 10000, 0.0),      # config-1 shape (N % 4 == 0), ~1 % missing genotypes
+    (2000, 257, 0, 0.0),          # no missing genotypes
+    (1003, 129, 20000, 0.01),     # N % 4 != 0 and NA phenotypes (scalar-path mask semantics)
+    (5, 3, 0, 0.0),               # tiny / ragged
+    (4100, 64, 5000, 0.002),      # pitch padding (mbytes = 1025)
+    (70000, 40, 5000, 0.0),       # long rows (several wave iterations)
+]
+
+
+@pytest.mark.parametrize("N,M,miss,fna", CASES)
+def test_stats_ax_atx_vs_oracle(oracle, N, M, miss, fna):
+    rng = np.random.default_rng(N + M)
+    bed = synth.synth_bed(N, M, seed=99, miss_ppm=miss)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        assert np.array_equal(sh.download_bed(), bed)
+        if fna > 0 or N % 4:
+            m4, nonas, present = make_mask(N, rng, fna)
+            sh.set_mask(m4, nonas)
+        else:
+            m4, nonas, present = None, N, np.ones(N, bool)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        o_mave, o_msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas)
+        assert np.allclose(mave, o_mave, rtol=1e-13, atol=1e-15)
+        assert np.allclose(msig, o_msig, rtol=1e-12, atol=0)
+
+        x = rng.standard_normal(M)
+        z = sh.Ax(x)
+        oz = oracle.ax(bed, N, M, o_mave, o_msig, x, mask4=m4)
+        assert z.shape == oz.shape == (4 * ((N + 3) // 4),)
+        assert rel(z, oz) < TOL
+        assert np.all(z[N:] == 0) and np.all(z[:N][~present] == 0)
+
+        p = np.zeros(4 * ((N + 3) // 4))
+        p[:N] = rng.standard_normal(N) * present
+        w = sh.ATx(p)
+        ow = oracle.atx(bed, N, M, o_mave, o_msig, p)
+        assert rel(w, ow) < TOL
+
+
+def test_monomorphic_and_all_missing_markers(oracle):
+    """Guards of data.cpp:462-483: sumb == 0 -> mave 0; sumsqr == 0 -> msig 1."""
+    N, M = 64, 4
+    bed = synth.synth_bed(N, M, seed=5, miss_ppm=0).reshape(M, N // 4).copy()
+    bed[0, :] = 0x55   # every genotype missing
+    bed[1, :] = 0xFF   # all homozygous a = 0
+    bed[2, :] = 0x00   # all a = 2
+    bed = bed.reshape(-1)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        o_mave, o_msig = oracle.marker_stats(bed, N, M)
+        assert np.array_equal(mave[:3], [0.0, 0.0, 2.0]) and np.array_equal(msig[:3], [1.0, 1.0, 1.0])
+        assert np.allclose(mave, o_mave, rtol=1e-14) and np.allclose(msig, o_msig, rtol=1e-13)
+        x = np.arange(1, M + 1, dtype=float)
+        assert rel(sh.Ax(x), oracle.ax(bed, N, M, o_mave, o_msig, x)) < TOL
+
+
+def test_alpha_scale(oracle):
+    N, M = 400, 50
+    bed = synth.synth_bed(N, M, seed=6)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics(alpha_scale=0.3)
+        _, msig = sh.marker_stats()
+        _, o_msig = oracle.marker_stats(bed, N, M, alpha_scale=0.3)
+        assert np.allclose(msig, o_msig, rtol=1e-12)
+
+
+def test_synth_bed_device_matches_host():
+    for N, M, S in ((2000, 100, 0), (1003, 17, 5), (33, 9, 1000)):
+        host = synth.synth_bed(N, M, seed=1234, miss_ppm=5000, S=S)
+        with capi.Shard(N, M, Mt=S + M + 3, S=S) as sh:
+            sh.synth_bed(1234, 5000)
+            assert np.array_equal(sh.download_bed(), host)
+
+
+def test_linearity_and_adjoint_at_scale():
+    """Size-independent properties at a shape the oracle would take minutes for: <Ax, p> == <x, A^T p>
+    (p masked) and A(ax1 + bx2) == aAx1 + bAx2."""
+    N, M = 100000, 20000
+    rng = np.random.default_rng(0)
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(77, 5000)
+        sh.compute_markers_statistics()
+        x1, x2 = rng.standard_normal(M), rng.standard_normal(M)
+        p = rng.standard_normal(N)
+        z1, z2 = sh.Ax(x1), sh.Ax(x2)
+        z12 = sh.Ax(2.5 * x1 - 0.75 * x2)
+        assert rel(z12, 2.5 * z1 - 0.75 * z2) < 1e-12
+        w = sh.ATx(p)
+        lhs, rhs = float(z1 @ p), float(x1 @ w)
+        assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs), 1.0)
+
+
+@pytest.mark.parametrize("denoiser", [1, 0])
+def test_cg_solve_vs_oracle(oracle, denoiser):
+    N, M = 2000, 1500
+    rng = np.random.default_rng(3)
+    bed = synth.synth_bed(N, M, seed=11)
+    v = rng.standard_normal(M)
+    mu0 = 0.1 * rng.standard_normal(M) if denoiser == 1 else None
+    tau, gam2 = 2.0, 1.35
+    o_mu, o_rr = oracle.cg_solve(bed, N, M, v, mu0, tau, gam2, denoiser, 25)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        dv, dmu = sh.vecM(v), sh.vecM()
+        dm0 = sh.vecM(mu0) if mu0 is not None else None
+        st, rr = sh.cg_solve(dv, dm0, tau, gam2, denoiser, 25, dmu)
+        mu = dmu.download()
+    assert len(rr) == len(o_rr)
+    assert np.allclose(rr, o_rr, rtol=1e-9)
+    assert rel(mu, o_mu) < 1e-11
+    assert st.n_ax == st.n_atx == st.iters + (1 if mu0 is not None else 0)
+
+
+def test_denoise_vs_oracle(oracle):
+    M = 5000
+    rng = np.random.default_rng(8)
+    r1 = rng.standard_normal(M) * np.where(rng.random(M) < 0.1, 5.0, 0.3)
+    probs, vs = [0.9, 0.07, 0.03], [0.0, 2.0, 20.0]
+    with capi.Shard(8, M) as sh:
+        dr, dx, dd = sh.vecM(r1), sh.vecM(), sh.vecM()
+        for gam1 in (0.7, 12.5, 1e-8, 1e12):
+            sums = sh.denoise(dr, gam1, probs, vs, dx, dd)
+            g1, g1d = oracle.g1_g1d(r1, gam1, probs, vs)
+            # at gam1 = 1e-8 both g1 (y + 1e8 * pkd/pk, vamp.cpp:831) and g1d (:866) cancel ~8 digits
+            tol = 1e-6 if gam1 < 1e-6 else 1e-11
+            assert np.allclose(dx.download(), g1, rtol=tol, atol=1e-300)
+            assert np.allclose(dd.download(), g1d, rtol=tol)
+            assert np.isclose(sums[0], g1d.sum(), rtol=tol)
+            assert np.isclose(sums[1], ((g1 - r1) ** 2).sum(), rtol=1e-11)
+
+
+def test_default_23_component_prior_denoise(oracle):
+    M, N, Mt = 4000, 100000, 500000
+    probs = [1 - 50000.0 / Mt]
+    p = min(50000.0 / Mt, 1.0) / (2 - 1.0 / 2 ** 21)
+    vs = [0.0]
+    v = 1e-5
+    for _ in range(22):
+        probs.append(p)
+        p /= 2
+        vs.append(v)
+        v *= 10 ** (7 / 21)
+    rng = np.random.default_rng(9)
+    r1 = rng.standard_normal(M) * 0.05
+    with capi.Shard(8, M) as sh:
+        dr, dx, dd = sh.vecM(r1), sh.vecM(), sh.vecM()
+        sh.denoise(dr, 400.0, probs, vs, dx, dd)
+        g1, g1d = oracle.g1_g1d(r1, 400.0, probs, vs)
+        assert np.allclose(dx.download(), g1, rtol=1e-11, atol=1e-300)
+        assert np.allclose(dd.download(), g1d, rtol=1e-10)
+
+
+def test_vector_ops():
+    M = 10007
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal(M), rng.standard_normal(M)
+    with capi.Shard(8, M) as sh:
+        da, db, dc = sh.vecM(a), sh.vecM(b), sh.vecM()
+        sh.axpby(dc, 2.0, da, -3.0, db)
+        assert np.allclose(dc.download(), 2 * a - 3 * b, rtol=1e-15)
+        assert np.isclose(sh.dot(da, db), a @ b, rtol=1e-12)
+        d = sh.dots([(da, da), (da, db), (db, db)])
+        assert np.allclose(d, [a @ a, a @ b, b @ b], rtol=1e-12)
+        # determinism of the ordered reductions
+        assert sh.dot(da, db) == sh.dot(da, db)
+
+
+def test_empty_shard():
+    with capi.Shard(100, 0, Mt=10, S=10) as sh:
+        sh.upload_bed(np.zeros(0, dtype=np.uint8))
+        sh.compute_markers_statistics()
+        z = sh.Ax(np.zeros(0))
+        assert z.shape == (100,) and np.all(z == 0)
+        assert sh.ATx(np.zeros(100)).shape == (0,)
+
+
+def test_errors_are_reported():
+    with capi.Shard(100, 10) as sh:
+        with pytest.raises(capi.GvError):
+            sh.Ax(np.zeros(10))            # no bed / stats yet
+        with pytest.raises(capi.GvError):
+            sh.upload_bed(np.zeros(7, dtype=np.uint8))   # wrong size
