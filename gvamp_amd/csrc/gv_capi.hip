@@ -112,10 +112,17 @@ struct Timer {
 
 // data::Ax on device pointers.  x: M doubles, out: npad doubles.
 int ax_device(gv_ctx* c, const double* x, double* out) {
-    NEED(c, c->bed && c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
+    NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = c->comm && c->nranks > 1;
-    {
+    if (c->kernel_mode == 1 && c->M > 0) {
+        NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+        Timer t(c, &c->cnt.ms_ax);
+        gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out);
+        KCHK(c);
+        t.stop();
+    } else {
+        NEED(c, c->have_raw, "Ax: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
         Timer t(c, &c->cnt.ms_ax);
         gvk::ax_table(c->stream, x, c->mave, c->msig, c->M, c->t3);
         gvk::ax_f64(c->stream, c->bed, c->M, c->pitch, c->t3, c->ax_chunks, c->ax_partial, c->npad);
@@ -136,9 +143,15 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
 int atx_device(gv_ctx* c, const double* p, double* out) {
-    NEED(c, c->bed && c->have_stats, "ATx: bed and marker statistics must be set first");
+    NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     Timer t(c, &c->cnt.ms_atx);
-    gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
+    if (c->kernel_mode == 1 && c->M > 0) {
+        NEED(c, c->have_stripes, "ATx: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out);
+    } else {
+        NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
+        gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
+    }
     KCHK(c);
     t.stop();
     c->cnt.n_atx++;
@@ -160,6 +173,10 @@ void free_dataset(gv_ctx* c) {
         p = nullptr;
     };
     F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial);
+    F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
+    F(c->plan.scal); F(c->plan.partial);
+    c->plan = gvm::Plan();
+    c->have_raw = c->have_stripes = false;
     for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d})
         if (*v) {
             (void)hipFree((*v)->d);
@@ -244,38 +261,102 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     if (chunks < 1) chunks = 1;
     c->ax_chunks = (int)chunks;
     HIPCHK(c, hipMalloc(&c->ax_partial, sizeof(double) * c->ax_chunks * c->npad));
+    // i8 MFMA family: int32 digit sums must not overflow (|r'| <= 3, |digit| <= 128; Ax adds the miss plane)
+    NEED(c, N * 384 < 2147483647LL, "gv_set_dims: N too large for the int32 accumulators of kernel mode 1");
+    gvm::Plan& pl = c->plan;
+    pl.M = M; pl.N = N;
+    pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
+    pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
+    auto pick_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks) {
+        int64_t ks = nrg > 0 ? (8192 + nrg - 1) / nrg : 1;
+        if (ks < min_ks) ks = min_ks;
+        if (ks > 64) ks = 64;
+        if (ks > nkb) ks = nkb;
+        return (int)(ks < 1 ? 1 : ks);
+    };
+    pl.ks_m = pick_ks(pl.nrg_m, pl.nkb_m, 1);
+    pl.ks_n = pick_ks(pl.nrg_n, pl.nkb_n, (M * 512 + 2147483646LL) / 2147483647LL);
     return gv_set_mask(c, nullptr, N);
 }
 
 int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 
+// Ingest: fills the resident layouts chunk by chunk (markers [m0, m0+mc), m0 % 256 == 0) so that the raw rows never
+// have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
+static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr) {
+    NEED(c, c->N > 0, "ingest: gv_set_dims must be called first");
+    NEED(c, c->want_raw || c->want_stripes, "ingest: gv_set_layout disabled both layouts");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t M = c->M, P = c->pitch;
+    gvm::Plan& pl = c->plan;
+    c->have_raw = c->have_stripes = c->have_stats = false;
+    if (c->want_raw && !c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(M > 0 ? M : 1) * P));
+    if (!c->want_raw && c->bed) { (void)hipFree(c->bed); c->bed = nullptr; }
+    if (c->want_stripes && !pl.stripes_m) {
+        const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
+        HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
+        HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
+        HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 2048));
+        HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 2048));
+        HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
+        HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
+        HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 4));
+        size_t pa = (size_t)pl.ks_m * 2 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * pl.nrg_n * 64 * 8 * 4;
+        pl.partial_bytes = pa > pb ? pa : pb;
+        HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
+    }
+    const int64_t CH = 32768;
+    uint8_t* tmp = nullptr;
+    if (!c->want_raw) HIPCHK(c, hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P));
+    int rc = 0;
+    for (int64_t m0 = 0; m0 < M && !rc; m0 += CH) {
+        const int64_t mc = M - m0 < CH ? M - m0 : CH;
+        uint8_t* rawp = c->want_raw ? c->bed + m0 * P : tmp;
+        hipError_t e = hipSuccess;
+        if (synth) {
+            gvk::synth_bed(c->stream, rawp, mc, c->S + m0, c->N, P, seed, miss_thr);
+        } else {
+            e = hipMemsetAsync(rawp, 0, (size_t)mc * P, c->stream);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(rawp, P, host_bed + (size_t)m0 * c->mbytes, c->mbytes, c->mbytes, mc,
+                                     hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess && c->want_stripes) {
+            gvm::stripes_m_chunk(c->stream, rawp, P, mc, c->N, pl.stripes_m, m0 / 64, pl.nkb_m);
+            gvm::stripes_n_chunk(c->stream, rawp, P, mc, c->N, pl.stripes_n, m0 / 256, pl.nkb_n, pl.nrg_n);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, "ingest chunk at marker %lld failed: %s", (long long)m0, hipGetErrorString(e));
+    }
+    if (tmp) (void)hipFree(tmp);
+    if (rc) return rc;
+    c->have_raw = c->want_raw;
+    c->have_stripes = c->want_stripes;
+    return 0;
+}
+
+int gv_set_layout(gv_ctx* c, int raw_rows, int stripes) {
+    NEED(c, raw_rows || stripes, "gv_set_layout: at least one layout is required");
+    c->want_raw = raw_rows != 0;
+    c->want_stripes = stripes != 0;
+    return 0;
+}
+
 int gv_upload_bed(gv_ctx* c, const uint8_t* bed, size_t nbytes) {
     NEED(c, c->N > 0, "gv_upload_bed: gv_set_dims must be called first");
     NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_upload_bed: nbytes != M * ceil(N/4)");
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(c->M > 0 ? c->M : 1) * c->pitch));
-    HIPCHK(c, hipMemsetAsync(c->bed, 0, (size_t)(c->M > 0 ? c->M : 1) * c->pitch, c->stream));
-    if (c->M > 0)
-        HIPCHK(c, hipMemcpy2DAsync(c->bed, c->pitch, bed, c->mbytes, c->mbytes, c->M, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_stats = false;
-    return 0;
+    return ingest(c, bed, false, 0, 0);
 }
 
 int gv_synth_bed(gv_ctx* c, uint64_t seed, uint32_t miss_ppm) {
     NEED(c, c->N > 0, "gv_synth_bed: gv_set_dims must be called first");
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(c->M > 0 ? c->M : 1) * c->pitch));
     uint32_t thr = (uint32_t)(((uint64_t)miss_ppm << 32) / 1000000ull);
-    gvk::synth_bed(c->stream, c->bed, c->M, c->S, c->N, c->pitch, seed, thr);
-    KCHK(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_stats = false;
-    return 0;
+    return ingest(c, nullptr, true, seed, thr);
 }
 
 int gv_download_bed(gv_ctx* c, uint8_t* bed, size_t nbytes) {
-    NEED(c, c->bed, "gv_download_bed: no bed resident");
+    NEED(c, c->have_raw, "gv_download_bed: the raw row layout is not resident (gv_set_layout)");
     NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_download_bed: nbytes != M * ceil(N/4)");
     if (c->M > 0)
         HIPCHK(c, hipMemcpy2DAsync(bed, c->mbytes, c->bed, c->pitch, c->mbytes, c->M, hipMemcpyDeviceToHost, c->stream));
@@ -300,8 +381,12 @@ int gv_set_mask(gv_ctx* c, const uint8_t* mask4, int64_t nonas) {
 }
 
 int gv_marker_stats(gv_ctx* c, double alpha_scale) {
-    NEED(c, c->bed && c->mask2, "gv_marker_stats: bed and mask must be set first");
-    gvk::marker_stats(c->stream, c->bed, c->mask2, c->M, c->pitch, (double)c->nonas, alpha_scale, c->mave, c->msig);
+    NEED(c, (c->have_raw || c->have_stripes) && c->mask2, "gv_marker_stats: bed and mask must be set first");
+    if (c->have_stripes && (c->kernel_mode == 1 || !c->have_raw))
+        gvm::stats_from_stripes(c->stream, c->plan.stripes_m, c->mask2, c->M, c->plan.nkb_m, c->pitch / 4,
+                                (double)c->nonas, alpha_scale, c->mave, c->msig);
+    else
+        gvk::marker_stats(c->stream, c->bed, c->mask2, c->M, c->pitch, (double)c->nonas, alpha_scale, c->mave, c->msig);
     KCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_stats = true;
@@ -317,7 +402,7 @@ int gv_get_marker_stats(gv_ctx* c, double* mave, double* msig) {
 }
 
 int gv_set_kernel_mode(gv_ctx* c, int mode) {
-    NEED(c, mode == 0, "gv_set_kernel_mode: only mode 0 (fp64 VALU) is built in this version");
+    NEED(c, mode == 0 || mode == 1, "gv_set_kernel_mode: mode must be 0 (fp64 VALU) or 1 (i8 MFMA fixed point)");
     c->kernel_mode = mode;
     return 0;
 }

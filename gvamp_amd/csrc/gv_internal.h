@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "gvamp.h"
+#include "gv_mfma.h"
 
 struct gv_vec {
     gv_ctx* ctx;
@@ -33,7 +34,10 @@ struct gv_ctx {
     double* mave = nullptr;
     double* msig = nullptr;
     bool have_stats = false;
-    int kernel_mode = 0;
+    int kernel_mode = 0;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
+    bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
+    bool have_raw = false, have_stripes = false;
+    gvm::Plan plan;
 
     // workspaces ---------------------------------------------------------------------------------
     double* t3 = nullptr;          // 3*M: per-marker Ax table {(2-mu)c, (1-mu)c, (0-mu)c}

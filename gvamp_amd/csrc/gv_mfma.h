@@ -1,0 +1,37 @@
+// gv_mfma.h -- host-side plan and launchers of the fixed-point i8 MFMA family (gv_mfma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace gvm {
+
+struct Plan {
+    int64_t M = 0, N = 0;
+    int64_t nrg_m = 0, nkb_m = 0;   // stripes_m: row groups of 64 markers x K-blocks of 256 individuals
+    int64_t nrg_n = 0, nkb_n = 0;   // stripes_n: row groups of 64 individuals x K-blocks of 256 markers
+    int ks_m = 1, ks_n = 1;         // K-splits (waves per row group)
+    void* stripes_m = nullptr;
+    void* stripes_n = nullptr;
+    void* dig0 = nullptr;           // digit buffers, max(nkb_m, nkb_n) * 2048 bytes each
+    void* dig1 = nullptr;
+    double* cv = nullptr;           // M doubles: c = msig * x
+    double* ev = nullptr;           // M doubles: e = (mave - 3) * c
+    double* scal = nullptr;         // 4 doubles: amax, sum, 2^(54-e), 2^(e-54)
+    int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
+    size_t partial_bytes = 0;
+};
+
+void stripes_m_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
+                     int64_t rg0, int64_t nkb);
+void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
+                     int64_t kb0, int64_t nkb, int64_t nrg_n);
+void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
+                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig);
+// out[M] = data::ATx(p); p has npad entries (zero at NA / pad slots)
+void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
+         double inv_sqrt_n, double* red_partial, double* out);
+// out[npad] = mask * (A~ x) * post   (post = 1/sqrt(N), or 1 when a cross-rank all-reduce follows)
+void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
+        int64_t npad, double post, double* red_partial, double* out);
+
+}  // namespace gvm

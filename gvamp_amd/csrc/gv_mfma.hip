@@ -1,0 +1,470 @@
+// gv_mfma.hip -- fixed-point i8 MFMA family for data::Ax / data::ATx on gfx950 (kernel mode 1).
+//
+// Why: one .bed byte = 4 genotypes = 4 fp64 FMAs; at HBM rate that alone is ~80 % of the fp64 VALU peak before
+// any decode, and the measured fp64 VALU kernels reach 4-9 % of HBM peak.  The matvec against a 2-bit
+// matrix is exact in integers once the vector is put in fixed point, and CDNA4 has an i8 matrix pipe:
+//
+//   v (fp64)  ->  q = rint(v * 2^(54-e)),  2^(e-1) <= max|v| < 2^e      (absolute error <= 2^-55 max|v| per entry)
+//             ->  7 balanced base-256 digits d_l in [-128,127]          (q = sum_l d_l 256^l, exact)
+//   per 16x64 genotype tile:  acc[row][l] += sum_k g[row][k] * d_l[k]   v_mfma_i32_16x16x64_i8, exact int32
+//   result = (sum_l acc_l 256^l) * 2^(e-54)                             exact int64 limbs -> one fp64 rounding
+//
+// All sums are integer: results do not depend on tile order, K-split count or wave scheduling (bitwise
+// reproducible), and the error is that of the input quantisation only -- below fp64 summation error.
+//
+// HBM layout ("stripes", built once at upload from the PLINK rows): 2-bit codes re-encoded to
+//   r' = 2 (a=2), 1 (a=1), 0 (a=0), 3 (missing)         [PLINK 00,10,11,01 ; data.cpp decode via dotp_lut]
+// so that sum_k r' v = sum a v + 3 sum miss v needs no table for the first plane.  A supertile = 64 rows x 256
+// K-entries = 4 KiB contiguous = 4 tiles of 16 rows; inside a tile lane l = (r = l&15, g = l>>4) owns 16 bytes =
+// K-entries [64g, 64g+64) of row r, dword d = entries 64g+16d+q at bits 2q.  One wave-wide 16-byte load is
+// therefore one fully coalesced KiB and feeds four MFMAs (d = 0..3) with NO cross-lane movement:
+//   A operand of MFMA d, VGPR s, byte t  =  (dword_d >> 2s) & 3 at byte t   <->  K-entry 64g + 16d + 4t + s
+// and the vector digits are stored in the same (d, g, s, t) order (k_quant).  Two stripe sets are resident:
+//   stripes_m : rows = markers,     K = individuals  (ATx)
+//   stripes_n : rows = individuals, K = markers      (Ax; the 2-bit transpose)
+#include "gv_internal.h"
+#include "gv_mfma.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t recode(uint32_t w) {   // PLINK code -> r'
+    return ((~w) & 0xAAAAAAAAu) | (((w >> 1) ^ w) & 0x55555555u);
+}
+// keep entries with index < nvalid (0..16) of a 16-entry word
+__device__ __forceinline__ uint32_t keep_lo(uint32_t w, int nvalid) {
+    return nvalid >= 16 ? w : (nvalid <= 0 ? 0u : (w & ((1u << (2 * nvalid)) - 1u)));
+}
+
+// ---- stripes_m from a raw chunk: markers [m0, m0 + mc) of the shard, m0 % 64 == 0 ----------------------------------
+// block = supertile (rg_local, kb); thread t = (i = t>>6, l = t&63 = (r, g)) moves one 16-byte piece.
+__global__ __launch_bounds__(256) void k_stripes_m(const uint8_t* __restrict__ raw, int64_t pitch, int64_t mc,
+                                                   int64_t N, uint4* __restrict__ stripes, int64_t rg0, int64_t nkb) {
+    const int t = threadIdx.x, i = t >> 6, l = t & 63, r = l & 15, g = l >> 4;
+    const int64_t kb = blockIdx.x, rgl = blockIdx.y;
+    const int64_t m = rgl * 64 + 16 * i + r;          // local marker in the chunk
+    const int64_t byte0 = kb * 64 + 16 * g;           // first byte of the piece in the row
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < mc && byte0 < pitch) {
+        v = *reinterpret_cast<const uint4*>(raw + m * pitch + byte0);
+        const int64_t n0 = byte0 * 4;                 // first individual of the piece
+        v.x = keep_lo(recode(v.x), (int)min((int64_t)16, max((int64_t)0, N - n0)));
+        v.y = keep_lo(recode(v.y), (int)min((int64_t)16, max((int64_t)0, N - n0 - 16)));
+        v.z = keep_lo(recode(v.z), (int)min((int64_t)16, max((int64_t)0, N - n0 - 32)));
+        v.w = keep_lo(recode(v.w), (int)min((int64_t)16, max((int64_t)0, N - n0 - 48)));
+    }
+    stripes[((rg0 + rgl) * nkb + kb) * 256 + t] = v;
+}
+
+// ---- stripes_n (2-bit transpose) from a raw chunk: markers [m0, m0 + mc), m0 % 256 == 0 ---------------------------
+// block = (kb_local: 256 markers, ng: 64 individuals).  Stage the 256 x 16-byte block in LDS, then every thread
+// gathers the 64 markers of one (individual, g) into its 16-byte piece.
+__global__ __launch_bounds__(256) void k_stripes_n(const uint8_t* __restrict__ raw, int64_t pitch, int64_t mc,
+                                                   int64_t N, uint4* __restrict__ stripes, int64_t kb0, int64_t nkb) {
+    __shared__ uint32_t sh[256][5];   // +1 pad: the gather reads column i of 64 consecutive rows
+    const int t = threadIdx.x;
+    const int64_t kbl = blockIdx.x, ng = blockIdx.y;
+    const int64_t m = kbl * 256 + t, byte0 = ng * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < mc && byte0 < pitch) {
+        v = *reinterpret_cast<const uint4*>(raw + m * pitch + byte0);
+        const int64_t n0 = ng * 64;
+        v.x = keep_lo(recode(v.x), (int)min((int64_t)16, max((int64_t)0, N - n0)));
+        v.y = keep_lo(recode(v.y), (int)min((int64_t)16, max((int64_t)0, N - n0 - 16)));
+        v.z = keep_lo(recode(v.z), (int)min((int64_t)16, max((int64_t)0, N - n0 - 32)));
+        v.w = keep_lo(recode(v.w), (int)min((int64_t)16, max((int64_t)0, N - n0 - 48)));
+    }
+    sh[t][0] = v.x; sh[t][1] = v.y; sh[t][2] = v.z; sh[t][3] = v.w;
+    __syncthreads();
+    const int i = t >> 6, l = t & 63, r = l & 15, g = l >> 4;
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) w |= ((sh[64 * g + 16 * d + q][i] >> (2 * r)) & 3u) << (2 * q);
+        o[d] = w;
+    }
+    stripes[(ng * nkb + kb0 + kbl) * 256 + t] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- compute_markers_statistics (data.cpp:451-484) from stripes_m: one wave per tile of 16 markers -------------
+__global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__ stripes, const uint32_t* __restrict__ mask2,
+                                                       int64_t M, int64_t nkb, int64_t P4, double nonas,
+                                                       double alpha_scale, double* __restrict__ mave,
+                                                       double* __restrict__ msig) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global 16-row tile
+    if (tile * 16 >= M) return;
+    const int64_t rg = tile >> 2, i = tile & 3;
+    uint32_t n2 = 0, n1 = 0, n0 = 0;
+    for (int64_t kb = 0; kb < nkb; kb++) {
+        uint4 v = stripes[(rg * nkb + kb) * 256 + i * 64 + lane];
+        const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
+        uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t pm = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
+            uint32_t lo = ws[d] & 0x55555555u, hi = (ws[d] >> 1) & 0x55555555u;
+            n2 += __popc(hi & ~lo & pm);
+            n1 += __popc(~hi & lo & pm);
+            n0 += __popc(~hi & ~lo & pm);
+        }
+    }
+    // sum over the 4 lanes (g) that share row r
+    n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
+    n1 += __shfl_xor(n1, 16, 64); n1 += __shfl_xor(n1, 32, 64);
+    n0 += __shfl_xor(n0, 16, 64); n0 += __shfl_xor(n0, 32, 64);
+    const int64_t m = tile * 16 + r;
+    if (g == 0 && m < M) {
+        double suma = 2.0 * n2 + 1.0 * n1, sumb = (double)n0 + (double)n1 + (double)n2;
+        double mu = (sumb != 0) ? suma / sumb : 0.0;
+        double sumsqr = n2 * ((2.0 - mu) * (2.0 - mu)) + n1 * ((1.0 - mu) * (1.0 - mu)) + n0 * (mu * mu);
+        double sg;
+        if (sumsqr != 0) {
+            if (alpha_scale == 1.0) sg = 1.0 / sqrt(sumsqr / (nonas - 1.0));
+            else sg = 1.0 / pow(sqrt(sumsqr / (nonas - 1.0)), alpha_scale);
+        } else
+            sg = 1.0;
+        mave[m] = mu;
+        msig[m] = sg;
+    }
+}
+
+// ---- vector preparation -------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Ax operands: c = msig*x, e = (mave-3)*c  (out = sum r' c + sum miss e - K0, K0 = sum mave*c).
+// block partials: [0] = max(|c|,|e|), [1] = sum mave*c
+__global__ __launch_bounds__(256) void k_prep_ax(const double* __restrict__ x, const double* __restrict__ mave,
+                                                 const double* __restrict__ msig, int64_t M, double* __restrict__ cv,
+                                                 double* __restrict__ ev, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
+    double mx = 0.0, s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        double c = msig[i] * x[i], mu = mave[i];
+        double e = (mu - 3.0) * c;
+        cv[i] = c;
+        ev[i] = e;
+        mx = fmax(mx, fmax(fabs(c), fabs(e)));
+        s += mu * c;
+    }
+    mx = wave_max(mx);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+        partial[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
+    }
+}
+// ATx operand p: block partials [0] = max|p|, [1] = sum p
+__global__ __launch_bounds__(256) void k_prep_atx(const double* __restrict__ p, int64_t n, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
+    double mx = 0.0, s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double v = p[i];
+        mx = fmax(mx, fabs(v));
+        s += v;
+    }
+    mx = wave_max(mx);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+        partial[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
+    }
+}
+// scal[0] = amax, scal[1] = sum (ordered), scal[2] = 2^(54-e) (quantisation multiplier, 0 if amax is 0 / not finite),
+// scal[3] = 2^(e-54)
+__global__ __launch_bounds__(256) void k_prep_final(const double* __restrict__ partial, int nblocks, double* __restrict__ scal) {
+    __shared__ double shm[256], shs[256];
+    double mx = 0.0, s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        mx = fmax(mx, partial[2 * b]);
+        s += partial[2 * b + 1];
+    }
+    shm[threadIdx.x] = mx;
+    shs[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + off]);
+            shs[threadIdx.x] += shs[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double amax = shm[0];
+        scal[0] = amax;
+        scal[1] = shs[0];
+        if (amax > 0.0 && amax < 1.7e308) {
+            int e = ilogb(amax) + 1;
+            scal[2] = ldexp(1.0, 54 - e);
+            scal[3] = ldexp(1.0, e - 54);
+        } else {
+            scal[2] = 0.0;
+            scal[3] = 0.0;
+        }
+    }
+}
+
+// fixed-point digits of v in MFMA B-operand order.  Thread = (kb, g, d, s): 4 entries k = 256kb+64g+16d+4t+s (t=0..3)
+// become byte t of one dword per digit c, stored at  kb*2048 + d*512 + (g*8 + c)*16 + 4s.  Digit column 7 is zero.
+__global__ __launch_bounds__(256) void k_quant(const double* __restrict__ v, int64_t n, int64_t nkb,
+                                               const double* __restrict__ scal, uint32_t* __restrict__ out) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nkb * 64) return;
+    const int s = tid & 3, d = (tid >> 2) & 3, g = (tid >> 4) & 3;
+    const int64_t kb = tid >> 6;
+    const double mult = scal[2];
+    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        int64_t k = kb * 256 + 64 * g + 16 * d + 4 * t + s;
+        double val = (k < n) ? v[k] : 0.0;
+        long long q = (long long)rint(val * mult);
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            long long dg = (long long)(signed char)(q & 0xFF);   // balanced digit in [-128, 127]
+            q = (q - dg) >> 8;
+            dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
+        }
+    }
+    uint32_t* o = out + kb * 512 + d * 128 + g * 32 + s;   // dword units: 2048/4, 512/4, (8*16)/4
+#pragma unroll
+    for (int c = 0; c < 8; c++) o[c * 4] = dig[c];
+}
+
+// ---- the matvec kernel ----------------------------------------------------------------------------------------------
+// MODE 0 (ATx): planes r' and miss against ONE digit vector -> two accumulators per tile.
+// MODE 1 (Ax):  plane r' against digits(c), plane miss against digits(e) -> ONE accumulator per tile.
+// A wave owns supertile row group rg (64 rows = 4 tiles) over K-blocks [kb0, kb1); digits are read once per K-block
+// and used for the 4 tiles.  No LDS, no cross-lane traffic in the loop.
+struct StepRegs {
+    uint4 a[4];
+    uint4 b0[4];
+    uint4 b1[4];
+};
+
+template <int MODE>
+__device__ __forceinline__ void load_step(StepRegs& s, const uint4* __restrict__ stripes, const uint4* __restrict__ dig0,
+                                          const uint4* __restrict__ dig1, int64_t rg, int64_t nkb, int64_t kb,
+                                          int lane, bool has_b, int bofs) {
+    const uint4* ap = stripes + (rg * nkb + kb) * 256 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.a[i] = ap[i * 64];
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4* bp = dig0 + kb * 128 + bofs;   // 2048 B per K-block = 128 uint4 ; d stride 32 uint4
+#pragma unroll
+    for (int d = 0; d < 4; d++) s.b0[d] = has_b ? bp[d * 32] : z;
+    if (MODE == 1) {
+        const uint4* bq = dig1 + kb * 128 + bofs;
+#pragma unroll
+        for (int d = 0; d < 4; d++) s.b1[d] = has_b ? bq[d * 32] : z;
+    }
+}
+
+__device__ __forceinline__ v4i as_v4i(uint4 u) {
+    v4i r = {(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+    return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ void compute_step(const StepRegs& s, v4i (&accX)[4], v4i (&accY)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t ws[4] = {s.a[i].x, s.a[i].y, s.a[i].z, s.a[i].w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t w = ws[d];
+            const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
+                           e3 = (w >> 6) & 0x03030303u;
+            v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            // byte LUT {0,0,0,1}: selector byte value 3 (missing) -> 1
+            v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
+                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
+                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
+                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            const v4i B0 = as_v4i(s.b0[d]);
+            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B0, accX[i], 0, 0, 0);
+            if (MODE == 0) {
+                accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B0, accY[i], 0, 0, 0);
+            } else {
+                const v4i B1 = as_v4i(s.b1[d]);
+                accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B1, accX[i], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// partial layout: [(ks * planes + plane) * rows_p + row] * 8 + digit   (int32), rows_p = 64 * nrg
+template <int MODE>
+__global__ __launch_bounds__(256) void k_mfma_matvec(const uint4* __restrict__ stripes, const uint4* __restrict__ dig0,
+                                                     const uint4* __restrict__ dig1, int64_t nrg, int64_t nkb,
+                                                     int ksplit, int32_t* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= nrg * ksplit) return;
+    const int64_t rg = wg % nrg;
+    const int ks = (int)(wg / nrg);
+    const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
+    const int c = lane & 15, g = lane >> 4;
+    const bool has_b = c < 8;
+    const int bofs = g * 8 + (c & 7);
+
+    v4i accX[4], accY[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        accX[i] = (v4i){0, 0, 0, 0};
+        accY[i] = (v4i){0, 0, 0, 0};
+    }
+    StepRegs cur, nxt;
+    if (kb0 < kb1) load_step<MODE>(cur, stripes, dig0, dig1, rg, nkb, kb0, lane, has_b, bofs);
+    for (int64_t kb = kb0; kb < kb1; kb++) {
+        if (kb + 1 < kb1) load_step<MODE>(nxt, stripes, dig0, dig1, rg, nkb, kb + 1, lane, has_b, bofs);
+        compute_step<MODE>(cur, accX, accY);
+        cur = nxt;
+    }
+    const int64_t rows_p = nrg * 64;
+    const int planes = (MODE == 0) ? 2 : 1;
+    if (has_b) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+                partial[(((int64_t)ks * planes + 0) * rows_p + row) * 8 + c] = accX[i][reg];
+                if (MODE == 0) partial[(((int64_t)ks * planes + 1) * rows_p + row) * 8 + c] = accY[i][reg];
+            }
+        }
+    }
+}
+
+// exact digit recombination: sum_c s_c 256^c as (hi, lo) with value = hi * 2^32 + lo
+__device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo) {
+    lo = s[0] + (s[1] << 8) + (s[2] << 16) + (s[3] << 24);
+    hi = s[4] + (s[5] << 8) + (s[6] << 16);
+}
+
+// data::ATx epilogue (data.cpp:779, :825-832): out[m] = msig (sum a p - mave sum b p) / sqrt(N),
+// sum a p = (X - 3Y) scale, sum b p = P - Y scale.
+__global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
+                                                 const double* __restrict__ scal, const double* __restrict__ mave,
+                                                 const double* __restrict__ msig, double inv_sqrt_n,
+                                                 double* __restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int ks = 0; ks < ksplit; ks++) {
+        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + 0) * rows_p + m) * 8);
+        const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + 1) * rows_p + m) * 8);
+        int4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
+        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+        sy[0] += y0.x; sy[1] += y0.y; sy[2] += y0.z; sy[3] += y0.w; sy[4] += y1.x; sy[5] += y1.y; sy[6] += y1.z;
+    }
+    long long xh, xl, yh, yl;
+    combine(sx, xh, xl);
+    combine(sy, yh, yl);
+    const double scale = scal[3], P = scal[1];
+    const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
+    const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
+    out[m] = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
+}
+
+// data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
+__global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
+                                                int64_t npad, const double* __restrict__ scal,
+                                                const uint32_t* __restrict__ mask2, double post,
+                                                double* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= npad) return;
+    const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+    if (!present || n >= rows_p) {
+        out[n] = 0.0;
+        return;
+    }
+    long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int ks = 0; ks < ksplit; ks++) {
+        const int4* px = reinterpret_cast<const int4*>(partial + ((int64_t)ks * rows_p + n) * 8);
+        int4 x0 = px[0], x1 = px[1];
+        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+    }
+    long long xh, xl;
+    combine(sx, xh, xl);
+    const double T = ((double)xh * 4294967296.0 + (double)xl) * scal[3];
+    out[n] = (T - scal[1]) * post;
+}
+
+inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+}  // namespace
+
+namespace gvm {
+
+void stripes_m_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
+                     int64_t rg0, int64_t nkb) {
+    if (mc <= 0) return;
+    hipLaunchKernelGGL(k_stripes_m, dim3((unsigned)nkb, (unsigned)((mc + 63) / 64)), dim3(256), 0, s, raw, pitch, mc, N,
+                       (uint4*)stripes, rg0, nkb);
+}
+void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
+                     int64_t kb0, int64_t nkb, int64_t nrg_n) {
+    if (mc <= 0) return;
+    hipLaunchKernelGGL(k_stripes_n, dim3((unsigned)((mc + 255) / 256), (unsigned)nrg_n), dim3(256), 0, s, raw, pitch, mc,
+                       N, (uint4*)stripes, kb0, nkb);
+}
+void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
+                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(k_stats_stripes, dim3(nblk((M + 15) / 16, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M,
+                       nkb, P4, nonas, alpha_scale, mave, msig);
+}
+
+static int prep_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
+
+void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
+         double inv_sqrt_n, double* red_partial, double* out) {
+    int nb = prep_blocks(npad);
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p, npad, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p, npad, pl.nkb_m, pl.scal,
+                       (uint32_t*)pl.dig0);
+    int64_t waves = pl.nrg_m * pl.ks_m;
+    hipLaunchKernelGGL(k_mfma_matvec<0>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const uint4*)pl.stripes_m,
+                       (const uint4*)pl.dig0, (const uint4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, out);
+}
+
+void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
+        int64_t npad, double post, double* red_partial, double* out) {
+    int nb = prep_blocks(pl.M);
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, x, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, pl.scal,
+                       (uint32_t*)pl.dig0);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, pl.scal,
+                       (uint32_t*)pl.dig1);
+    int64_t waves = pl.nrg_n * pl.ks_n;
+    hipLaunchKernelGGL(k_mfma_matvec<1>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const uint4*)pl.stripes_n,
+                       (const uint4*)pl.dig0, (const uint4*)pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, out);
+}
+
+}  // namespace gvm

@@ -61,6 +61,11 @@ int gv_get_marker_stats(gv_ctx* ctx, double* mave, double* msig); /* M doubles e
 int gv_ax(gv_ctx* ctx, const double* x, double* out);
 int gv_atx(gv_ctx* ctx, const double* p, double* out);
 
+/* Resident HBM layouts built at the next gv_upload_bed / gv_synth_bed: raw_rows = the PLINK rows (pitch-padded;
+ * needed by kernel mode 0 and gv_download_bed), stripes = the two re-encoded 2-bit stripe sets of kernel mode 1
+ * (marker-major for ATx, individual-major for Ax).  Default: both.  With raw_rows = 0 the rows stream through a
+ * chunk buffer and only the stripes stay resident (2 x M*N/4 bytes). */
+int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
 /* kernel family for Ax/ATx: 0 = fp64 VALU kernels (parity anchor), 1 = i8 MFMA fixed-point kernels. */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);
 int gv_get_kernel_mode(const gv_ctx* ctx);

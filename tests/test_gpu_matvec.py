@@ -67,6 +67,40 @@ def test_stats_ax_atx_vs_oracle(oracle, N, M, miss, fna):
         ow = oracle.atx(bed, N, M, o_mave, o_msig, p)
         assert rel(w, ow) < TOL
 
+        # kernel mode 1: i8 MFMA fixed point on the stripe layouts (statistics recomputed from the stripes)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        mave1, msig1 = sh.marker_stats()
+        assert np.array_equal(mave1, mave) and np.array_equal(msig1, msig)
+        z1 = sh.Ax(x)
+        assert rel(z1, oz) < TOL
+        assert np.all(z1[N:] == 0) and np.all(z1[:N][~present] == 0)
+        w1 = sh.ATx(p)
+        assert rel(w1, ow) < TOL
+        # exact integer accumulation: bitwise reproducible
+        assert np.array_equal(sh.Ax(x), z1) and np.array_equal(sh.ATx(p), w1)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1.0, 1e30])
+def test_mfma_fixed_point_dynamic_range(oracle, scale):
+    """The fixed-point scale follows max|v|: entries 2^-40 below the maximum still contribute exactly, and the
+    result is invariant to the overall magnitude; an all-zero vector gives exact zeros."""
+    N, M = 3000, 500
+    rng = np.random.default_rng(17)
+    bed = synth.synth_bed(N, M, seed=21, miss_ppm=10000)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        x = rng.standard_normal(M) * 10.0 ** rng.uniform(-12, 0, M) * scale
+        oz = oracle.ax(bed, N, M, mave, msig, x)
+        assert rel(sh.Ax(x), oz) < TOL
+        p = np.zeros(4 * ((N + 3) // 4))
+        p[:N] = rng.standard_normal(N) * 10.0 ** rng.uniform(-12, 0, N) * scale
+        assert rel(sh.ATx(p), oracle.atx(bed, N, M, mave, msig, p)) < TOL
+        assert np.all(sh.Ax(np.zeros(M)) == 0) and np.all(sh.ATx(np.zeros(p.size)) == 0)
+
 
 def test_monomorphic_and_all_missing_markers(oracle):
     """Guards of data.cpp:462-483: sumb == 0 -> mave 0; sumsqr == 0 -> msig 1."""
