@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the gVAMP hot path on MI355X.
+
+Metric (BASELINE.json): genotype matvec GB/s at N=400k x Mt=1M, 1/2/4/8 GPUs (strong scaling: the marker
+dimension is sharded exactly as the reference shards over MPI ranks, utilities.cpp:259-291).
+
+A "step" is one application of the LMMSE operator of the CG loop (vamp.cpp:1074-1118):
+    d = tau * A^T (A p) + gam2 * p   =  data::Ax (+ N-vector all-reduce across ranks) + data::ATx + axpy
+i.e. two streams over the rank's whole 2-bit genotype shard.  `value` = algorithmic bytes of the WHOLE job per
+step (2 x (Mt*ceil(N/4) + 24*Mt + 32*ceil(N/4))) x steps / wall time, inputs resident in HBM.
+
+One process per GPU:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=400000, help="individuals")
+    ap.add_argument("--Mt", type=int, default=1000000, help="total markers")
+    ap.add_argument("--mode", type=int, default=1, help="0 = fp64 VALU kernels, 1 = i8 MFMA fixed point")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-markers", type=int, default=0, help="markers of the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def divide_work(Mt, nranks, rank):
+    """utilities.cpp:259-291"""
+    size, modu = divmod(Mt, nranks)
+    lens = [size + 1 if i < modu else size for i in range(nranks)]
+    return lens[rank], sum(lens[:rank])
+
+
+def alg_bytes(N, M):
+    mb = (N + 3) // 4
+    return M * mb + 24 * M + 32 * mb
+
+
+def cpu_baseline(N, seed, want_markers, device):
+    """Oracle (CPU restatement, OpenMP over all host cores) timed on a bounded sample: the first `m` markers of
+    the same synthetic matrix, one Ax + one ATx."""
+    from gvamp_amd import capi
+    from oracle import gvoracle as go
+    cores = os.cpu_count() or 1
+    mb = (N + 3) // 4
+    m = want_markers or max(256, min(20000, int(2.0e9 // mb)))
+    with capi.Shard(N, m, Mt=m, S=0, device=device) as sh:
+        sh.set_layout(True, False)
+        sh.synth_bed(seed, 5000)
+        bed = sh.download_bed()
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    mave, msig = go.marker_stats(bed, N, m, nthreads=cores)
+    x = rng.standard_normal(m)
+    reps, t_ax, t_atx = 0, 0.0, 0.0
+    while reps < 1 or (t_ax + t_atx < 8.0 and reps < 50):
+        t1 = time.time()
+        z = go.ax(bed, N, m, mave, msig, x, nthreads=cores)
+        t2 = time.time()
+        go.atx(bed, N, m, mave, msig, z, nthreads=cores)
+        t3 = time.time()
+        t_ax += t2 - t1
+        t_atx += t3 - t2
+        reps += 1
+    gbps = 2 * alg_bytes(N, m) * reps / (t_ax + t_atx) / 1e9
+    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ (OpenMP, %d threads) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix, "
+                      "%d repetitions; Ax %.3f s, ATx %.3f s per call" % (cores, m, N, reps, t_ax / reps, t_atx / reps),
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
+                  % (a.gpus, world, a.gpus), file=sys.stderr)
+        a.gpus = world
+
+    # torch first: it brings its own ROCm runtime libraries, and libgvamp.so then binds to the same loaded
+    # libamdhip64 / librccl (same SONAMEs) -- the other order leaves torch without a device.
+    import torch
+    import torch.distributed as dist
+    from gvamp_amd import capi      # the HIP library: raises if it is not built / no GPU
+    capi.load()
+
+    dev_ok = torch.cuda.is_available()
+    if not dev_ok:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous + timing reductions only;
+        # the data path's collectives are RCCL calls inside libgvamp (gv_comm_init below)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    N, Mt = a.N, a.Mt
+    M, S = divide_work(Mt, world, rank)
+    sh = capi.Shard(N, M, Mt=Mt, S=S, device=local_rank)
+    if a.mode == 1:
+        sh.set_layout(False, True)     # stripes only: 2 x M*N/4 bytes resident
+    else:
+        sh.set_layout(True, False)
+    sh.set_kernel_mode(a.mode)
+    t0 = time.time()
+    sh.synth_bed(a.seed, 5000)
+    sh.compute_markers_statistics()
+    t_ingest = time.time() - t0
+    if world > 1:
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        sh.comm_init(world, rank, uid[0])
+
+    rng = np.random.default_rng(7)          # same p on every rank's own slice
+    p = sh.vecM(rng.standard_normal(Mt)[S:S + M])
+    d = sh.vecM()
+    tau, gam2 = 2.0, 1.35
+
+    def step():
+        sh.lmmse_mult(p, tau, gam2, d)
+
+    for _ in range(a.warmup):
+        step()
+    sh.set_timing(2)
+    sh.counters(reset=True)
+    sh.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sh.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cnt = sh.counters()
+    sh.set_timing(0)
+
+    job_bytes = 2 * alg_bytes(N, Mt)
+    value = job_bytes * a.steps / dt / 1e9
+    # roofline of the dominant kernel on THIS rank's shard (Ax: the 2-bit-transposed stream)
+    shard_bytes = alg_bytes(N, M)
+    ms_ax = cnt["ms_ax_kernel"] / max(cnt["n_ax_kernel"], 1)
+    ms_atx = cnt["ms_atx_kernel"] / max(cnt["n_atx_kernel"], 1)
+    ax_gbps = shard_bytes / (ms_ax * 1e-3) / 1e9 if ms_ax > 0 else 0.0
+    atx_gbps = shard_bytes / (ms_atx * 1e-3) / 1e9 if ms_atx > 0 else 0.0
+    kname = "k_mfma_matvec<1> (Ax)" if a.mode == 1 else "k_ax_f64"
+    out = {
+        "metric": "genotype_matvec_GBps", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "i8 MFMA / i32 accumulate, 56-bit fixed point (fp64 in/out)" if a.mode == 1 else "f64",
+        "data": "synthetic",
+        "config": {"workload": "N=%d x Mt=%d 2-bit genotype matrix, step = lmmse_mult = Ax + N-vector all-reduce + ATx "
+                               "(vamp.cpp:1074-1118)" % (N, Mt),
+                   "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
+                   "ingest_s": round(t_ingest, 2)},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(ax_gbps / 8000.0, 4), "traffic": None,
+                     "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4)},
+        "kernels": {"ax": {"avg_ms": round(ms_ax, 4), "GBps": round(ax_gbps, 1), "launches": cnt["n_ax_kernel"]},
+                    "atx": {"avg_ms": round(ms_atx, 4), "GBps": round(atx_gbps, 1), "launches": cnt["n_atx_kernel"]}},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
+    sh.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,8 @@ class CgStats(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("n_ax", C.c_int64), ("n_atx", C.c_int64), ("ms_ax", C.c_double), ("ms_atx", C.c_double),
-                ("ms_allreduce", C.c_double)]
+                ("ms_allreduce", C.c_double), ("n_ax_kernel", C.c_int64), ("n_atx_kernel", C.c_int64),
+                ("ms_ax_kernel", C.c_double), ("ms_atx_kernel", C.c_double)]
 
 
 def load():
@@ -312,7 +313,9 @@ class Shard:
         self._ck(self.L.gv_get_counters(self.h, C.byref(c)))
         if reset:
             self._ck(self.L.gv_reset_counters(self.h))
-        return dict(n_ax=c.n_ax, n_atx=c.n_atx, ms_ax=c.ms_ax, ms_atx=c.ms_atx, ms_allreduce=c.ms_allreduce)
+        return dict(n_ax=c.n_ax, n_atx=c.n_atx, ms_ax=c.ms_ax, ms_atx=c.ms_atx, ms_allreduce=c.ms_allreduce,
+                    n_ax_kernel=c.n_ax_kernel, n_atx_kernel=c.n_atx_kernel, ms_ax_kernel=c.ms_ax_kernel,
+                    ms_atx_kernel=c.ms_atx_kernel)
 
     def synchronize(self):
         self._ck(self.L.gv_synchronize(self.h))

@@ -96,7 +96,7 @@ struct Timer {
     gv_ctx* c;
     double* acc;
     bool on;
-    Timer(gv_ctx* c_, double* acc_) : c(c_), acc(acc_), on(c_->timing != 0) {
+    Timer(gv_ctx* c_, double* acc_) : c(c_), acc(acc_), on(c_->timing == 1) {
         if (on) (void)hipEventRecord(c->ev0, c->stream);
     }
     void stop() {
@@ -110,6 +110,31 @@ struct Timer {
     }
 };
 
+// timing == 2: resolve the pending event pairs into the kernel counters
+void ev_resolve(gv_ctx* c) {
+    for (size_t i = 0; i < c->ev_used; i++) {
+        gv_ctx::EvRec& r = c->ev_pool[i];
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            if (r.kind == 0) { c->cnt.ms_ax_kernel += ms; c->cnt.n_ax_kernel++; }
+            else { c->cnt.ms_atx_kernel += ms; c->cnt.n_atx_kernel++; }
+        }
+    }
+    c->ev_used = 0;
+}
+gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
+    if (c->timing != 2) return nullptr;
+    if (c->ev_used == 4096) ev_resolve(c);
+    if (c->ev_used == c->ev_pool.size()) {
+        gv_ctx::EvRec r{nullptr, nullptr, kind};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(r);
+    }
+    gv_ctx::EvRec* r = &c->ev_pool[c->ev_used++];
+    r->kind = kind;
+    return r;
+}
+
 // data::Ax on device pointers.  x: M doubles, out: npad doubles.
 int ax_device(gv_ctx* c, const double* x, double* out) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
@@ -118,6 +143,9 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
         Timer t(c, &c->cnt.ms_ax);
+        gv_ctx::EvRec* er = ev_next(c, 0);
+        c->plan.ev0 = er ? er->a : nullptr;
+        c->plan.ev1 = er ? er->b : nullptr;
         gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out);
         KCHK(c);
         t.stop();
@@ -125,7 +153,10 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
         NEED(c, c->have_raw, "Ax: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
         Timer t(c, &c->cnt.ms_ax);
         gvk::ax_table(c->stream, x, c->mave, c->msig, c->M, c->t3);
+        gv_ctx::EvRec* er = ev_next(c, 0);
+        if (er) (void)hipEventRecord(er->a, c->stream);
         gvk::ax_f64(c->stream, c->bed, c->M, c->pitch, c->t3, c->ax_chunks, c->ax_partial, c->npad);
+        if (er) (void)hipEventRecord(er->b, c->stream);
         gvk::ax_reduce(c->stream, c->ax_partial, c->ax_chunks, c->npad, c->mask2, multi ? 1.0 : scale, out);
         KCHK(c);
         t.stop();
@@ -147,10 +178,16 @@ int atx_device(gv_ctx* c, const double* p, double* out) {
     Timer t(c, &c->cnt.ms_atx);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "ATx: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+        gv_ctx::EvRec* er = ev_next(c, 1);
+        c->plan.ev0 = er ? er->a : nullptr;
+        c->plan.ev1 = er ? er->b : nullptr;
         gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out);
     } else {
         NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
+        gv_ctx::EvRec* er = ev_next(c, 1);
+        if (er) (void)hipEventRecord(er->a, c->stream);
         gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
+        if (er) (void)hipEventRecord(er->b, c->stream);
     }
     KCHK(c);
     t.stop();
@@ -228,6 +265,7 @@ void gv_destroy(gv_ctx* c) {
     if (c->red_partial) (void)hipFree(c->red_partial);
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
+    for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -296,12 +334,11 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
         HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
         HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
-        HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 2048));
-        HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 2048));
+        HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 4));
-        size_t pa = (size_t)pl.ks_m * 2 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * pl.nrg_n * 64 * 8 * 4;
+        size_t pa = (size_t)pl.ks_m * 2 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 2 * pl.nrg_n * 64 * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
@@ -682,10 +719,12 @@ int gv_set_timing(gv_ctx* c, int timing) {
     return 0;
 }
 int gv_get_counters(gv_ctx* c, gv_counters* out) {
+    ev_resolve(c);
     *out = c->cnt;
     return 0;
 }
 int gv_reset_counters(gv_ctx* c) {
+    ev_resolve(c);
     c->cnt = gv_counters{};
     return 0;
 }

@@ -57,6 +57,9 @@ struct gv_ctx {
     int timing = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     gv_counters cnt{};
+    struct EvRec { hipEvent_t a, b; int kind; };
+    std::vector<EvRec> ev_pool;   // timing == 2: un-synchronised event pairs around the matvec kernels
+    size_t ev_used = 0;
 };
 
 constexpr int RED_BLOCKS = 1024;

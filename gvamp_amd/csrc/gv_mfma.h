@@ -19,6 +19,7 @@ struct Plan {
     double* scal = nullptr;         // 4 doubles: amax, sum, 2^(54-e), 2^(e-54)
     int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
     size_t partial_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // when set: recorded around the matvec kernel launch (roofline timing)
 };
 
 void stripes_m_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,

@@ -221,9 +221,12 @@ __global__ __launch_bounds__(256) void k_prep_final(const double* __restrict__ p
 }
 
 // fixed-point digits of v in MFMA B-operand order.  Thread = (kb, g, d, s): 4 entries k = 256kb+64g+16d+4t+s (t=0..3)
-// become byte t of one dword per digit c, stored at  kb*2048 + d*512 + (g*8 + c)*16 + 4s.  Digit column 7 is zero.
+// become byte t of one dword per digit c, stored at byte  ((kb*4 + d)*4 + g)*ncol*16 + (col0 + c)*16 + 4s.
+// Digit column 7 of each vector is zero.
+// ncol = 8 (ATx: 2 KiB per K-block) or 16 (Ax: [c | e], 4 KiB per K-block); col0 = first column of this vector.
 __global__ __launch_bounds__(256) void k_quant(const double* __restrict__ v, int64_t n, int64_t nkb,
-                                               const double* __restrict__ scal, uint32_t* __restrict__ out) {
+                                               const double* __restrict__ scal, uint32_t* __restrict__ out, int ncol,
+                                               int col0) {
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nkb * 64) return;
     const int s = tid & 3, d = (tid >> 2) & 3, g = (tid >> 4) & 3;
@@ -242,78 +245,65 @@ __global__ __launch_bounds__(256) void k_quant(const double* __restrict__ v, int
             dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
         }
     }
-    uint32_t* o = out + kb * 512 + d * 128 + g * 32 + s;   // dword units: 2048/4, 512/4, (8*16)/4
+    // dword units: K-block = 64*ncol, dword-slot d = 16*ncol, lane-group g = 4*ncol, column = 4
+    uint32_t* o = out + kb * (64 * ncol) + d * (16 * ncol) + g * (4 * ncol) + col0 * 4 + s;
 #pragma unroll
     for (int c = 0; c < 8; c++) o[c * 4] = dig[c];
 }
 
 // ---- the matvec kernel ----------------------------------------------------------------------------------------------
-// MODE 0 (ATx): planes r' and miss against ONE digit vector -> two accumulators per tile.
-// MODE 1 (Ax):  plane r' against digits(c), plane miss against digits(e) -> ONE accumulator per tile.
-// A wave owns supertile row group rg (64 rows = 4 tiles) over K-blocks [kb0, kb1); digits are read once per K-block
-// and used for the 4 tiles.  No LDS, no cross-lane traffic in the loop.
-struct StepRegs {
-    uint4 a[4];
-    uint4 b0[4];
-    uint4 b1[4];
-};
+// One kernel for both products.  Per K-block (256 K-entries) a wave reads its supertile (4 tiles x 1 KiB, streamed
+// once, non-temporal) and ONE digit block, and issues per (tile, dword) two MFMAs: plane r' -> accX, plane miss -> accY.
+//   MODE 0 (ATx): digit block = digits(p), 8 columns (2 KiB); lanes c >= 8 alias column c-8 (their results are
+//                 never stored).  result rows: X = accX[:, 0:8], Y = accY[:, 0:8].
+//   MODE 1 (Ax):  digit block = [digits(c) | digits(e)], 16 columns (4 KiB).  r'.c comes out in accX[:, 0:8] and
+//                 miss.e in accY[:, 8:16]; both are stored as two "planes" and added (exactly) by k_fin_ax.
+// Software pipeline in registers: NA = 3 supertile buffers (two K-blocks in flight from HBM) and NB = 2 digit
+// buffers (one in flight from L2).  No LDS, no cross-lane traffic, no barriers in the loop.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+struct ABuf { u32x4 t[4]; };
+struct BBuf { u32x4 d[4]; };
+
+__device__ __forceinline__ void load_a(ABuf& a, const u32x4* __restrict__ ap) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) a.t[i] = __builtin_nontemporal_load(ap + i * 64);
+}
 template <int MODE>
-__device__ __forceinline__ void load_step(StepRegs& s, const uint4* __restrict__ stripes, const uint4* __restrict__ dig0,
-                                          const uint4* __restrict__ dig1, int64_t rg, int64_t nkb, int64_t kb,
-                                          int lane, bool has_b, int bofs) {
-    const uint4* ap = stripes + (rg * nkb + kb) * 256 + lane;
+__device__ __forceinline__ void load_b(BBuf& b, const u32x4* __restrict__ bp) {
+    constexpr int DS = (MODE == 0) ? 32 : 64;   // u32x4 per dword-slot d
 #pragma unroll
-    for (int i = 0; i < 4; i++) s.a[i] = ap[i * 64];
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const uint4* bp = dig0 + kb * 128 + bofs;   // 2048 B per K-block = 128 uint4 ; d stride 32 uint4
-#pragma unroll
-    for (int d = 0; d < 4; d++) s.b0[d] = has_b ? bp[d * 32] : z;
-    if (MODE == 1) {
-        const uint4* bq = dig1 + kb * 128 + bofs;
-#pragma unroll
-        for (int d = 0; d < 4; d++) s.b1[d] = has_b ? bq[d * 32] : z;
-    }
+    for (int d = 0; d < 4; d++) b.d[d] = bp[d * DS];
 }
 
-__device__ __forceinline__ v4i as_v4i(uint4 u) {
-    v4i r = {(int)u.x, (int)u.y, (int)u.z, (int)u.w};
-    return r;
-}
-
-template <int MODE>
-__device__ __forceinline__ void compute_step(const StepRegs& s, v4i (&accX)[4], v4i (&accY)[4]) {
+__device__ __forceinline__ void compute_step(const ABuf& a, const BBuf& b, v4i (&accX)[4], v4i (&accY)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t ws[4] = {s.a[i].x, s.a[i].y, s.a[i].z, s.a[i].w};
+    for (int d = 0; d < 4; d++) {
+        const v4i B = {(int)b.d[d].x, (int)b.d[d].y, (int)b.d[d].z, (int)b.d[d].w};
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint32_t w = ws[d];
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w = a.t[i][d];
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
-            v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B, accX[i], 0, 0, 0);
             // byte LUT {0,0,0,1}: selector byte value 3 (missing) -> 1
-            v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                     (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
-            const v4i B0 = as_v4i(s.b0[d]);
-            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B0, accX[i], 0, 0, 0);
-            if (MODE == 0) {
-                accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B0, accY[i], 0, 0, 0);
-            } else {
-                const v4i B1 = as_v4i(s.b1[d]);
-                accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B1, accX[i], 0, 0, 0);
-            }
+            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B, accY[i], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the X/Y operand live ranges inside one dword-slot
     }
 }
 
-// partial layout: [(ks * planes + plane) * rows_p + row] * 8 + digit   (int32), rows_p = 64 * nrg
+// partial layout: [(ks * 2 + plane) * rows_p + row] * 8 + digit   (int32), rows_p = 64 * nrg
 template <int MODE>
-__global__ __launch_bounds__(256) void k_mfma_matvec(const uint4* __restrict__ stripes, const uint4* __restrict__ dig0,
-                                                     const uint4* __restrict__ dig1, int64_t nrg, int64_t nkb,
-                                                     int ksplit, int32_t* __restrict__ partial) {
+__global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig,
+                                                     int64_t nrg, int64_t nkb, int ksplit,
+                                                     int32_t* __restrict__ partial) {
+    constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of the digit buffer
     const int lane = threadIdx.x & 63;
     const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= nrg * ksplit) return;
@@ -321,8 +311,7 @@ __global__ __launch_bounds__(256) void k_mfma_matvec(const uint4* __restrict__ s
     const int ks = (int)(wg / nrg);
     const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
     const int c = lane & 15, g = lane >> 4;
-    const bool has_b = c < 8;
-    const int bofs = g * 8 + (c & 7);
+    const int bofs = (MODE == 0) ? g * 8 + (c & 7) : g * 16 + c;
 
     v4i accX[4], accY[4];
 #pragma unroll
@@ -330,24 +319,38 @@ __global__ __launch_bounds__(256) void k_mfma_matvec(const uint4* __restrict__ s
         accX[i] = (v4i){0, 0, 0, 0};
         accY[i] = (v4i){0, 0, 0, 0};
     }
-    StepRegs cur, nxt;
-    if (kb0 < kb1) load_step<MODE>(cur, stripes, dig0, dig1, rg, nkb, kb0, lane, has_b, bofs);
-    for (int64_t kb = kb0; kb < kb1; kb++) {
-        if (kb + 1 < kb1) load_step<MODE>(nxt, stripes, dig0, dig1, rg, nkb, kb + 1, lane, has_b, bofs);
-        compute_step<MODE>(cur, accX, accY);
-        cur = nxt;
+    const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
+    const u32x4* bp = dig + kb0 * KBS + bofs;
+    const int64_t nsteps = kb1 - kb0;
+    if (nsteps <= 0) return;   // cannot happen (ksplit <= nkb); rows of an empty range would stay unwritten
+    // Unconditional, clamped prefetch (no branches around loads): the tail re-reads the last K-block.
+    const int64_t last = nsteps - 1;
+    ABuf a0, a1, a2;
+    BBuf b0, b1;
+    load_a(a0, ap);
+    load_b<MODE>(b0, bp);
+    load_a(a1, ap + (last < 1 ? last : 1) * 256);
+#pragma unroll 1
+    for (int64_t st = 0; st < nsteps; st++) {
+        const int64_t n2 = st + 2 < last ? st + 2 : last, n1 = st + 1 < last ? st + 1 : last;
+        load_a(a2, ap + n2 * 256);
+        load_b<MODE>(b1, bp + n1 * KBS);
+        compute_step(a0, b0, accX, accY);
+        a0 = a1;
+        a1 = a2;
+        b0 = b1;
     }
     const int64_t rows_p = nrg * 64;
-    const int planes = (MODE == 0) ? 2 : 1;
-    if (has_b) {
+    const bool stX = c < 8;                         // accX: digit columns 0..7
+    const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);   // accY: columns 0..7 (ATx) or 8..15 (Ax, digits of e)
+    const int cd = c & 7;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 4; i++) {
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
-                partial[(((int64_t)ks * planes + 0) * rows_p + row) * 8 + c] = accX[i][reg];
-                if (MODE == 0) partial[(((int64_t)ks * planes + 1) * rows_p + row) * 8 + c] = accY[i][reg];
-            }
+        for (int reg = 0; reg < 4; reg++) {
+            const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+            if (stX) partial[(((int64_t)ks * 2 + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
+            if (stY) partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
         }
     }
 }
@@ -397,9 +400,11 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     }
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int ks = 0; ks < ksplit; ks++) {
-        const int4* px = reinterpret_cast<const int4*>(partial + ((int64_t)ks * rows_p + n) * 8);
-        int4 x0 = px[0], x1 = px[1];
-        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+        for (int plane = 0; plane < 2; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
+            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + plane) * rows_p + n) * 8);
+            int4 x0 = px[0], x1 = px[1];
+            sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+        }
     }
     long long xh, xl;
     combine(sx, xh, xl);
@@ -443,10 +448,12 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
     hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p, npad, red_partial);
     hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p, npad, pl.nkb_m, pl.scal,
-                       (uint32_t*)pl.dig0);
+                       (uint32_t*)pl.dig0, 8, 0);
     int64_t waves = pl.nrg_m * pl.ks_m;
-    hipLaunchKernelGGL(k_mfma_matvec<0>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const uint4*)pl.stripes_m,
-                       (const uint4*)pl.dig0, (const uint4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    hipLaunchKernelGGL(k_mfma_matvec<0>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
+                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, out);
 }
@@ -457,12 +464,14 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
     hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, x, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
     hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, pl.scal,
-                       (uint32_t*)pl.dig0);
+                       (uint32_t*)pl.dig0, 16, 0);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, pl.scal,
-                       (uint32_t*)pl.dig1);
+                       (uint32_t*)pl.dig0, 16, 8);
     int64_t waves = pl.nrg_n * pl.ks_n;
-    hipLaunchKernelGGL(k_mfma_matvec<1>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const uint4*)pl.stripes_n,
-                       (const uint4*)pl.dig0, (const uint4*)pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    hipLaunchKernelGGL(k_mfma_matvec<1>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_n,
+                       (const u32x4*)pl.dig0, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
                        pl.scal, mask2, post, out);
 }

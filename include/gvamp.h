@@ -131,8 +131,12 @@ typedef struct {
     int64_t n_ax, n_atx;          /* kernel launches of each matvec since the last reset */
     double ms_ax, ms_atx;         /* HIP-event time spent in them (on the context's stream) */
     double ms_allreduce;          /* HIP-event time of the N-vector all-reduces */
+    int64_t n_ax_kernel, n_atx_kernel;   /* timing == 2: launches of the dominant matvec kernel measured ... */
+    double ms_ax_kernel, ms_atx_kernel;  /* ... and their summed HIP-event durations */
 } gv_counters;
-/* timing != 0 brackets every matvec with HIP events (adds a sync per call; bench/roofline only) */
+/* timing: 0 off; 1 brackets every whole matvec (prep + kernel + epilogue) with HIP events and synchronises per
+ * call (development); 2 records event pairs around the dominant matvec kernel only, WITHOUT synchronising --
+ * they are resolved in gv_get_counters (live roofline measurement inside a timed region). */
 int gv_set_timing(gv_ctx* ctx, int timing);
 int gv_get_counters(gv_ctx* ctx, gv_counters* out);
 int gv_reset_counters(gv_ctx* ctx);
