@@ -1,0 +1,238 @@
+// data.cpp -- see data.hpp.
+#include "data.hpp"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+#include "utilities.hpp"
+
+namespace {
+[[noreturn]] void die(const std::string& msg) {
+    std::cout << msg << std::endl;
+    exit(EXIT_FAILURE);
+}
+void ck(gv_ctx* ctx, int rc, const char* what) {
+    if (rc) die(std::string("FATAL: ") + what + ": " + gv_last_error(ctx));
+}
+// whitespace split that keeps the reference's quirk: a leading blank yields an empty token 0 (std::regex
+// "\\s+" with sregex_token_iterator(-1), data.cpp:143-144)
+std::vector<std::string> split_ws(const std::string& line) {
+    std::vector<std::string> tok;
+    size_t i = 0, n = line.size();
+    if (n && isspace((unsigned char)line[0])) {
+        tok.push_back("");
+        while (i < n && isspace((unsigned char)line[i])) i++;
+    }
+    while (i < n) {
+        size_t j = i;
+        while (j < n && !isspace((unsigned char)line[j])) j++;
+        tok.push_back(line.substr(i, j - i));
+        i = j;
+        while (i < n && isspace((unsigned char)line[i])) i++;
+    }
+    return tok;
+}
+}  // namespace
+
+void data::open_device(int device, int kernel_mode) {
+    if (device < 0) device = gv_env_local_rank();
+    if (gv_create(device, &ctx)) die(std::string("FATAL: ") + gv_last_error(nullptr));
+    ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
+    ck(ctx, gv_set_layout(ctx, kernel_mode == 0, kernel_mode != 0), "gv_set_layout");
+    ck(ctx, gv_set_kernel_mode(ctx, kernel_mode), "gv_set_kernel_mode");
+    const int nranks = gv_env_nranks();
+    if (nranks > 1) {
+        // one process per GPU: rank 0 publishes the RCCL unique id through a file next to the outputs
+        const char* rdv = getenv("GVAMP_RENDEZVOUS");
+        std::string path = rdv ? rdv : "/tmp/gvamp_rccl_id";
+        path += "." + std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+        unsigned char id[128];
+        if (rank == 0) {
+            ck(nullptr, gv_comm_unique_id(id), "gv_comm_unique_id");
+            std::string tmp = path + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, 128, f) != 128) die("FATAL: cannot write " + tmp);
+            fclose(f);
+            rename(tmp.c_str(), path.c_str());
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = fopen(path.c_str(), "rb")); tries++) {
+                struct timespec ts = {0, 10000000};
+                nanosleep(&ts, nullptr);
+            }
+            if (!f || fread(id, 1, 128, f) != 128) die("FATAL: cannot read " + path);
+            fclose(f);
+        }
+        ck(ctx, gv_comm_init(ctx, nranks, rank, id), "gv_comm_init");
+        if (rank == 0) remove(path.c_str());
+    }
+}
+
+void data::push_mask() { ck(ctx, gv_set_mask(ctx, mask4.data(), nonas), "gv_set_mask"); }
+
+data::data(std::vector<double> y, std::string genofp, const int N, const int M, const int Mt, const int S,
+           const int rank, std::string type_data, double alpha_scale, std::string bimfp, int device, int kernel_mode)
+    : bimfp(bimfp), type_data(type_data), N(N), M(M), Mt(Mt), S(S), rank(rank), phen_data(y), alpha_scale(alpha_scale) {
+    if (type_data != "bed") die("FATAL: only type_data == \"bed\" is supported by this build");
+    mbytes = (N % 4) ? (size_t)N / 4 + 1 : (size_t)N / 4;
+    im4 = (int)mbytes;
+    mask4.assign(mbytes, 0x0F);                       // data.cpp:86-89
+    if (N % 4) {                                      // data.cpp:92-98
+        for (int i = N % 4; i < 4; i++) mask4[N / 4] &= ~(0b1 << i);
+        std::cout << "rank = " << rank << ": setting last " << 4 - N % 4 << " bits to NAs" << std::endl;
+    }
+    set_nonas(N);
+    open_device(device, kernel_mode);
+    push_mask();
+    bedfp = genofp;
+    read_genotype_data();
+    compute_markers_statistics();
+}
+
+data::data(std::string fp, std::string genofp, const int N, const int M, const int Mt, const int S, const int rank,
+           std::string type_data, double alpha_scale, std::string bimfp, int device, int kernel_mode)
+    : phenfp(fp), bimfp(bimfp), type_data(type_data), N(N), M(M), Mt(Mt), S(S), rank(rank), alpha_scale(alpha_scale) {
+    if (type_data != "bed") die("FATAL: only type_data == \"bed\" is supported by this build");
+    mbytes = (N % 4) ? (size_t)N / 4 + 1 : (size_t)N / 4;
+    im4 = (int)mbytes;
+    bedfp = genofp;
+    read_phen();
+    open_device(device, kernel_mode);
+    push_mask();
+    read_genotype_data();
+    compute_markers_statistics();
+}
+
+data::data(gv_ctx* resident, std::vector<double> y, const int N, const int M, const int Mt, const int S, const int rank,
+           const std::vector<unsigned char>* m4, int nonas_, double alpha_scale)
+    : N(N), M(M), Mt(Mt), S(S), rank(rank), phen_data(y), alpha_scale(alpha_scale), ctx(resident), owns_ctx(false) {
+    mbytes = (N % 4) ? (size_t)N / 4 + 1 : (size_t)N / 4;
+    im4 = (int)mbytes;
+    if (m4) {
+        mask4 = *m4;
+        nonas = nonas_;
+    } else {
+        mask4.assign(mbytes, 0x0F);
+        if (N % 4)
+            for (int i = N % 4; i < 4; i++) mask4[N / 4] &= ~(0b1 << i);
+        nonas = N;
+    }
+    push_mask();
+    compute_markers_statistics();
+}
+
+data::~data() {
+    if (ctx && owns_ctx) gv_destroy(ctx);
+}
+
+// data.cpp:128-192: 3rd token of every line; "NA" -> DBL_MAX and mask bit cleared; scaled (not centred) by
+// sqrt((nonas-1) / sum (y - mean)^2) -- NA slots are scaled too and become +inf, as in the reference.
+void data::read_phen() {
+    std::ifstream infile(phenfp);
+    if (!infile.is_open()) die("FATAL: could not open phenotype file: " + phenfp);
+    std::string line;
+    double sum = 0.0;
+    int line_n = 0;
+    nonas = nas = 0;
+    mask4.clear();
+    phen_data.clear();
+    while (getline(infile, line)) {
+        const int k = line_n % 4;
+        if (k == 0) mask4.push_back(0x0F);
+        std::vector<std::string> tokens = split_ws(line);
+        if (tokens.size() < 3) die("FATAL: phenotype line with fewer than 3 columns in " + phenfp);
+        if (tokens[2] == "NA") {
+            nas++;
+            phen_data.push_back(std::numeric_limits<double>::max());
+            mask4[line_n / 4] &= ~(0b1 << k);
+        } else {
+            nonas++;
+            const double v = atof(tokens[2].c_str());
+            phen_data.push_back(v);
+            sum += v;
+        }
+        line_n++;
+    }
+    assert(nas + nonas == N);
+    if (line_n % 4) {
+        for (int i = line_n % 4; i < 4; i++) mask4[line_n / 4] &= ~(0b1 << i);
+        std::cout << "rank = " << rank << ": setting last " << 4 - line_n % 4 << " bits to NAs" << std::endl;
+    }
+    const double avg = sum / double(nonas);
+    double sqn = 0.0;
+    for (double v : phen_data)
+        if (v != std::numeric_limits<double>::max()) sqn += (v - avg) * (v - avg);
+    sqn = sqrt(double(nonas - 1) / sqn);
+    for (double& v : phen_data) v *= sqn;
+    intercept = avg;
+    scale = sqn;
+}
+
+// data.cpp:201-234: this rank's slab of the SNP-major .bed at byte offset 3 + S*mbytes (magic bytes skipped, not
+// validated), handed to the device in bounded pieces.
+void data::read_genotype_data() {
+    const size_t size_bytes = size_t(M) * mbytes;
+    std::vector<unsigned char> buf(size_bytes);
+    FILE* f = fopen(bedfp.c_str(), "rb");
+    if (!f) die("FATAL: could not open bed file: " + bedfp);
+    if (fseeko(f, (off_t)(3 + size_t(S) * mbytes), SEEK_SET) != 0 || fread(buf.data(), 1, size_bytes, f) != size_bytes)
+        die("FATAL: short read on bed file: " + bedfp);
+    fclose(f);
+    printf("INFO   : rank %d has allocated %zu bytes (%.3f GB) for raw data.\n", rank, size_bytes, double(size_bytes) / 1.0E9);
+    ck(ctx, gv_upload_bed(ctx, buf.data(), size_bytes), "gv_upload_bed");
+}
+
+std::vector<int> data::read_chromosome_info(std::string bim_file) {
+    std::vector<int> chroms;
+    std::ifstream infile(bim_file);
+    if (!infile.is_open()) die("FATAL: could not open bim file: " + bim_file);
+    std::string line;
+    for (int line_n = 0; getline(infile, line); line_n++) {
+        if (line_n < S || line_n >= S + M) continue;
+        std::vector<std::string> tokens = split_ws(line);
+        chroms.push_back(tokens[0] == "X" ? 23 : (int)atof(tokens[0].c_str()));
+    }
+    return chroms;
+}
+
+void data::compute_markers_statistics() {
+    ck(ctx, gv_marker_stats(ctx, alpha_scale), "gv_marker_stats");
+    mave.assign(M > 0 ? M : 1, 0.0);
+    msig.assign(M > 0 ? M : 1, 0.0);
+    ck(ctx, gv_get_marker_stats(ctx, mave.data(), msig.data()), "gv_get_marker_stats");
+}
+
+std::vector<double> data::Ax(double* __restrict__ phen) {
+    std::vector<double> out(4 * mbytes, 0.0);
+    ck(ctx, gv_ax(ctx, phen, out.data()), "gv_ax");
+    return out;
+}
+
+std::vector<double> data::ATx(double* __restrict__ phen) {
+    std::vector<double> out(M > 0 ? M : 0, 0.0);
+    ck(ctx, gv_atx(ctx, phen, out.data()), "gv_atx");
+    return out;
+}
+
+// length 4*mbytes (the reference returns N entries and lets ATx read past the end when N % 4 != 0)
+std::vector<double> data::filter_pheno() {
+    std::vector<double> y(4 * mbytes, 0.0);
+    for (int n = 0; n < N; n++)
+        if ((mask4[n / 4] >> (n % 4)) & 1) y[n] = phen_data[n];
+    return y;
+}
+
+std::vector<double> data::filter_pheno(int* nonnan) {
+    std::vector<double> y = filter_pheno();
+    int cnt = 0;
+    for (int n = 0; n < N; n++) cnt += (mask4[n / 4] >> (n % 4)) & 1;
+    *nonnan = cnt;
+    return y;
+}

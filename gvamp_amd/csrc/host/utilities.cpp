@@ -1,0 +1,139 @@
+// utilities.cpp -- see utilities.hpp.
+#include "utilities.hpp"
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <random>
+#include <stdexcept>
+
+static int env_int(const char* k, int dflt) {
+    const char* v = getenv(k);
+    return v ? atoi(v) : dflt;
+}
+int gv_env_rank() { return env_int("RANK", 0); }
+int gv_env_nranks() { return env_int("WORLD_SIZE", 1); }
+int gv_env_local_rank() { return env_int("LOCAL_RANK", gv_env_rank()); }
+
+void divide_work(int Mt, int nranks, int rank, int* M, int* S, int* Mm) {
+    const int base = Mt / nranks, extra = Mt % nranks;   // the first `extra` ranks get one more marker
+    int start = 0;
+    for (int r = 0; r < rank; r++) start += base + (r < extra ? 1 : 0);
+    *M = base + (rank < extra ? 1 : 0);
+    *S = start;
+    if (Mm) *Mm = base + (extra ? 1 : 0);
+}
+
+std::vector<double> divide_work(int Mt) {
+    int M, S, Mm;
+    const int rank = gv_env_rank(), nranks = gv_env_nranks();
+    divide_work(Mt, nranks, rank, &M, &S, &Mm);
+    printf("INFO   : rank %4d has %d markers over tot Mt = %d, max Mm = %d, starting at S = %d\n", rank, M, Mt, Mm, S);
+    return {(double)M, (double)S, (double)Mm};
+}
+
+std::vector<double> simulate(int M, std::vector<double> eta, std::vector<double> pi, long unsigned int seed) {
+    std::vector<double> signal(M, 0.0);
+    const size_t K = eta.size();
+    for (int i = 0; i < M; i++) {
+        std::mt19937 gen{seed + i};                      // a fresh engine per marker (utilities.cpp:52)
+        std::uniform_real_distribution<double> unif(0.0, 1.0);
+        const double u = unif(gen);
+        double cum = 0;
+        for (size_t j = 0; j < K; j++) {
+            cum += pi[j];
+            if (u <= cum) {
+                if (eta[j] != 0) {
+                    std::normal_distribution<double> slab(0.0, sqrt(eta[j]));
+                    signal[i] = slab(gen);
+                }
+                break;
+            }
+        }
+    }
+    return signal;
+}
+
+void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int N, int Mt, int rank) {
+    if (!probs.empty() || !vars.empty()) return;
+    const int L = 23;
+    if (Mt <= 50000) throw std::invalid_argument("No probabilities or variances were specified and Mt < 50,000.");
+    double p = std::min(50000.0 / Mt, 1.0) / (2 - 1.0 / pow(2, 21));
+    probs.push_back(1 - 50000.0 / Mt);
+    for (int k = 1; k < L; k++, p /= 2) probs.push_back(p);
+    const double ratio = pow(10, log10(1e2 / 1e-5) / (L - 2));
+    double v = 1e-5;
+    vars.push_back(0);
+    for (int k = 1; k < L; k++, v *= ratio) vars.push_back(v);
+    for (double& x : vars) x /= N;
+    if (rank == 0) {
+        std::cout << "probs = ";
+        for (double x : probs) std::cout << x << ' ';
+        std::cout << std::endl << "scaled variances = ";
+        for (double x : vars) std::cout << x * N << ' ';
+        std::cout << std::endl;
+    }
+}
+
+double noise_prec_calc(double SNR, std::vector<double> vars, std::vector<double> probs, int Mt, int N) {
+    (void)N;
+    double expe = 0;
+    for (size_t i = 0; i < vars.size(); i++) expe += vars[i] * probs[i];
+    return SNR / Mt / expe;
+}
+
+std::vector<double> read_vec_from_file(std::string filename, int M, int S) {
+    std::vector<double> v;
+    std::ifstream in(filename);
+    double value;
+    for (int it = 0; it < S + M && (in >> value); it++)
+        if (it >= S) v.push_back(value);
+    return v;
+}
+
+void store_vec_to_file(std::string filepath, std::vector<double> vec) {
+    std::ofstream file(filepath);
+    for (double x : vec) file << x << std::endl;   // default ostream precision, one value per line
+}
+
+void mpi_store_vec_to_file(std::string filepath_out, std::vector<double> vec, int S, int M) {
+    int fd = open(filepath_out.c_str(), O_CREAT | O_WRONLY, 0644);
+    if (fd < 0) return;
+    ssize_t w = pwrite(fd, vec.data(), sizeof(double) * (size_t)M, (off_t)S * (off_t)sizeof(double));
+    (void)w;
+    close(fd);
+}
+
+std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S) {
+    std::vector<double> vec(M, 0.0);
+    int fd = open(filename.c_str(), O_RDONLY);
+    if (fd < 0) return vec;
+    ssize_t r = pread(fd, vec.data(), sizeof(double) * (size_t)M, (off_t)S * (off_t)sizeof(double));
+    (void)r;
+    close(fd);
+    return vec;
+}
+
+double inner_prod(std::vector<double> const& u, std::vector<double> const& v, int sync) {
+    (void)sync;
+    double acc = 0;
+    for (size_t i = 0; i < u.size(); i++) acc += u[i] * v[i];
+    return acc;
+}
+double l2_norm2(std::vector<double> const& u, int sync) { return inner_prod(u, u, sync); }
+
+double calc_stdev(std::vector<double> vec, int sync) {
+    (void)sync;
+    const double sum = std::accumulate(vec.begin(), vec.end(), 0.0);
+    const double sq = std::inner_product(vec.begin(), vec.end(), vec.begin(), 0.0);
+    const int n = (int)vec.size();
+    const double mean = sum / n;
+    return std::sqrt((sq - n * mean * mean) / (n - 1));
+}

@@ -1,0 +1,26 @@
+// utilities.hpp -- host helpers with the reference's names and semantics (utilities.hpp:11-51, utilities.cpp).
+// MPI is replaced by the process environment (RANK / WORLD_SIZE as set by any one-process-per-GPU launcher) and
+// by the communicator inside libgvamp; file outputs keep the reference's formats.
+#pragma once
+#include <string>
+#include <vector>
+
+int gv_env_rank();     // RANK (default 0)
+int gv_env_nranks();   // WORLD_SIZE (default 1)
+int gv_env_local_rank();
+
+// utilities.cpp:259-291 -- {M, S, Mm} of this rank
+std::vector<double> divide_work(int Mt);
+void divide_work(int Mt, int nranks, int rank, int* M, int* S, int* Mm);
+// utilities.cpp:48-88 -- spike-and-slab draw per marker from mt19937{seed + i}
+std::vector<double> simulate(int M, std::vector<double> eta, std::vector<double> pi, long unsigned int seed);
+// utilities.cpp:91-140 -- default 23-component prior when neither --probs nor --vars is given
+void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int N, int Mt, int rank);
+double noise_prec_calc(double SNR, std::vector<double> vars, std::vector<double> probs, int Mt, int N);
+std::vector<double> read_vec_from_file(std::string filename, int M, int S);          // utilities.cpp:156-174 (text)
+void store_vec_to_file(std::string filepath, std::vector<double> vec);                // utilities.cpp:178-187 (text)
+void mpi_store_vec_to_file(std::string filepath_out, std::vector<double> vec, int S, int M);   // :293-301 (binary at S*8)
+std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S);       // :303-319
+double inner_prod(std::vector<double> const& u, std::vector<double> const& v, int sync);   // host vectors, sync ignored
+double l2_norm2(std::vector<double> const& u, int sync);
+double calc_stdev(std::vector<double> vec, int sync = 0);

@@ -1,0 +1,408 @@
+// vamp.cpp -- see vamp.hpp.  Statement order of infere_linear follows vamp.cpp:261-759 line by line (SURVEY App. A:
+// "statement order matters"); deviations are listed in DESIGN.md (all result-neutral).
+#include "vamp.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <random>
+
+#include "utilities.hpp"
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+void vamp::ck(int rc, const char* what) {
+    if (rc) {
+        std::cout << "FATAL: " << what << ": " << gv_last_error(ctx) << std::endl;
+        exit(EXIT_FAILURE);
+    }
+}
+
+void vamp::common_init(const Options& opt) {
+    C = opt.get_C();
+    init_est = opt.get_init_est();
+    seed = opt.get_seed();
+    estimate_file = opt.get_estimate_file();
+    learn_vars = opt.get_learn_vars();
+    EM_max_iter = opt.get_EM_max_iter();
+    EM_err_thr = opt.get_EM_err_thr();
+    CG_max_iter = opt.get_CG_max_iter();
+    reverse = opt.get_use_XXT_denoiser();
+    use_lmmse_damp = opt.get_use_lmmse_damp();
+    stop_criteria_thr = opt.get_stop_criteria_thr();
+    gam1_init = opt.get_gam1_init();
+    gamw_init = opt.get_gamw_init();
+    r1_init_file = opt.get_estimate_file();
+    store_pvals = opt.get_store_pvals();   // the reference's ctor 1 leaves 1 here (vamp.hpp:53); --store-pvals is honoured
+    diagnostics = opt.get_diagnostics();
+    store_iterates = opt.get_store_iterates();
+    nranks = gv_env_nranks();
+    initialize_prior(this->probs, this->vars, N, Mt, rank);
+}
+
+vamp::vamp(int N, int M, int Mt, double gam1, double gamw, int max_iter, double rho, std::vector<double> vars,
+           std::vector<double> probs, std::vector<double> true_signal, int rank, std::string out_dir,
+           std::string out_name, std::string model, Options opt)
+    : N(N), M(M), Mt(Mt), max_iter(max_iter), rank(rank), gam1(gam1), rho(rho), gamw(gamw), true_signal(true_signal),
+      probs(probs), vars(vars), model(model), out_dir(out_dir), out_name(out_name) {
+    common_init(opt);
+}
+
+vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int rank, Options opt)
+    : N(opt.get_N()), M(M), Mt(opt.get_Mt()), max_iter(opt.get_iterations()), rank(rank), gam1(gam1), rho(opt.get_rho()),
+      gamw(gamw), true_signal(true_signal), probs(opt.get_probs()), vars(opt.get_vars()), model(opt.get_model()),
+      out_dir(opt.get_out_dir()), out_name(opt.get_out_name()) {
+    common_init(opt);
+}
+
+vamp::~vamp() {
+    if (!ctx) return;
+    for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
+                      tN, tN2})
+        if (v) gv_vec_free(ctx, v);
+}
+
+double vamp::dotM(gv_vec* a, gv_vec* b) {
+    double out = 0;
+    ck(gv_vec_dot(ctx, a, b, 1, &out), "gv_vec_dot");
+    return out;
+}
+double vamp::dotN(gv_vec* a, gv_vec* b) {
+    double out = 0;
+    ck(gv_vec_dot(ctx, a, b, 0, &out), "gv_vec_dot");
+    return out;
+}
+
+// vamp.cpp:447-462 / :538-542 / :608-612: vec / sqrt(N) at byte offset S*8 of a shared .bin
+void vamp::store_scaled(const std::string& path, gv_vec* v, std::vector<std::vector<double>>* hist) {
+    if (!store_iterates && !(hist && keep_history)) return;
+    std::vector<double> h(M > 0 ? M : 0);
+    ck(gv_vec_download(ctx, v, h.data()), "gv_vec_download");
+    const double scale = sqrt((double)N);
+    for (double& x : h) x /= scale;
+    if (store_iterates && !path.empty()) mpi_store_vec_to_file(path, h, S, M);
+    if (hist && keep_history) hist->push_back(h);
+}
+
+// vamp::precondCG_solver (vamp.cpp:1130-1229) = gv_cg_solve; mu_start == nullptr is the zero start of :1120-1128
+int vamp::cg(gv_vec* v, gv_vec* mu_start, double tau, int denoiser, gv_vec* mu_out, int* iters) {
+    gv_cg_stats st;
+    std::vector<double> relres(CG_max_iter > 0 ? CG_max_iter : 1);
+    ck(gv_cg_solve(ctx, v, mu_start, tau, gam2, denoiser, CG_max_iter, mu_out, &st, relres.data()), "gv_cg_solve");
+    if (verbose && rank == 0)
+        for (int i = 0; i < st.n_relres; i++)
+            printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, relres[i]);
+    if (iters) *iters = st.iters;
+    return 0;
+}
+
+std::vector<double> vamp::infere(data* dataset) {
+    for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;   // design matrix is scaled by 1/sqrt(N) (vamp.cpp:154-155)
+    if (reverse == 1) {
+        std::cout << "FATAL: --use-XXT-denoiser 1 is not built yet (SURVEY 8f next-2)" << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    if (!strcmp(model.c_str(), "linear")) return infere_linear(dataset);
+    throw "invalid model specification!";   // vamp.cpp:180 (bin_class / robust: SURVEY 8f)
+}
+
+// vamp.cpp:871-889: u in {+-1/sqrt(Mt)}^M from mt19937{seed + S} + bernoulli(0.5) on the host (bit-comparable with the
+// reference at matched shard boundaries), CG on the device.
+double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
+    std::mt19937 rd{seed + (long unsigned int)dataset->get_S()};
+    std::bernoulli_distribution bern(0.5);
+    std::vector<double> u(M > 0 ? M : 0);
+    for (int i = 0; i < M; i++) u[i] = (2 * bern(rd) - 1) / sqrt(Mt);
+    ck(gv_vec_upload(ctx, bern_vec, u.data()), "gv_vec_upload");
+    cg(bern_vec, nullptr, tau, 0, invQ_bern_vec, iters);
+    return gam2_ * dotM(bern_vec, invQ_bern_vec);
+}
+
+// vamp.cpp:892-927.  temp = A x2 - y is also what err_measures(2) recomputes (:1301-1314); its R2 is taken here so
+// that the duplicate Ax of the reference is not repeated.
+void vamp::updateNoisePrec(data* dataset, double* R2_out) {
+    (void)dataset;
+    ck(gv_ax_dev(ctx, x2_hat, tN), "gv_ax_dev");
+    ck(gv_vec_axpby(ctx, tN, 1.0, tN, -1.0, y), "gv_vec_axpby");          // temp = A x2_hat - y
+    const gv_vec* xs[2] = {tN, y};
+    const gv_vec* ys[2] = {tN, y};
+    double d2[2];
+    ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
+    const double temp_norm2 = d2[0];
+    ck(gv_ax_dev(ctx, invQ_bern_vec, tN2), "gv_ax_dev");
+    ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
+    const double trace_corr = dotM(bern_vec, tM) * Mt;
+    if (verbose && rank == 0) {
+        std::cout << "l2_norm2(temp) / N = " << temp_norm2 / N << std::endl;
+        std::cout << "trace_correction / N = " << trace_corr / N << std::endl;
+    }
+    gamw = (double)N / (temp_norm2 + trace_corr);
+    if (R2_out) {
+        const double l2_pred_err = sqrt(temp_norm2 / d2[1]);
+        *R2_out = 1 - l2_pred_err * l2_pred_err;
+    }
+}
+
+// vamp.cpp:929-1072: EM on (probs, vars).  The loop over markers (:953-1013) is gv_prior_estep; its 1 + 2(L-1) sums
+// travel in ONE all-reduce instead of 1 + 2(L-1) scalar ones.
+void vamp::updatePrior(int verbose_) {
+    double lambda = 1 - probs[0];
+    std::vector<double> omegas = probs;
+    for (size_t j = 1; j < omegas.size(); j++) omegas[j] /= lambda;
+    int it;
+    for (it = 0; it < EM_max_iter; it++) {
+        const int L = (int)probs.size();
+        std::vector<double> probs_prev = probs, vars_prev = vars;
+        if (L >= 2) {
+            std::vector<double> sums(1 + 2 * (L - 1));
+            ck(gv_prior_estep(ctx, r1, gam1, lambda, omegas.data(), vars.data(), L, sums.data()), "gv_prior_estep");
+            ck(gv_allreduce_host(ctx, sums.data(), (int)sums.size()), "gv_allreduce_host");
+            const double sum_of_pin = sums[0];
+            lambda = sum_of_pin / Mt;
+            for (int j = 0; j < L - 1; j++) {
+                const double res_total = sums[1 + 2 * j], res_gammas_total = sums[2 + 2 * j];
+                if (learn_vars == 1) vars[j + 1] = res_gammas_total / res_total;
+                omegas[j + 1] = res_total / sum_of_pin;
+                probs[j + 1] = lambda * omegas[j + 1];
+            }
+            probs[0] = 1 - lambda;
+        }
+        double distance_probs = 0, norm_probs = 0, distance_vars = 0, norm_vars = 0;
+        for (size_t j = 0; j < probs.size(); j++) {
+            distance_probs += (probs[j] - probs_prev[j]) * (probs[j] - probs_prev[j]);
+            norm_probs += probs[j] * probs[j];
+            distance_vars += (vars[j] - vars_prev[j]) * (vars[j] - vars_prev[j]);
+            norm_vars += vars[j] * vars[j];
+        }
+        const double dist_probs = sqrt(distance_probs / norm_probs), dist_vars = sqrt(distance_vars / norm_vars);
+        if (verbose_ == 1 && verbose && rank == 0)
+            std::cout << "it = " << it << ": dist_probs = " << dist_probs << " & dist_vars = " << dist_vars << std::endl;
+        if (dist_probs < EM_err_thr && dist_vars < EM_err_thr) break;
+    }
+    if (verbose_ == 1 && verbose && rank == 0)
+        std::cout << "Final number of prior EM iterations = " << std::min(it + 1, EM_max_iter) << " / " << EM_max_iter
+                  << std::endl;
+    // merging close variances (vamp.cpp:1054-1071)
+    for (size_t j = 0; j < vars.size(); j++)
+        for (size_t k = j + 1; k < vars.size(); k++) {
+            const double denom = (vars[j] != 0) ? std::min(vars[j], vars[k]) : 1e-7;
+            if (std::abs(vars[j] - vars[k]) / denom < 5e-1) {
+                probs[j] += probs[k];
+                vars.erase(vars.begin() + k);
+                probs.erase(probs.begin() + k);
+                k--;
+            }
+        }
+}
+
+std::vector<double> vamp::infere_linear(data* dataset) {
+    ctx = dataset->get_ctx();
+    S = dataset->get_S();
+    auto newM = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_M, v), "gv_vec_alloc"); };
+    auto newN = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_N, v), "gv_vec_alloc"); };
+    for (gv_vec** v : {&x1_hat, &x1_hat_prev, &x2_hat, &r1, &r2, &r2_prev, &mu_CG_last, &bern_vec, &invQ_bern_vec, &vM, &tM})
+        newM(v);
+    for (gv_vec** v : {&z1, &y, &tN, &tN2}) newN(v);
+    {   // y = filter_pheno() (vamp.cpp:219): NA / pad slots zeroed on the device
+        std::vector<double> yh = dataset->get_phen();
+        yh.resize(N, 0.0);
+        ck(gv_set_phen(ctx, y, yh.data()), "gv_set_phen");
+    }
+    alpha1 = 0;
+    alpha2 = 0;   // read at vamp.cpp:501 before its first assignment (:631); harmless there, 0 here
+    const double sqrtN = sqrt((double)N);
+
+    if (gam1_init != -1) {   // restart (vamp.cpp:226-233): r1 file stores r1 / sqrt(N)... and is divided once more
+        gam1 = gam1_init;
+        gamw = gamw_init;
+        std::vector<double> r1_init = mpi_read_vec_from_file(r1_init_file, M, S);
+        for (double& v : r1_init) v /= sqrtN;
+        ck(gv_vec_upload(ctx, r1, r1_init.data()), "gv_vec_upload");
+    }
+    if (init_est == 1) {     // vamp.cpp:244-258
+        const size_t pos_dot = estimate_file.find(".");
+        std::vector<double> x_est = (estimate_file.substr(pos_dot + 1) == "bin") ? mpi_read_vec_from_file(estimate_file, M, S)
+                                                                                  : read_vec_from_file(estimate_file, M, S);
+        x_est.resize(M, 0.0);
+        for (double& v : x_est) v *= sqrtN;
+        ck(gv_vec_upload(ctx, x1_hat, x_est.data()), "gv_vec_upload");
+        ck(gv_vec_upload(ctx, r1, x_est.data()), "gv_vec_upload");
+    }
+    const std::string pre = out_dir + out_name;
+    std::vector<double> x1_hat_stored(M > 0 ? M : 0, 0.0);
+
+    for (int it = 1; it <= max_iter; it++) {
+        const double t_start = now_s();
+        double t_io = 0;
+        gv_counters c0;
+        gv_get_counters(ctx, &c0);
+        vamp_iter_stats st;
+        memset(&st, 0, sizeof(st));
+        if (verbose && rank == 0)
+            std::cout << std::endl << "********************" << std::endl << "iteration = " << it << std::endl
+                      << "********************" << std::endl << "->DENOISING" << std::endl;
+
+        ck(gv_vec_copy(ctx, x1_hat_prev, x1_hat), "gv_vec_copy");
+        probs_before = probs;
+        vars_before = vars;
+        const double alpha1_prev = alpha1;
+        int it_revar = 1;
+        for (; it_revar <= auto_var_max_iter; it_revar++) {               // vamp.cpp:289-338
+            double sums[2];
+            if (it == 1 && init_est == 1) {                               // :295-296: x1_hat = r1, g1d still evaluated
+                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), tM, nullptr, sums), "gv_denoise");
+                ck(gv_vec_copy(ctx, x1_hat, r1), "gv_vec_copy");
+                sums[1] = 0.0;
+            } else
+                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, nullptr, sums), "gv_denoise");
+            ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");     // :313 (+ the l2_norm2 of :326, same message)
+            alpha1 = sums[0] / Mt;
+            eta1 = gam1 / alpha1;
+            if (it <= 1) break;
+            const double gam1_reEst_prev = gam1;
+            gam1 = std::min(std::max(1.0 / (1.0 / eta1 + sums[1] / Mt), gamma_min), gamma_max);   // :326
+            updatePrior(0);
+            if (verbose && rank == 0) std::cout << "[old] it_revar = " << it_revar << ": gam1 = " << gam1 << std::endl;
+            if (std::abs(gam1 - gam1_reEst_prev) < 1e-3) break;
+        }
+        gam1s.push_back(gam1);
+        st.gam1_denoise = gam1;
+        st.revar_rounds = std::max(it_revar - 1, 1);
+        if (verbose && rank == 0)
+            std::cout << "A total of " << st.revar_rounds << " variance and prior tuning iterations were performed" << std::endl;
+
+        if (it > 1) {                                                     // damping (:348-414)
+            ck(gv_vec_axpby(ctx, x1_hat, rho, x1_hat, 1 - rho, x1_hat_prev), "gv_vec_axpby");
+            alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
+        }
+        ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");                      // z1 = A x1_hat (:429)
+
+        double t0 = now_s();
+        if (store_iterates && rank == 0) {                                // :435-436 (every rank in the reference)
+            std::vector<double> zh(4 * dataset->get_mbytes());
+            ck(gv_vec_download(ctx, z1, zh.data()), "gv_vec_download");
+            store_vec_to_file(pre + "_z1_it_" + std::to_string(it) + ".csv", zh);
+        }
+        if (verbose && rank == 0) std::cout << "rho = " << rho << std::endl;
+        {
+            ck(gv_vec_download(ctx, x1_hat, x1_hat_stored.data()), "gv_vec_download");
+            for (double& v : x1_hat_stored) v /= sqrtN;
+            if (store_iterates) mpi_store_vec_to_file(pre + "_it_" + std::to_string(it) + ".bin", x1_hat_stored, S, M);
+            if (keep_history) x1_hist.push_back(x1_hat_stored);
+        }
+        store_scaled(pre + "_r1_it_" + std::to_string(it) + ".bin", r1, &r1_hist);
+        t_io += now_s() - t0;
+
+        gam_before = gam2;
+        gam2 = std::min(std::max(eta1 - gam1, gamma_min), gamma_max);    // :472
+        if (verbose && rank == 0) std::cout << "eta1 = " << eta1 << std::endl << "gam2 = " << gam2 << std::endl;
+        ck(gv_vec_copy(ctx, r2_prev, r2), "gv_vec_copy");                 // :483
+        ck(gv_vec_axpby(ctx, r2, eta1 / gam2, x1_hat, -gam1 / gam2, r1), "gv_vec_axpby");   // :485-486
+        if (use_lmmse_damp == 1 && it > 1) {                              // :488-498
+            const double xi = std::min(2 * rho, 1.0);
+            gam2 = 1.0 / pow(xi / sqrt(gam2) + (1 - xi) / sqrt(gam_before), 2);
+        }
+        rho = std::max(rho, std::min(2 * std::min(alpha1, alpha2), 1.0));  // :501-502
+        st.alpha1 = alpha1; st.eta1 = eta1; st.gam2 = gam2; st.rho = rho;
+
+        if (auto_var_max_iter == 0 || it <= 1) updatePrior(1);            // :518-519
+        {   // err_measures(1) (:1295-1317): R2 of the cached z1
+            ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, z1), "gv_vec_axpby");
+            const gv_vec* xs[2] = {tN, y};
+            const gv_vec* ys[2] = {tN, y};
+            double d2[2];
+            ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
+            const double e = sqrt(d2[0] / d2[1]);
+            st.R2_denoise = 1 - e * e;
+            R2trains.push_back(st.R2_denoise);
+            if (verbose && rank == 0) std::cout << "R2 = " << st.R2_denoise << std::endl;
+        }
+        if (verbose && rank == 0) {
+            std::cout << "prior variances = ";
+            for (double v : vars) std::cout << v << ' ';
+            std::cout << std::endl << "prior probabilities = ";
+            for (double p : probs) std::cout << p << ' ';
+            std::cout << std::endl << "gamw = " << gamw << std::endl;
+        }
+        t0 = now_s();
+        store_scaled(pre + "_r2_it_" + std::to_string(it) + ".bin", r2, nullptr);
+        t_io += now_s() - t0;
+
+        // ---- LMMSE step (:547-620)
+        if (verbose && rank == 0) std::cout << "______________________" << std::endl << "->LMMSE" << std::endl;
+        ck(gv_atx_dev(ctx, y, vM), "gv_atx_dev");                          // v = gamw A^T y + gam2 r2 (:588-591)
+        ck(gv_vec_axpby(ctx, vM, gamw, vM, gam2, r2), "gv_vec_axpby");
+        cg(vM, (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last, gamw, 1, x2_hat, &st.cg_iters);   // :593-596
+        ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");           // :1225-1226
+        have_mu_CG_last = true;
+        t0 = now_s();
+        store_scaled(pre + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat, &x2_hist);
+        t_io += now_s() - t0;
+
+        alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);     // :631
+        st.alpha2 = alpha2;
+        if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
+        if (it > 1 && diagnostics) {
+            // "polynomial onsager" diagnostics (:646-681): printed only; off by default (they cost 3 Ax per iteration)
+            ck(gv_vec_axpby(ctx, tM, 1.0, r2, -1.0, r2_prev), "gv_vec_axpby");
+            const double onsager_approx = dotM(x2_hat, tM) / dotM(r2, tM);
+            ck(gv_ax_dev(ctx, r2, tN), "gv_ax_dev");
+            ck(gv_ax_dev(ctx, x2_hat, tN2), "gv_ax_dev");
+            ck(gv_ax_dev(ctx, x2_hat, tN2), "gv_ax_dev");
+            if (rank == 0) std::cout << "onsager approx = " << onsager_approx << std::endl;
+        }
+        eta2 = gam2 / alpha2;                                              // :682
+        if (auto_var_max_iter >= 1 && it > 2) {                            // :686-693
+            ck(gv_vec_axpby(ctx, tM, 1.0, x2_hat, -1.0, r2), "gv_vec_axpby");
+            gam2 = std::min(std::max(1 / (1 / eta2 + dotM(tM, tM) / Mt), gamma_min), gamma_max);
+        }
+        gam2s.push_back(gam2);
+        st.eta2 = eta2; st.gam2_reest = gam2;
+        gam1 = std::min(std::max(eta2 - gam2, gamma_min), gamma_max);     // :702
+        ck(gv_vec_axpby(ctx, r1, eta2 / gam1, x2_hat, -gam2 / gam1, r2), "gv_vec_axpby");   // :706-707
+        st.gam1_next = gam1;
+        if (verbose && rank == 0) std::cout << "gam2 re-est = " << gam2 << std::endl << "gam1 = " << gam1 << std::endl;
+
+        updateNoisePrec(dataset, &st.R2_lmmse);                            // :726 (+ err_measures(2), :731)
+        R2trains.push_back(st.R2_lmmse);
+        st.gamw = gamw;
+        if (verbose && rank == 0) std::cout << "R2 = " << st.R2_lmmse << std::endl << "gamw = " << gamw << std::endl;
+
+        st.L_after = (int)probs.size();
+        gv_counters c1;
+        gv_get_counters(ctx, &c1);
+        st.n_ax = (long)(c1.n_ax - c0.n_ax);
+        st.n_atx = (long)(c1.n_atx - c0.n_atx);
+
+        // stopping criterion (:741-749)
+        ck(gv_vec_axpby(ctx, tM, 1.0, x1_hat_prev, -1.0, x1_hat), "gv_vec_axpby");
+        const gv_vec* xs[2] = {tM, x1_hat_prev};
+        const gv_vec* ys[2] = {tM, x1_hat_prev};
+        double d2[2];
+        ck(gv_vec_dots(ctx, 2, xs, ys, 1, d2), "gv_vec_dots");
+        st.seconds_io = t_io;
+        st.seconds = now_s() - t_start - t_io;
+        stats.push_back(st);
+        if (it > 1 && sqrt(d2[0] / d2[1]) < stop_criteria_thr) {
+            if (verbose && rank == 0)
+                std::cout << "VAMP stopping criteria fulfilled with threshold = " << stop_criteria_thr << "." << std::endl;
+            break;
+        }
+        if (verbose && rank == 0)
+            std::cout << "total iteration time = " << st.seconds << " (Ax " << st.n_ax << ", ATx " << st.n_atx << ")"
+                      << std::endl << std::endl;
+    }
+    if (store_pvals == 1 && rank == 0)
+        std::cout << "NOTE: --store-pvals 1: LOO / LOCO p-values are not built yet (SURVEY 8f next-3)" << std::endl;
+    if (store_iterates && rank == 0) {                                      // :779-794 (rank 0 only, App. B)
+        store_vec_to_file(pre + "_gam1s.csv", gam1s);
+        store_vec_to_file(pre + "_gam2s.csv", gam2s);
+        store_vec_to_file(pre + "_R2trains.csv", R2trains);
+    }
+    return x1_hat_stored;   // x1_hat / sqrt(N) of the last iteration (:802)
+}

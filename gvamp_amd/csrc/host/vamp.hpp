@@ -1,0 +1,79 @@
+// vamp.hpp -- host side of the reference's `class vamp` (vamp.hpp:7-151) for `--model linear`.
+// Same constructors and entry point (infere(data*)); every M- or N-length vector of vamp.cpp lives in HBM as a
+// gv_vec and every loop over markers / individuals is a HIP kernel behind include/gvamp.h.  The host keeps only the
+// scalar recursions (gam1, gam2, eta, alpha, rho, gamw), the prior (probs / vars) and the Hutchinson RNG.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "data.hpp"
+#include "options.hpp"
+
+struct vamp_iter_stats {     // one row per VAMP iteration (what the reference prints on rank 0)
+    double gam1_denoise, alpha1, eta1, gam2, alpha2, eta2, gam2_reest, gam1_next, gamw, rho, R2_denoise, R2_lmmse;
+    int cg_iters, onsager_iters, revar_rounds, L_after;
+    long n_ax, n_atx;
+    double seconds, seconds_io;
+};
+
+class vamp {
+private:
+    int N, M, Mt, S = 0, C = 0, max_iter, rank, nranks;
+    double gam1, gam2 = 0, gam_before = 0, eta1 = 0, eta2 = 0;
+    std::vector<double> gam1s, gam2s, R2trains;
+    double alpha1 = 0, alpha2 = 0, rho, gamw;
+    std::vector<double> true_signal;
+    std::vector<double> probs, probs_before, vars, vars_before;
+    double gamma_min = 1e-11, gamma_max = 1e11;          // vamp.hpp:31-32
+    int EM_max_iter, CG_max_iter, auto_var_max_iter = 5; // vamp.hpp:34-37
+    double EM_err_thr, stop_criteria_thr;
+    int learn_vars, init_est = 0;
+    long unsigned int seed;
+    std::string model, out_dir, out_name;
+    int store_pvals = 0, use_lmmse_damp = 0, reverse = 0;
+    double gam1_init = -1, gamw_init = 0;
+    std::string r1_init_file, estimate_file;
+    int diagnostics = 0, store_iterates = 1, verbose = 1;
+
+    // device state (allocated in infere_linear)
+    gv_ctx* ctx = nullptr;
+    gv_vec *x1_hat = nullptr, *x1_hat_prev = nullptr, *x2_hat = nullptr, *r1 = nullptr, *r2 = nullptr, *r2_prev = nullptr,
+           *z1 = nullptr, *y = nullptr, *mu_CG_last = nullptr, *bern_vec = nullptr, *invQ_bern_vec = nullptr,
+           *vM = nullptr, *tM = nullptr, *tN = nullptr, *tN2 = nullptr;
+    bool have_mu_CG_last = false;
+    std::vector<vamp_iter_stats> stats;
+    std::vector<std::vector<double>> x1_hist, x2_hist, r1_hist;   // per iteration, already / sqrt(N) (if keep_history)
+    int keep_history = 0;
+
+    void ck(int rc, const char* what);
+    double dotM(gv_vec* a, gv_vec* b);   // inner_prod(a, b, 1): all-reduced
+    double dotN(gv_vec* a, gv_vec* b);   // inner_prod(a, b, 0): N-vectors are replicated
+    void store_scaled(const std::string& path, gv_vec* v, std::vector<std::vector<double>>* hist);
+    int cg(gv_vec* v, gv_vec* mu_start, double tau, int denoiser, gv_vec* mu_out, int* iters);
+    void common_init(const Options& opt);
+
+public:
+    vamp(int N, int M, int Mt, double gam1, double gamw, int max_iter, double rho, std::vector<double> vars,
+         std::vector<double> probs, std::vector<double> true_signal, int rank, std::string out_dir,
+         std::string out_name, std::string model, Options opt = Options());                    // vamp.cpp:32-82
+    vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int rank, Options opt);   // vamp.cpp:89-139
+    ~vamp();
+
+    std::vector<double> infere(data* dataset);           // vamp.cpp:149-183
+    std::vector<double> infere_linear(data* dataset);    // vamp.cpp:190-803
+    double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
+    void updatePrior(int verbose);                       // vamp.cpp:929-1072
+    void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)
+
+    void set_verbose(int v) { verbose = v; }
+    void set_keep_history(int k) { keep_history = k; }
+    const std::vector<vamp_iter_stats>& get_stats() const { return stats; }
+    const std::vector<std::vector<double>>& get_x1_hist() const { return x1_hist; }
+    const std::vector<std::vector<double>>& get_x2_hist() const { return x2_hist; }
+    const std::vector<std::vector<double>>& get_r1_hist() const { return r1_hist; }
+    std::vector<double> get_probs() const { return probs; }
+    std::vector<double> get_vars() const { return vars; }
+    std::vector<double> get_gam1s() const { return gam1s; }
+    std::vector<double> get_gam2s() const { return gam2s; }
+    std::vector<double> get_R2trains() const { return R2trains; }
+};

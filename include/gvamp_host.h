@@ -1,0 +1,49 @@
+/* gvamp_host.h -- C entry points of libgvamp_host.so: the host-side C++ mirror of the reference's `vamp` / `data`
+ * classes (gvamp_amd/csrc/host) driven on a shard that is already resident in a gv_ctx.  Used by bench.py (VAMP
+ * iterations/s on synthetic UKB-scale shards, which have no .bed file) and by the full-run parity tests; the
+ * executables gvamp_sim / gvamp_main_real are the reference-style drivers (sim.cpp, main_real.cpp). */
+#ifndef GVAMP_HOST_H
+#define GVAMP_HOST_H
+#include "gvamp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {                 /* the knobs vamp reads from Options (options.hpp:91-142) and its constructor */
+    int iterations, CG_max_iter, EM_max_iter;
+    double EM_err_thr, stop_criteria_thr, rho;
+    int learn_vars;
+    unsigned long seed;
+    int use_lmmse_damp;
+    double gam1, gamw;            /* sim.cpp:242-251: 1e-8, 2 ; main_real.cpp:64-70: 1e-6, 2 or 1/(1-h2) */
+    int L;
+    const double* probs;          /* unscaled, as on the command line; L == 0 -> default 23-component prior */
+    const double* vars;
+    const char* out_prefix;       /* out_dir + out_name (vamp.cpp:435); NULL or "" = no per-iteration files */
+    int verbose;
+    int diagnostics;              /* 1: also run the 3 print-only Ax of vamp.cpp:646-681 */
+    double alpha_scale;
+} gvh_opts;
+
+typedef struct {
+    double gam1_denoise, alpha1, eta1, gam2, alpha2, eta2, gam2_reest, gam1_next, gamw, rho, R2_denoise, R2_lmmse;
+    int cg_iters, onsager_iters, revar_rounds, L_after;
+    long n_ax, n_atx;
+    double seconds, seconds_io;   /* compute wall time of the iteration, and time spent writing / copying iterates */
+} gvh_iter;
+
+/* sim.cpp data recipe on a resident single-rank shard: beta_out[Mt], y_out[N] */
+int gvh_sim_phen(gv_ctx* ctx, int N, int Mt, double h2, int CV, unsigned long seed, double* beta_out, double* y_out);
+
+/* vamp::infere (vamp.cpp:149) for --model linear on the shard resident in ctx.  y[N]; mask4 NULL = all present.
+ * x_est[M] = x1_hat / sqrt(N) of the last iteration.  x1_hist / x2_hist / r1_hist (optional): iters_cap * M doubles. */
+int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int S, int rank, const double* y,
+                      const unsigned char* mask4, int nonas, const double* true_signal, double* x_est,
+                      gvh_iter* iters, int iters_cap, int* n_iters, double* x1_hist, double* x2_hist, double* r1_hist,
+                      double* probs_out, double* vars_out, int* L_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
