@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-markers", type=int, default=0, help="markers of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--vamp-iterations", type=int, default=5, help="VAMP iterations of the iters/s leg (0 = skip)")
+    ap.add_argument("--CG-max-iter", type=int, default=50)
     return ap.parse_args()
 
 
@@ -76,7 +78,8 @@ def cpu_baseline(N, seed, want_markers, device):
         t_atx += t3 - t2
         reps += 1
     gbps = 2 * alg_bytes(N, m) * reps / (t_ax + t_atx) / 1e9
-    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port", "sample_markers": m,
+            "ax_s": t_ax / reps, "atx_s": t_atx / reps,
             "sample": "oracle/ (OpenMP, %d threads) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix, "
                       "%d repetitions; Ax %.3f s, ATx %.3f s per call" % (cores, m, N, reps, t_ax / reps, t_atx / reps),
             "cpu_model": _cpu_model()}
@@ -202,8 +205,46 @@ def main():
         "kernels": {"ax": {"avg_ms": round(ms_ax, 4), "GBps": round(ax_gbps, 1), "launches": cnt["n_ax_kernel"]},
                     "atx": {"avg_ms": round(ms_atx, 4), "GBps": round(atx_gbps, 1), "launches": cnt["n_atx_kernel"]}},
     }
+    # ---- second half of the metric: VAMP iterations/s (vamp::infere of the host C++ mirror on the same shard) ----
+    if a.vamp_iterations > 0:
+        from gvamp_amd import hostapi
+        p.free(); d.free()
+        CV = max(1, Mt // 100)
+        beta, y = hostapi.sim_phen(sh, 0.5, CV, 1, rank=rank)                 # sim.cpp recipe, h2 = 0.5, seed 1
+        barrier()
+        t1 = time.perf_counter()
+        r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5,
+                                  seed=1, gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank)
+        sh.synchronize()
+        t_total = time.perf_counter() - t1
+        its = r.trace
+        tail = its[1:] if len(its) > 1 else its                               # iteration 1 has a cold CG
+        secs = [t["seconds"] for t in tail]
+        if world > 1:
+            tt = torch.tensor([sum(secs)], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tot = float(tt.item())
+        else:
+            tot = sum(secs)
+        out["vamp"] = {
+            "iters_per_s": round(len(tail) / tot, 4) if tot > 0 else None,
+            "seconds_per_iter": [round(t["seconds"], 4) for t in its], "wall_s_all_iterations": round(t_total, 3),
+            "n_ax": [t["n_ax"] for t in its], "n_atx": [t["n_atx"] for t in its],
+            "cg_iters": [t["cg_iters"] for t in its], "onsager_iters": [t["onsager_iters"] for t in its],
+            "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "L_after": [t["L_after"] for t in its],
+            "config": "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, "
+                      "%d iterations; iters/s over iterations 2.., file output off" % (CV, a.CG_max_iter, len(its)),
+        }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
+        cb = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
+        if "vamp" in out and len(out["vamp"]["n_ax"]) > 1:
+            f = Mt / cb["sample_markers"]       # CPU matvec time is linear in the number of markers at fixed N
+            v = out["vamp"]
+            est = [(v["n_ax"][i] * cb["ax_s"] + v["n_atx"][i] * cb["atx_s"]) * f for i in range(1, len(v["n_ax"]))]
+            cb["vamp_iter_s_extrapolated"] = round(sum(est) / len(est), 1)
+            cb["vamp_note"] = ("seconds per VAMP iteration the CPU port would need for the SAME matvec counts: "
+                               "(n_ax*t_ax + n_atx*t_atx) measured on the sample, scaled linearly by Mt/sample_markers")
+        out["cpu_baseline"] = cb
     sh.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -12,22 +12,24 @@
 
 extern "C" {
 
-// sim.cpp:78-79,153,183-218 on an already-resident shard (single rank): beta (Mt), y (N)
-int gvh_sim_phen(gv_ctx* ctx, int N, int Mt, double h2, int CV, unsigned long seed, double* beta_out, double* y_out) {
+// sim.cpp:78-79,153,183-218 on an already-resident shard: beta (local M), y (N).  Every rank draws the same beta /
+// noise streams; data::Ax carries the cross-rank all-reduce when a communicator is attached.
+int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, int CV, unsigned long seed,
+                 double* beta_out, double* y_out) {
     std::vector<double> vars_true{0, h2 / CV};
     std::vector<double> probs_true{1 - (double)CV / Mt, (double)CV / Mt};
     const double gamw = 1 / (1 - h2);
-    std::vector<double> beta_true = simulate(Mt, vars_true, probs_true, seed);
+    std::vector<double> beta_all = simulate(Mt, vars_true, probs_true, seed);
     std::mt19937 generator{seed};
     std::normal_distribution<double> gauss(0, 1 / sqrt(gamw));
     std::vector<double> noise(N);
     for (int i = 0; i < N; i++) noise[i] = gauss(generator);
-    data ds(ctx, std::vector<double>(N, 0.0), N, Mt, Mt, 0, 0);
-    std::vector<double> scaled = beta_true;
+    data ds(ctx, std::vector<double>(N, 0.0), N, M, Mt, S, rank);
+    std::vector<double> scaled(beta_all.begin() + S, beta_all.begin() + S + M);
     for (double& b : scaled) b *= sqrt(N);
     std::vector<double> y = ds.Ax(scaled.data());
     for (int i = 0; i < N; i++) y[i] += noise[i];
-    memcpy(beta_out, beta_true.data(), sizeof(double) * Mt);
+    memcpy(beta_out, beta_all.data() + S, sizeof(double) * M);
     memcpy(y_out, y.data(), sizeof(double) * N);
     return 0;
 }

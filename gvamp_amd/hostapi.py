@@ -38,7 +38,7 @@ def load():
             raise capi.GvError("libgvamp_host.so is not built: run `make -C gvamp_amd/csrc/host`")
         L = C.CDLL(LIB_PATH)
         dp, up = C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
-        L.gvh_sim_phen.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, dp, dp]
+        L.gvh_sim_phen.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, dp, dp]
         L.gvh_infere_linear.argtypes = [C.c_void_p, C.POINTER(Opts), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, up,
                                         C.c_int, dp, dp, C.POINTER(Iter), C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp,
                                         C.POINTER(C.c_int)]
@@ -50,12 +50,12 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
-def sim_phen(shard, h2, CV, seed):
-    """sim.cpp:78-79,153,183-218 on a resident single-rank shard."""
-    beta, y = np.empty(shard.Mt), np.empty(shard.N)
-    if load().gvh_sim_phen(shard.h, shard.N, shard.Mt, h2, CV, seed, _dp(beta), _dp(y)):
+def sim_phen(shard, h2, CV, seed, rank=0):
+    """sim.cpp:78-79,153,183-218 on a resident shard: (beta of this rank's markers, y)."""
+    beta, y = np.empty(max(shard.M, 1)), np.empty(shard.N)
+    if load().gvh_sim_phen(shard.h, shard.N, shard.M, shard.Mt, shard.S, rank, h2, CV, seed, _dp(beta), _dp(y)):
         raise capi.GvError("gvh_sim_phen failed")
-    return beta, y
+    return beta[:shard.M].copy(), y
 
 
 class Result:

@@ -33,8 +33,9 @@ typedef struct {
     double seconds, seconds_io;   /* compute wall time of the iteration, and time spent writing / copying iterates */
 } gvh_iter;
 
-/* sim.cpp data recipe on a resident single-rank shard: beta_out[Mt], y_out[N] */
-int gvh_sim_phen(gv_ctx* ctx, int N, int Mt, double h2, int CV, unsigned long seed, double* beta_out, double* y_out);
+/* sim.cpp data recipe on a resident shard: beta_out[M] (this rank's slice), y_out[N] (identical on every rank) */
+int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, int CV, unsigned long seed,
+                 double* beta_out, double* y_out);
 
 /* vamp::infere (vamp.cpp:149) for --model linear on the shard resident in ctx.  y[N]; mask4 NULL = all present.
  * x_est[M] = x1_hat / sqrt(N) of the last iteration.  x1_hist / x2_hist / r1_hist (optional): iters_cap * M doubles. */

@@ -1,0 +1,105 @@
+"""Unit properties of the CPU oracle (host logic, no GPU): the restated semantics behave as SURVEY App. A says."""
+import numpy as np
+import pytest
+
+from gvamp_amd import synth
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def decode(bed, N, M):
+    """independent numpy decode: a in {2,0,1,0}, b in {1,0,1,1} for PLINK codes 00,01,10,11 (dotp_lut.hpp)."""
+    mb = (N + 3) // 4
+    bits = np.unpackbits(np.asarray(bed, dtype=np.uint8).reshape(M, mb), axis=1, bitorder="little").reshape(M, mb * 4, 2)
+    code = bits[:, :, 0] + 2 * bits[:, :, 1]
+    a = np.array([2.0, 0.0, 1.0, 0.0])[code]
+    b = np.array([1.0, 0.0, 1.0, 1.0])[code]
+    return a[:, :N], b[:, :N]
+
+
+def test_divide_work(oracle):
+    # utilities.cpp:259-291: remainder to the low ranks, contiguous, covering
+    for Mt, n in ((10000, 8), (10, 3), (7, 7), (5, 8)):
+        parts = [oracle.divide_work(Mt, n, r) for r in range(n)]
+        assert sum(m for m, _ in parts) == Mt
+        assert all(parts[i][1] + parts[i][0] == parts[i + 1][1] for i in range(n - 1))
+        assert max(m for m, _ in parts) - min(m for m, _ in parts) <= 1 and parts[0][0] >= parts[-1][0]
+
+
+@pytest.mark.parametrize("N,M,fna", [(200, 37, 0.0), (203, 20, 0.05)])
+def test_stats_ax_atx_against_dense_numpy(oracle, N, M, fna):
+    rng = np.random.default_rng(N)
+    bed = synth.synth_bed(N, M, seed=3, miss_ppm=20000)
+    a, b = decode(bed, N, M)
+    present = rng.random(N) >= fna
+    m4 = np.zeros((N + 3) // 4, dtype=np.uint8)
+    for n in np.nonzero(present)[0]:
+        m4[n >> 2] |= 1 << (n & 3)
+    nonas = int(present.sum())
+    mave, msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas)
+    mu = (a * b * present).sum(1) / (b * present).sum(1)
+    sg = 1 / np.sqrt((((a - mu[:, None]) * b * present) ** 2).sum(1) / (nonas - 1))
+    assert np.allclose(mave, mu, rtol=1e-13) and np.allclose(msig, sg, rtol=1e-12)
+    A = ((a - mu[:, None]) * sg[:, None] * b).T / np.sqrt(N)          # N x M standardised design matrix
+    x = rng.standard_normal(M)
+    z = oracle.ax(bed, N, M, mave, msig, x, mask4=m4)
+    assert rel(z[:N], (A * present[:, None]) @ x) < 1e-12 and np.all(z[N:] == 0)
+    p = np.zeros(4 * ((N + 3) // 4))
+    p[:N] = rng.standard_normal(N) * present
+    assert rel(oracle.atx(bed, N, M, mave, msig, p), A.T @ p[:N]) < 1e-12
+    # threads do not change the result (same per-element summation order)
+    assert np.array_equal(oracle.ax(bed, N, M, mave, msig, x, mask4=m4, nthreads=4), z)
+
+
+def test_g1_limits(oracle):
+    r = np.linspace(-3, 3, 13)
+    g1, g1d = oracle.g1_g1d(r, 1e12, [0.9, 0.1], [0.0, 1.0])          # |sigma| < 1e-10 -> identity (vamp.cpp:813,844)
+    assert np.array_equal(g1, r) and np.all(g1d == 1)
+    g1, g1d = oracle.g1_g1d(r, 2.0, [1.0], [0.0])                      # pure spike at 0 shrinks everything to 0
+    assert np.allclose(g1, 0, atol=1e-15)
+    g1, _ = oracle.g1_g1d(r, 2.0, [0.0, 1.0], [0.0, 3.0])              # pure slab: Wiener gain v/(v + 1/gam1)
+    assert np.allclose(g1, r * 3.0 / (3.0 + 0.5), rtol=1e-13)
+
+
+def test_update_prior_merges_close_variances(oracle):
+    rng = np.random.default_rng(0)
+    r1 = rng.standard_normal(5000) * np.where(rng.random(5000) < 0.1, 2.0, 0.05)
+    p, v = oracle.update_prior(r1, 5000, 5.0, [0.8, 0.1, 0.1], [0.0, 1.0, 1.2], EM_max_iter=1, learn_vars=0)
+    assert len(p) == 2 and np.isclose(p.sum(), 1.0)                    # |1.2-1|/1 < 0.5 -> merged (vamp.cpp:1054-1071)
+    p, v = oracle.update_prior(r1, 5000, 5.0, [0.8, 0.1, 0.1], [0.0, 1.0, 4.0], EM_max_iter=3)
+    assert len(p) == 3 and np.isclose(p.sum(), 1.0) and v[0] == 0
+
+
+def test_cg_solves_the_lmmse_system(oracle):
+    N, M = 300, 120
+    rng = np.random.default_rng(5)
+    bed = synth.synth_bed(N, M, seed=9, miss_ppm=5000)
+    a, b = decode(bed, N, M)
+    mave, msig = oracle.marker_stats(bed, N, M)
+    A = ((a - mave[:, None]) * msig[:, None] * b).T / np.sqrt(N)
+    v = rng.standard_normal(M)
+    tau, gam2 = 2.0, 0.7
+    mu, rr = oracle.cg_solve(bed, N, M, v, None, tau, gam2, 1, 200)
+    exact = np.linalg.solve(tau * A.T @ A + gam2 * np.eye(M), v)
+    assert rr[-1] < 1e-5 and rel(mu, exact) < 1e-4
+    assert np.all(np.diff(np.log(rr)) < 0.5)                           # residual trace essentially decreasing
+
+
+def test_bern_vec_depends_on_shard_start(oracle):
+    u0, u5 = oracle.bern_vec(7, 0, 100, 1000), oracle.bern_vec(7, 5, 100, 1000)   # mt19937{seed + S} (vamp.cpp:875)
+    assert np.allclose(np.abs(u0), 1 / np.sqrt(1000)) and not np.array_equal(u0, u5)
+    assert np.array_equal(oracle.bern_vec(12, 0, 100, 1000), u5)
+
+
+def test_infere_stops_on_criterion_and_counts_matvecs(oracle):
+    N, M = 400, 600
+    bed = synth.synth_bed(N, M, seed=4)
+    beta, y = oracle.sim_phen(bed, N, M, 0.5, 30, 3)
+    r = oracle.infere(bed, N, M, y, [0.9, 0.1], [0, 0.01], iterations=30, CG_max_iter=10, rho=0.5, seed=3,
+                      stop_criteria_thr=1e-2, true_signal=beta)
+    assert 2 <= r.niter < 30                                           # vamp.cpp:745
+    t = r.trace[1]
+    # per iteration (it > 1): Ax = K1 + K2 + 8 incl. warm start, ATx = K1 + K2 + 3
+    assert t["n_ax"] == t["cg_iters"] + t["onsager_iters"] + 1 + 7 and t["n_atx"] == t["cg_iters"] + t["onsager_iters"] + 3
