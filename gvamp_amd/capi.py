@@ -20,7 +20,7 @@ EXPORTS = [
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_denoise", "gv_prior_estep",
-    "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
 ]
 
@@ -92,6 +92,7 @@ def load():
     L.gv_allreduce_host.argtypes = [vp, dp, C.c_int]
     L.gv_comm_unique_id.argtypes = [C.c_void_p]
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.gv_comm_rank.argtypes = [vp]
     L.gv_comm_size.argtypes = [vp]
     L.gv_set_timing.argtypes = [vp, C.c_int]
@@ -304,6 +305,9 @@ class Shard:
     def comm_init(self, nranks, rank, uid):
         buf = (C.c_ubyte * 128).from_buffer_copy(uid)
         self._ck(self.L.gv_comm_init(self.h, nranks, rank, buf))
+
+    def comm_init_local(self, group, nranks, rank):
+        self._ck(self.L.gv_comm_init_local(self.h, group, nranks, rank))
 
     def set_timing(self, on):
         self._ck(self.L.gv_set_timing(self.h, int(on)))

@@ -3,7 +3,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "gv_internal.h"
 
@@ -82,14 +86,67 @@ int read_scalars(gv_ctx* c, int K, double* out) {
     return 0;
 }
 
+bool is_multi(const gv_ctx* c);
+int comm_allreduce(gv_ctx* c, double* dev, size_t n);
+
 // MPI_Allreduce(SUM, MPI_DOUBLE) of K host scalars (utilities.cpp:203): device round trip through RCCL
 int allreduce_scalars(gv_ctx* c, double* buf, int K) {
-    if (!c->comm || c->nranks == 1) return 0;
+    if (!is_multi(c)) return 0;
     NEED(c, K <= RED_MAXK, "allreduce_scalars: too many scalars");
     memcpy(c->host_pin, buf, sizeof(double) * K);
     HIPCHK(c, hipMemcpyAsync(c->red_out, c->host_pin, sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, ncclAllReduce(c->red_out, c->red_out, K, ncclDouble, ncclSum, c->comm, c->stream));
+    if (comm_allreduce(c, c->red_out, K)) return 1;
     return read_scalars(c, K, buf);
+}
+
+// ---- in-process communicator: nranks contexts of ONE process (threads) behave like nranks MPI ranks.  Sums in rank
+// order on the host (deterministic).  For tests of the sharded algorithm on a single GPU; production uses RCCL.
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long gen = 0;
+    std::vector<const double*> slots;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long g = gen;
+        if (++arrived == n) {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+        } else
+            cv.wait(lk, [&] { return gen != g; });
+    }
+};
+std::mutex g_groups_mu;
+std::map<int, std::shared_ptr<LocalGroup>> g_groups;
+
+bool is_multi(const gv_ctx* c) { return c->nranks > 1 && (c->comm || c->local); }
+
+// SUM all-reduce of n doubles living on the device, on the context's stream
+int comm_allreduce(gv_ctx* c, double* dev, size_t n) {
+    if (!is_multi(c)) return 0;
+    if (c->comm) {
+        NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+        return 0;
+    }
+    LocalGroup* g = static_cast<LocalGroup*>(c->local);
+    c->local_buf.resize(n);
+    HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    g->slots[c->rank] = c->local_buf.data();
+    g->barrier();
+    std::vector<double> sum(n, 0.0);
+    for (int r = 0; r < g->n; r++) {
+        const double* s = g->slots[r];
+        for (size_t i = 0; i < n; i++) sum[i] += s[i];
+    }
+    g->barrier();
+    c->local_buf.swap(sum);
+    HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 struct Timer {
@@ -139,7 +196,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 int ax_device(gv_ctx* c, const double* x, double* out) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
-    const bool multi = c->comm && c->nranks > 1;
+    const bool multi = is_multi(c);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
         Timer t(c, &c->cnt.ms_ax);
@@ -164,7 +221,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
     c->cnt.n_ax++;
     if (multi) {   // data.cpp:995 MPI_Allreduce, then the 1/sqrt(N) of :998-1005
         Timer t(c, &c->cnt.ms_allreduce);
-        NCCLCHK(c, ncclAllReduce(out, out, c->npad, ncclDouble, ncclSum, c->comm, c->stream));
+        if (comm_allreduce(c, out, c->npad)) return 1;
         gvk::scale_vec(c->stream, out, c->npad, scale);
         KCHK(c);
         t.stop();
@@ -495,8 +552,7 @@ int gv_vec_dots(gv_ctx* c, int n, const gv_vec* const* x, const gv_vec* const* y
     }
     gvk::dots(c->stream, n, xs, ys, x[0]->len, c->red_partial, c->red_out);
     KCHK(c);
-    if (sync && c->comm && c->nranks > 1)
-        NCCLCHK(c, ncclAllReduce(c->red_out, c->red_out, n, ncclDouble, ncclSum, c->comm, c->stream));
+    if (sync && comm_allreduce(c, c->red_out, n)) return 1;
     return read_scalars(c, n, out);
 }
 int gv_vec_dot(gv_ctx* c, const gv_vec* x, const gv_vec* y, int sync, double* out) {
@@ -559,7 +615,7 @@ int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, 
     const int64_t M = c->M;
     hipStream_t s = c->stream;
     double *r = c->cg_r->d, *z = c->cg_z->d, *p = c->cg_p->d, *d = c->cg_d->d, *mu = mu_out->d;
-    const bool multi = c->comm && c->nranks > 1;
+    const bool multi = is_multi(c);
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
     double sc[4];
@@ -708,6 +764,25 @@ int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    return 0;
+}
+int gv_comm_init_local(gv_ctx* c, int group, int nranks, int rank) {
+    NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init_local: bad rank / nranks");
+    if (c->comm) {
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    std::shared_ptr<LocalGroup>& g = g_groups[group];
+    if (!g || g->n != nranks) {
+        g = std::make_shared<LocalGroup>();
+        g->n = nranks;
+        g->slots.assign(nranks, nullptr);
+    }
+    c->local_keep = g;
+    c->local = g.get();
+    c->rank = rank;
+    c->nranks = nranks;
     return 0;
 }
 int gv_comm_rank(const gv_ctx* c) { return c->rank; }

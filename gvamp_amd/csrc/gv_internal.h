@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,9 @@ struct gv_ctx {
     // communicator ---------------------------------------------------------------------------------
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    void* local = nullptr;                 // in-process test communicator (gv_comm_init_local)
+    std::shared_ptr<void> local_keep;
+    std::vector<double> local_buf;
 
     // instrumentation ------------------------------------------------------------------------------
     int timing = 0;

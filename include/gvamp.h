@@ -123,6 +123,10 @@ int gv_allreduce_host(gv_ctx* ctx, double* buf, int n);
  * other ranks by any out-of-band channel (bench.py: torch.distributed broadcast). */
 int gv_comm_unique_id(void* id128);
 int gv_comm_init(gv_ctx* ctx, int nranks, int rank, const void* id128);
+/* In-process communicator for tests: `nranks` contexts of one process (one thread each, any GPUs) that name the same
+ * `group` behave like nranks ranks; sums are taken in rank order on the host.  Every collective must be entered by
+ * all members concurrently (from different threads). */
+int gv_comm_init_local(gv_ctx* ctx, int group, int nranks, int rank);
 int gv_comm_rank(const gv_ctx* ctx);
 int gv_comm_size(const gv_ctx* ctx);
 
