@@ -117,12 +117,14 @@ def main():
     if not dev_ok:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("GVAMP_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the
+    # N > 1 plumbing (rendezvous, id broadcast, RCCL communicator) on a single-GPU box under torchrun --nproc-per-node 1
+    if world > 1 or force_dist:
         dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous + timing reductions only;
         # the data path's collectives are RCCL calls inside libgvamp (gv_comm_init below)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     N, Mt = a.N, a.Mt
@@ -137,7 +139,7 @@ def main():
     sh.synth_bed(a.seed, 5000)
     sh.compute_markers_statistics()
     t_ingest = time.time() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         sh.comm_init(world, rank, uid[0])
@@ -248,7 +250,7 @@ def main():
     sh.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

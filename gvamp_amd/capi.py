@@ -303,7 +303,7 @@ class Shard:
 
     # ---- communicator / instrumentation --------------------------------------------------------------------
     def comm_init(self, nranks, rank, uid):
-        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid) if uid is not None else None
         self._ck(self.L.gv_comm_init(self.h, nranks, rank, buf))
 
     def comm_init_local(self, group, nranks, rank):

@@ -758,12 +758,23 @@ int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
         (void)ncclCommDestroy(c->comm);
         c->comm = nullptr;
     }
+    c->local = nullptr;
+    c->local_keep.reset();
     c->rank = rank;
     c->nranks = nranks;
-    if (nranks == 1) return 0;
+    if (nranks == 1 && !id128) return 0;
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    // self-test: a 4-double SUM all-reduce on the context's stream must give nranks * (rank-independent value)
+    double probe[4] = {1.0, 2.0, 3.0, 4.0};
+    memcpy(c->host_pin, probe, sizeof(probe));
+    HIPCHK(c, hipMemcpyAsync(c->red_out, c->host_pin, sizeof(probe), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->red_out, c->red_out, 4, ncclDouble, ncclSum, c->comm, c->stream));
+    double back[4];
+    if (read_scalars(c, 4, back)) return 1;
+    for (int i = 0; i < 4; i++)
+        if (back[i] != probe[i] * nranks) return fail(c, "gv_comm_init: RCCL all-reduce self-test failed (%g != %g)", back[i], probe[i] * nranks);
     return 0;
 }
 int gv_comm_init_local(gv_ctx* c, int group, int nranks, int rank) {

@@ -122,6 +122,7 @@ int gv_allreduce_host(gv_ctx* ctx, double* buf, int n);
  * RCCL over xGMI, one process per GPU.  Rank 0 calls gv_comm_unique_id and ships the 128 bytes to the
  * other ranks by any out-of-band channel (bench.py: torch.distributed broadcast). */
 int gv_comm_unique_id(void* id128);
+/* nranks == 1 with id128 == NULL attaches nothing; with an id a 1-rank RCCL communicator is created (self-test). */
 int gv_comm_init(gv_ctx* ctx, int nranks, int rank, const void* id128);
 /* In-process communicator for tests: `nranks` contexts of one process (one thread each, any GPUs) that name the same
  * `group` behave like nranks ranks; sums are taken in rank order on the host.  Every collective must be entered by

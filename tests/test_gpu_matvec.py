@@ -249,3 +249,26 @@ def test_errors_are_reported():
             sh.Ax(np.zeros(10))            # no bed / stats yet
         with pytest.raises(capi.GvError):
             sh.upload_bed(np.zeros(7, dtype=np.uint8))   # wrong size
+
+
+def test_rccl_single_rank_communicator_selftest():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce(double, sum) on the context's stream (1-rank communicator)."""
+    with capi.Shard(64, 8) as sh:
+        sh.comm_init(1, 0, capi.comm_unique_id())
+
+
+def test_kernel_families_agree_at_scale():
+    """5 GB shard (row offsets beyond 2^32 bytes): fp64 VALU family vs i8 MFMA fixed point, and the adjoint identity."""
+    N, M = 100000, 200000
+    rng = np.random.default_rng(12)
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(4242, 5000)
+        sh.compute_markers_statistics()
+        x, p = rng.standard_normal(M), rng.standard_normal(N)
+        z0, w0 = sh.Ax(x), sh.ATx(p)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        z1, w1 = sh.Ax(x), sh.ATx(p)
+        assert rel(z1, z0) < 1e-12 and rel(w1, w0) < 1e-12
+        lhs, rhs = float(z1 @ p), float(x @ w1)
+        assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
