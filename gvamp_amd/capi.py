@@ -16,11 +16,11 @@ SPACE_M, SPACE_N = 0, 1
 
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
-    "gv_upload_bed", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
+    "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_denoise", "gv_prior_estep",
-    "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
 ]
 
@@ -61,6 +61,7 @@ def load():
     L.gv_mbytes.restype = i64
     L.gv_upload_bed.argtypes = [vp, up, C.c_size_t]
     L.gv_synth_bed.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.gv_upload_bed_file.argtypes = [vp, C.c_char_p, i64]
     L.gv_download_bed.argtypes = [vp, up, C.c_size_t]
     L.gv_set_mask.argtypes = [vp, up, i64]
     L.gv_marker_stats.argtypes = [vp, C.c_double]
@@ -90,6 +91,8 @@ def load():
     L.gv_denoise.argtypes = [vp, vp, C.c_double, dp, dp, C.c_int, vp, vp, dp]
     L.gv_prior_estep.argtypes = [vp, vp, C.c_double, C.c_double, dp, dp, C.c_int, dp]
     L.gv_allreduce_host.argtypes = [vp, dp, C.c_int]
+    L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
+    L.gv_pvals_loco.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp]
     L.gv_comm_unique_id.argtypes = [C.c_void_p]
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -183,6 +186,10 @@ class Shard:
     def upload_bed(self, bed):
         bed = np.ascontiguousarray(bed, dtype=np.uint8)
         self._ck(self.L.gv_upload_bed(self.h, _up(bed), bed.size))
+
+    def upload_bed_file(self, path, offset=None):
+        off = 3 + self.S * self.mbytes if offset is None else offset
+        self._ck(self.L.gv_upload_bed_file(self.h, path.encode(), off))
 
     def synth_bed(self, seed, miss_ppm=5000):
         self._ck(self.L.gv_synth_bed(self.h, seed, miss_ppm))
@@ -295,6 +302,17 @@ class Shard:
         sums = np.empty(1 + 2 * (om.size - 1))
         self._ck(self.L.gv_prior_estep(self.h, r1.h, gam1, lam, _dp(om), _dp(vs), om.size, _dp(sums)))
         return sums
+
+    def pvals_calc(self, z1, y, x1_hat, chrom=None):
+        """data::pvals_calc (chrom None) / data::pvals_calc_LOCO on device handles; returns pvals[M]."""
+        out = np.zeros(max(self.M, 1))
+        if chrom is None:
+            self._ck(self.L.gv_pvals_loo(self.h, z1.h, y.h, x1_hat.h, _dp(out)))
+        else:
+            ch = np.ascontiguousarray(chrom, dtype=np.int32)
+            assert ch.size == self.M
+            self._ck(self.L.gv_pvals_loco(self.h, z1.h, y.h, x1_hat.h, ch.ctypes.data_as(C.POINTER(C.c_int)), _dp(out)))
+        return out[:self.M].copy()
 
     def allreduce_host(self, a):
         a = np.ascontiguousarray(a, dtype=np.float64)

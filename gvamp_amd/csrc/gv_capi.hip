@@ -266,7 +266,7 @@ void free_dataset(gv_ctx* c) {
         if (p) (void)hipFree(p);
         p = nullptr;
     };
-    F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial);
+    F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial); F(c->counts);
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
     F(c->plan.scal); F(c->plan.partial);
     c->plan = gvm::Plan();
@@ -349,6 +349,7 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     HIPCHK(c, hipMalloc(&c->mave, sizeof(double) * Mal));
     HIPCHK(c, hipMalloc(&c->msig, sizeof(double) * Mal));
     HIPCHK(c, hipMalloc(&c->t3, sizeof(double) * 3 * Mal));
+    HIPCHK(c, hipMalloc(&c->counts, sizeof(uint32_t) * 3 * Mal));
     int64_t col_tiles = (c->pitch / 4 + 255) / 256;
     int64_t chunks = (2048 + col_tiles - 1) / col_tiles;
     if (chunks > 256) chunks = 256;
@@ -378,7 +379,7 @@ int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 
 // Ingest: fills the resident layouts chunk by chunk (markers [m0, m0+mc), m0 % 256 == 0) so that the raw rows never
 // have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
-static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr) {
+static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr, FILE* file = nullptr) {
     NEED(c, c->N > 0, "ingest: gv_set_dims must be called first");
     NEED(c, c->want_raw || c->want_stripes, "ingest: gv_set_layout disabled both layouts");
     HIPCHK(c, hipSetDevice(c->device));
@@ -394,13 +395,15 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 4));
-        size_t pa = (size_t)pl.ks_m * 2 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 2 * pl.nrg_n * 64 * 8 * 4;
+        HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
+        size_t pa = (size_t)pl.ks_m * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 2 * pl.nrg_n * 64 * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
-    const int64_t CH = 32768;
+    const int64_t CH = file ? 8192 : 32768;   // file source: the pinned staging buffer is CH * mbytes bytes
     uint8_t* tmp = nullptr;
+    uint8_t* stage = nullptr;
+    if (file) HIPCHK(c, hipHostMalloc(&stage, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * c->mbytes));
     if (!c->want_raw) HIPCHK(c, hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P));
     int rc = 0;
     for (int64_t m0 = 0; m0 < M && !rc; m0 += CH) {
@@ -410,10 +413,14 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         if (synth) {
             gvk::synth_bed(c->stream, rawp, mc, c->S + m0, c->N, P, seed, miss_thr);
         } else {
+            const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage;
+            if (file && fread(stage, 1, (size_t)mc * c->mbytes, file) != (size_t)mc * c->mbytes) {
+                rc = fail(c, "ingest: short read on the .bed file at marker %lld", (long long)(c->S + m0));
+                break;
+            }
             e = hipMemsetAsync(rawp, 0, (size_t)mc * P, c->stream);
             if (e == hipSuccess)
-                e = hipMemcpy2DAsync(rawp, P, host_bed + (size_t)m0 * c->mbytes, c->mbytes, c->mbytes, mc,
-                                     hipMemcpyHostToDevice, c->stream);
+                e = hipMemcpy2DAsync(rawp, P, src, c->mbytes, c->mbytes, mc, hipMemcpyHostToDevice, c->stream);
         }
         if (e == hipSuccess && c->want_stripes) {
             gvm::stripes_m_chunk(c->stream, rawp, P, mc, c->N, pl.stripes_m, m0 / 64, pl.nkb_m);
@@ -424,6 +431,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         if (e != hipSuccess) rc = fail(c, "ingest chunk at marker %lld failed: %s", (long long)m0, hipGetErrorString(e));
     }
     if (tmp) (void)hipFree(tmp);
+    if (stage) (void)hipHostFree(stage);
     if (rc) return rc;
     c->have_raw = c->want_raw;
     c->have_stripes = c->want_stripes;
@@ -441,6 +449,19 @@ int gv_upload_bed(gv_ctx* c, const uint8_t* bed, size_t nbytes) {
     NEED(c, c->N > 0, "gv_upload_bed: gv_set_dims must be called first");
     NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_upload_bed: nbytes != M * ceil(N/4)");
     return ingest(c, bed, false, 0, 0);
+}
+
+int gv_upload_bed_file(gv_ctx* c, const char* path, int64_t offset) {
+    NEED(c, c->N > 0, "gv_upload_bed_file: gv_set_dims must be called first");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, "gv_upload_bed_file: could not open bed file: %s", path);
+    if (fseeko(f, (off_t)offset, SEEK_SET) != 0) {
+        fclose(f);
+        return fail(c, "gv_upload_bed_file: cannot seek to %lld in %s", (long long)offset, path);
+    }
+    int rc = ingest(c, nullptr, false, 0, 0, f);
+    fclose(f);
+    return rc;
 }
 
 int gv_synth_bed(gv_ctx* c, uint64_t seed, uint32_t miss_ppm) {
@@ -478,9 +499,11 @@ int gv_marker_stats(gv_ctx* c, double alpha_scale) {
     NEED(c, (c->have_raw || c->have_stripes) && c->mask2, "gv_marker_stats: bed and mask must be set first");
     if (c->have_stripes && (c->kernel_mode == 1 || !c->have_raw))
         gvm::stats_from_stripes(c->stream, c->plan.stripes_m, c->mask2, c->M, c->plan.nkb_m, c->pitch / 4,
-                                (double)c->nonas, alpha_scale, c->mave, c->msig);
+                                (double)c->nonas, alpha_scale, c->mave, c->msig, c->counts);
     else
-        gvk::marker_stats(c->stream, c->bed, c->mask2, c->M, c->pitch, (double)c->nonas, alpha_scale, c->mave, c->msig);
+        gvk::marker_stats(c->stream, c->bed, c->mask2, c->M, c->pitch, (double)c->nonas, alpha_scale, c->mave, c->msig,
+                          c->counts);
+    c->alpha_scale = alpha_scale;
     KCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_stats = true;
@@ -732,6 +755,154 @@ int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, cons
     gvk::prior_estep(c->stream, r1->d, c->M, gam1, lambda, pr, c->red_partial, c->red_out);
     KCHK(c);
     return read_scalars(c, 1 + 2 * (L - 1), sums);
+}
+
+// ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------
+// Student-t two-sided tail P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2): Lentz continued fraction of the incomplete beta
+// function (DLMF 8.17.22); the reference calls Boost's students_t (utilities.cpp:330-331).
+static double beta_cf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 100000; m++) {
+        const double m2 = 2.0 * m;
+        double num = m * (b - m) * x / ((a - 1.0 + m2) * (a + m2));
+        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        num = -(a + m) * (a + b + m) * x / ((a + m2) * (a + 1.0 + m2));
+        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double delta = d * c;
+        h *= delta;
+        if (fabs(delta - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+static double t_two_sided(double t, double nu) {
+    if (std::isnan(t) || !(nu > 0)) return NAN;
+    if (t == 0) return 1.0;
+    if (std::isinf(t)) return 0.0;
+    const double a = 0.5 * nu, b = 0.5, w = t * t / nu, x = 1.0 / (1.0 + w);
+    double lnB;   // -ln B(a, 1/2); asymptotic series of lgamma(a + 1/2) - lgamma(a) for large a (DLMF 5.11.13)
+    if (a >= 30.0) {
+        const double ia = 1.0 / a, ia2 = ia * ia;
+        lnB = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
+    } else
+        lnB = lgamma(a + b) - lgamma(a) - lgamma(b);
+    const double front = exp(lnB - a * log1p(w) + b * (log(w) - log1p(w)));
+    if (x < (a + 1.0) / (a + b + 2.0)) return front * beta_cf(a, b, x) / a;
+    return 1.0 - front * beta_cf(b, a, w / (1.0 + w)) / b;
+}
+// utilities.cpp:321-334
+static double reg1d_pval(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, double n) {
+    const double s2y = (sumsqy - sumy * sumy / n) / (n - 1), s2x = (sumsqx - sumx * sumx / n) / (n - 1);
+    const double sxy = (sumxy - sumx * sumy / n) / (n - 1);
+    const double rxy = sxy / sqrt(s2x * s2y);
+    const double t = rxy * sqrt((n - 2) / (1 - rxy * rxy));
+    return t_two_sided(fabs(t), n - 2);
+}
+
+// out4[4m..] = {sum a p, sum b p, sum a p^2, sum b p^2} for the N-space device vector p (one pass in kernel mode 1)
+static int marker_sums_p_p2(gv_ctx* c, const double* p, double* p2_scratch, double* out4_dev) {
+    gvk::mul(c->stream, p2_scratch, p, p, c->npad);
+    if (c->kernel_mode == 1 && c->M > 0) {
+        NEED(c, c->have_stripes, "p-values: kernel mode 1 needs the stripe layouts");
+        gvm::marker_sums2(c->stream, c->plan, p, p2_scratch, c->npad, c->red_partial, out4_dev);
+    } else {
+        NEED(c, c->have_raw, "p-values: kernel mode 0 needs the raw row layout");
+        gvk::marker_sums2_f64(c->stream, c->bed, c->M, c->pitch, p, p2_scratch, out4_dev);
+    }
+    KCHK(c);
+    return 0;
+}
+
+// chrom == NULL: leave-one-out (the marker's own effect is added back analytically); else leave-one-chromosome-out.
+static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom,
+                      double* pvals) {
+    NEED(c, z1->space == GV_SPACE_N && y->space == GV_SPACE_N && x1_hat->space == GV_SPACE_M, "gv_pvals: bad vector spaces");
+    NEED(c, c->have_stats, "gv_pvals: marker statistics must be computed first");
+    if (ensure_work(c)) return 1;
+    const int64_t M = c->M;
+    const double sqrtN = sqrt((double)c->N);
+    gv_vec *ymod = nullptr, *ych = nullptr, *sq = nullptr, *xch = nullptr;
+    double* sums_dev = nullptr;
+    int* chrom_dev = nullptr;
+    int rc = 0;
+    std::vector<double> sums(4 * (M > 0 ? M : 1)), mave(M > 0 ? M : 1), msig(M > 0 ? M : 1), xh(M > 0 ? M : 1);
+    std::vector<uint32_t> cnt(3 * (M > 0 ? M : 1));
+    auto cleanup = [&]() {
+        for (gv_vec* v : {ymod, ych, sq, xch}) if (v) { (void)hipFree(v->d); delete v; }
+        if (sums_dev) (void)hipFree(sums_dev);
+        if (chrom_dev) (void)hipFree(chrom_dev);
+    };
+#define PV_TRY(expr) do { if ((rc = (expr)) != 0) { cleanup(); return rc; } } while (0)
+#define PV_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    PV_TRY(vec_new(c, GV_SPACE_N, &ymod));
+    PV_TRY(vec_new(c, GV_SPACE_N, &sq));
+    PV_HIP(hipMalloc(&sums_dev, sizeof(double) * 4 * (M > 0 ? M : 1)));
+    gvk::axpby(c->stream, ymod->d, 1.0, y->d, -1.0, z1->d, c->npad);            // y_mod = y - z1 (data.cpp:1117-1119)
+    PV_HIP(hipMemcpyAsync(mave.data(), c->mave, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    PV_HIP(hipMemcpyAsync(msig.data(), c->msig, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    PV_HIP(hipMemcpyAsync(cnt.data(), c->counts, sizeof(uint32_t) * 3 * M, hipMemcpyDeviceToHost, c->stream));
+    PV_HIP(hipMemcpyAsync(xh.data(), x1_hat->d, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
+    auto marker_test = [&](int64_t k, double cself) {
+        // exact masked sums of the standardised column from the genotype counts (the reference sums them in fp64)
+        const double n2 = cnt[3 * k], n1 = cnt[3 * k + 1], n0 = cnt[3 * k + 2], mu = mave[k], sg = msig[k];
+        const double count = n0 + n1 + n2;
+        const double sumx = sg * (2.0 * n2 + n1 - mu * count);
+        const double sumsqx = sg * sg * (n2 * (2.0 - mu) * (2.0 - mu) + n1 * (1.0 - mu) * (1.0 - mu) + n0 * mu * mu);
+        const double* s4 = &sums[4 * k];
+        const double svy = sg * (s4[0] - mu * s4[1]);                            // sum value * y
+        const double sumxy = svy + cself * sumsqx;
+        const double sumy = s4[1] + cself * sumx;
+        const double sumsqy = s4[3] + 2.0 * cself * svy + cself * cself * sumsqx;
+        return reg1d_pval(sumx, sumsqx, sumxy, sumy, sumsqy, count);
+    };
+    if (!chrom) {
+        PV_TRY(marker_sums_p_p2(c, ymod->d, sq->d, sums_dev));
+        PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
+        PV_HIP(hipStreamSynchronize(c->stream));
+        // y_mark = y_mod + gen_part * x1_hat[k] (data.cpp:1145-1148): the marker's own column, c = x1_hat[k] / sqrt(N)
+        for (int64_t k = 0; k < M; k++) pvals[k] = marker_test(k, xh[k] / sqrtN);
+    } else {
+        PV_TRY(vec_new(c, GV_SPACE_N, &ych));
+        PV_TRY(vec_new(c, GV_SPACE_M, &xch));
+        PV_HIP(hipMalloc(&chrom_dev, sizeof(int) * (M > 0 ? M : 1)));
+        PV_HIP(hipMemcpyAsync(chrom_dev, chrom, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
+        double present[24];
+        for (int ch = 0; ch < 24; ch++) present[ch] = 0;
+        for (int64_t k = 0; k < M; k++) if (chrom[k] >= 1 && chrom[k] <= 23) present[chrom[k]] += 1;
+        PV_TRY(allreduce_scalars(c, present, 24));
+        for (int64_t k = 0; k < M; k++) pvals[k] = 0.0;
+        for (int ch = 1; ch <= 23; ch++) {
+            if (present[ch] == 0) continue;      // no rank holds a marker of this chromosome
+            gvk::select_eq(c->stream, xch->d, x1_hat->d, chrom_dev, ch, M);
+            PV_TRY(ax_device(c, xch->d, ych->d));                                // chromosome predictor, all ranks (:1268-1272)
+            gvk::axpby(c->stream, ych->d, 1.0, ych->d, 1.0, ymod->d, c->npad);   // + y_mod (:1284)
+            PV_TRY(marker_sums_p_p2(c, ych->d, sq->d, sums_dev));
+            PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
+            PV_HIP(hipStreamSynchronize(c->stream));
+            for (int64_t k = 0; k < M; k++)
+                if (chrom[k] == ch) pvals[k] = marker_test(k, 0.0);
+        }
+    }
+#undef PV_TRY
+#undef PV_HIP
+    cleanup();
+    return 0;
+}
+
+int gv_pvals_loo(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, double* pvals) {
+    return pvals_impl(c, z1, y, x1_hat, nullptr, pvals);
+}
+int gv_pvals_loco(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom, double* pvals) {
+    NEED(c, chrom != nullptr, "gv_pvals_loco: chrom is NULL");
+    return pvals_impl(c, z1, y, x1_hat, chrom, pvals);
 }
 
 int gv_allreduce_host(gv_ctx* c, double* buf, int n) {

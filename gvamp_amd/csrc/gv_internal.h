@@ -34,6 +34,8 @@ struct gv_ctx {
     int64_t nonas = 0;
     double* mave = nullptr;
     double* msig = nullptr;
+    uint32_t* counts = nullptr;     // 3*M: present individuals with a = 2, 1, 0 per marker (marker statistics)
+    double alpha_scale = 1.0;       // of the last gv_marker_stats
     bool have_stats = false;
     int kernel_mode = 0;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
     bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
@@ -81,7 +83,11 @@ namespace gvk {
 void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
                uint32_t miss_thr);
 void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
-                  double alpha_scale, double* mave, double* msig);
+                  double alpha_scale, double* mave, double* msig, uint32_t* counts);
+void marker_sums2_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p1, const double* p2,
+                      double* out4);
+void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n);
+void select_eq(hipStream_t s, double* out, const double* x, const int* key, int value, int64_t n);
 void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3);
 void ax_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* t3, int chunks,
             double* partial, int64_t npad);

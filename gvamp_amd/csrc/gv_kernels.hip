@@ -76,7 +76,7 @@ __global__ void k_synth_bed(uint32_t* bed, int64_t M, int64_t S, int64_t N, int6
 __global__ __launch_bounds__(256) void k_marker_stats(const uint32_t* __restrict__ bed,
                                                       const uint32_t* __restrict__ mask2, int64_t M, int64_t P4,
                                                       double nonas, double alpha_scale, double* __restrict__ mave,
-                                                      double* __restrict__ msig) {
+                                                      double* __restrict__ msig, uint32_t* __restrict__ counts) {
     int lane = threadIdx.x & 63;
     int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -104,6 +104,11 @@ __global__ __launch_bounds__(256) void k_marker_stats(const uint32_t* __restrict
             sg = 1.0;
         mave[m] = mu;
         msig[m] = sg;
+        if (counts) {
+            counts[3 * m] = n2;
+            counts[3 * m + 1] = n1;
+            counts[3 * m + 2] = n0;
+        }
     }
 }
 
@@ -203,6 +208,56 @@ __global__ __launch_bounds__(256) void k_atx_f64(const uint32_t* __restrict__ be
         double a = wave_sum(sa[k]), b = wave_sum(sb[k]);
         if (lane == 0 && m0 + k < M) out[m0 + k] = msig[m0 + k] * (a - mave[m0 + k] * b) * scale;
     }
+}
+
+// Raw per-marker sums of two N-vectors (fp64 family of gvm::marker_sums2): out4[4m..] = {sum a p1, sum b p1,
+// sum a p2, sum b p2} -- the ingredients of data::pvals_calc (data.cpp:1150-1170).  A wave handles 4 markers.
+__global__ __launch_bounds__(256) void k_marker_sums2_f64(const uint32_t* __restrict__ bed, int64_t M, int64_t P4,
+                                                          const double* __restrict__ p1, const double* __restrict__ p2,
+                                                          double* __restrict__ out4) {
+    constexpr int MW = 4;
+    int lane = threadIdx.x & 63;
+    int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * MW;
+    if (m0 >= M) return;
+    double s[MW][4];
+#pragma unroll
+    for (int k = 0; k < MW; k++) s[k][0] = s[k][1] = s[k][2] = s[k][3] = 0.0;
+    for (int64_t j = lane; j < P4; j += WAVE) {
+        uint32_t w[MW];
+#pragma unroll
+        for (int k = 0; k < MW; k++) w[k] = (m0 + k < M) ? bed[(m0 + k) * P4 + j] : 0x55555555u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double v1 = p1[j * 16 + q], v2 = p2[j * 16 + q];
+#pragma unroll
+            for (int k = 0; k < MW; k++) {
+                uint32_t c = (w[k] >> (2 * q)) & 3u;
+                double a = (c == 0u) ? 2.0 : (c == 2u) ? 1.0 : 0.0, b = (c == 1u) ? 0.0 : 1.0;
+                s[k][0] += a * v1;
+                s[k][1] += b * v1;
+                s[k][2] += a * v2;
+                s[k][3] += b * v2;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MW; k++) {
+        double r0 = wave_sum(s[k][0]), r1 = wave_sum(s[k][1]), r2 = wave_sum(s[k][2]), r3 = wave_sum(s[k][3]);
+        if (lane == 0 && m0 + k < M) {
+            double* o = out4 + 4 * (m0 + k);
+            o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+        }
+    }
+}
+
+// out = x * y (element-wise) and out = a where mask (chrom[i] == ch) else 0 helpers of the p-value passes
+__global__ void k_mul(double* out, const double* x, const double* y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * y[i];
+}
+__global__ void k_select_eq(double* out, const double* x, const int* key, int value, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (key[i] == value) ? x[i] : 0.0;
 }
 
 // ---- element-wise ------------------------------------------------------------------------------------------
@@ -423,10 +478,27 @@ void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int
 }
 
 void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
-                  double alpha_scale, double* mave, double* msig) {
+                  double alpha_scale, double* mave, double* msig, uint32_t* counts) {
     if (M == 0) return;
     hipLaunchKernelGGL(k_marker_stats, dim3(nblk(M, 4)), dim3(256), 0, s, (const uint32_t*)bed, mask2, M, pitch / 4,
-                       nonas, alpha_scale, mave, msig);
+                       nonas, alpha_scale, mave, msig, counts);
+}
+
+void marker_sums2_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p1, const double* p2,
+                      double* out4) {
+    if (M == 0) return;
+    hipLaunchKernelGGL(k_marker_sums2_f64, dim3(nblk(M, 16)), dim3(256), 0, s, (const uint32_t*)bed, M, pitch / 4, p1, p2,
+                       out4);
+}
+
+void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_mul, dim3(nblk(n, 256)), dim3(256), 0, s, out, x, y, n);
+}
+
+void select_eq(hipStream_t s, double* out, const double* x, const int* key, int value, int64_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_select_eq, dim3(nblk(n, 256)), dim3(256), 0, s, out, x, key, value, n);
 }
 
 void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3) {

@@ -16,7 +16,7 @@ struct Plan {
     void* dig1 = nullptr;
     double* cv = nullptr;           // M doubles: c = msig * x
     double* ev = nullptr;           // M doubles: e = (mave - 3) * c
-    double* scal = nullptr;         // 4 doubles: amax, sum, 2^(54-e), 2^(e-54)
+    double* scal = nullptr;         // 2 x 4 doubles: amax, sum, 2^(54-e), 2^(e-54) (second set: marker_sums2's p2)
     int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
     size_t partial_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // when set: recorded around the matvec kernel launch (roofline timing)
@@ -26,8 +26,12 @@ void stripes_m_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t m
                      int64_t rg0, int64_t nkb);
 void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
                      int64_t kb0, int64_t nkb, int64_t nrg_n);
+// counts (may be NULL): 3 per marker = present individuals with a = 2, 1, 0
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
-                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig);
+                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts);
+// one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2} (raw, unscaled)
+void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
+                  double* out4);
 // out[M] = data::ATx(p); p has npad entries (zero at NA / pad slots)
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
          double inv_sqrt_n, double* red_partial, double* out);

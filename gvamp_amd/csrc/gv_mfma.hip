@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_stripes_n(const uint8_t* __restrict__ r
 __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__ stripes, const uint32_t* __restrict__ mask2,
                                                        int64_t M, int64_t nkb, int64_t P4, double nonas,
                                                        double alpha_scale, double* __restrict__ mave,
-                                                       double* __restrict__ msig) {
+                                                       double* __restrict__ msig, uint32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global 16-row tile
     if (tile * 16 >= M) return;
@@ -129,6 +129,11 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
             sg = 1.0;
         mave[m] = mu;
         msig[m] = sg;
+        if (counts) {
+            counts[3 * m] = n2;
+            counts[3 * m + 1] = n1;
+            counts[3 * m + 2] = n0;
+        }
     }
 }
 
@@ -341,9 +346,23 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         b0 = b1;
     }
     const int64_t rows_p = nrg * 64;
+    const int cd = c & 7;
+    if (MODE == 2) {
+        // two vectors: planes 0/1 = X/Y of vector 1 (columns 0..7), planes 2/3 = X/Y of vector 2 (columns 8..15)
+        const int pv = (c >> 3) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+                partial[(((int64_t)ks * 4 + pv + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
+                partial[(((int64_t)ks * 4 + pv + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
+            }
+        }
+        return;
+    }
     const bool stX = c < 8;                         // accX: digit columns 0..7
     const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);   // accY: columns 0..7 (ATx) or 8..15 (Ax, digits of e)
-    const int cd = c & 7;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -352,6 +371,43 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
             if (stX) partial[(((int64_t)ks * 2 + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
             if (stY) partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
         }
+    }
+}
+
+__device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
+
+// Raw per-marker sums of TWO N-vectors from one pass over stripes_m (MODE 2):
+//   out[4m + 0] = sum_n a p1, [4m + 1] = sum_n b p1, [4m + 2] = sum_n a p2, [4m + 3] = sum_n b p2
+// (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N): the ingredients of data::pvals_calc, data.cpp:1150-1170)
+__global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
+                                                   const double* __restrict__ scal1, const double* __restrict__ scal2,
+                                                   double* __restrict__ out) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    long long s[4][7];
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+        for (int c = 0; c < 7; c++) s[pl][c] = 0;
+    for (int ks = 0; ks < ksplit; ks++) {
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) {
+            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 4 + pl) * rows_p + m) * 8);
+            int4 x0 = px[0], x1 = px[1];
+            s[pl][0] += x0.x; s[pl][1] += x0.y; s[pl][2] += x0.z; s[pl][3] += x0.w;
+            s[pl][4] += x1.x; s[pl][5] += x1.y; s[pl][6] += x1.z;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+        long long xh, xl, yh, yl;
+        combine(s[2 * v], xh, xl);
+        combine(s[2 * v + 1], yh, yl);
+        const double* sc = v ? scal2 : scal1;
+        const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * sc[3];
+        const double sm = ((double)yh * 4294967296.0 + (double)yl) * sc[3];
+        out[4 * m + 2 * v] = sa;
+        out[4 * m + 2 * v + 1] = sc[1] - sm;
     }
 }
 
@@ -431,10 +487,10 @@ void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t m
                        N, (uint4*)stripes, kb0, nkb);
 }
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
-                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig) {
+                        int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts) {
     if (M <= 0) return;
     hipLaunchKernelGGL(k_stats_stripes, dim3(nblk((M + 15) / 16, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M,
-                       nkb, P4, nonas, alpha_scale, mave, msig);
+                       nkb, P4, nonas, alpha_scale, mave, msig, counts);
 }
 
 static int prep_blocks(int64_t n) {
@@ -456,6 +512,25 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, out);
+}
+
+// one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
+void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
+                  double* out4) {
+    int nb = prep_blocks(npad);
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p1, npad, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p2, npad, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal + 4);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p1, npad, pl.nkb_m, pl.scal,
+                       (uint32_t*)pl.dig0, 16, 0);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p2, npad, pl.nkb_m, pl.scal + 4,
+                       (uint32_t*)pl.dig0, 16, 8);
+    int64_t waves = pl.nrg_m * pl.ks_m;
+    hipLaunchKernelGGL(k_mfma_matvec<2>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
+                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal, pl.scal + 4, out4);
 }
 
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,

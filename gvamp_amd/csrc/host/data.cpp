@@ -179,14 +179,8 @@ void data::read_phen() {
 // validated), handed to the device in bounded pieces.
 void data::read_genotype_data() {
     const size_t size_bytes = size_t(M) * mbytes;
-    std::vector<unsigned char> buf(size_bytes);
-    FILE* f = fopen(bedfp.c_str(), "rb");
-    if (!f) die("FATAL: could not open bed file: " + bedfp);
-    if (fseeko(f, (off_t)(3 + size_t(S) * mbytes), SEEK_SET) != 0 || fread(buf.data(), 1, size_bytes, f) != size_bytes)
-        die("FATAL: short read on bed file: " + bedfp);
-    fclose(f);
-    printf("INFO   : rank %d has allocated %zu bytes (%.3f GB) for raw data.\n", rank, size_bytes, double(size_bytes) / 1.0E9);
-    ck(ctx, gv_upload_bed(ctx, buf.data(), size_bytes), "gv_upload_bed");
+    printf("INFO   : rank %d streams %zu bytes (%.3f GB) of raw data to the device.\n", rank, size_bytes, double(size_bytes) / 1.0E9);
+    ck(ctx, gv_upload_bed_file(ctx, bedfp.c_str(), (int64_t)(3 + size_t(S) * mbytes)), "gv_upload_bed_file");
 }
 
 std::vector<int> data::read_chromosome_info(std::string bim_file) {
@@ -219,6 +213,61 @@ std::vector<double> data::ATx(double* __restrict__ phen) {
     std::vector<double> out(M > 0 ? M : 0, 0.0);
     ck(ctx, gv_atx(ctx, phen, out.data()), "gv_atx");
     return out;
+}
+
+std::vector<double> data::pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco) {
+    std::vector<double> pv(M > 0 ? M : 1, 0.0);
+    if (loco) {
+        std::vector<int> ch_info = read_chromosome_info(bimfp);
+        ch_info.resize(M > 0 ? M : 1, 0);
+        ck(ctx, gv_pvals_loco(ctx, z1, y, x1_hat, ch_info.data(), pv.data()), "gv_pvals_loco");
+    } else
+        ck(ctx, gv_pvals_loo(ctx, z1, y, x1_hat, pv.data()), "gv_pvals_loo");
+    pv.resize(M > 0 ? M : 0);
+    return pv;
+}
+
+static std::vector<std::vector<double>> pvals_host(data* d, gv_ctx* ctx, int M, size_t mbytes,
+                                                   std::vector<std::vector<double>>& z1, std::vector<double>& y,
+                                                   std::vector<std::vector<double>>& x1_hat, bool loco) {
+    std::vector<std::vector<double>> out;
+    gv_vec *dz = nullptr, *dy = nullptr, *dx = nullptr;
+    ck(ctx, gv_vec_alloc(ctx, GV_SPACE_N, &dz), "gv_vec_alloc");
+    ck(ctx, gv_vec_alloc(ctx, GV_SPACE_N, &dy), "gv_vec_alloc");
+    ck(ctx, gv_vec_alloc(ctx, GV_SPACE_M, &dx), "gv_vec_alloc");
+    std::vector<double> yp(y);
+    yp.resize(4 * mbytes, 0.0);
+    ck(ctx, gv_vec_upload(ctx, dy, yp.data()), "gv_vec_upload");
+    for (size_t ie = 0; ie < z1.size(); ie++) {
+        std::vector<double> zp(z1[ie]);
+        zp.resize(4 * mbytes, 0.0);
+        ck(ctx, gv_vec_upload(ctx, dz, zp.data()), "gv_vec_upload");
+        std::vector<double> xp(x1_hat[ie]);
+        xp.resize(M > 0 ? M : 1, 0.0);
+        ck(ctx, gv_vec_upload(ctx, dx, xp.data()), "gv_vec_upload");
+        out.push_back(d->pvals_calc_dev(dz, dy, dx, loco));
+    }
+    gv_vec_free(ctx, dz);
+    gv_vec_free(ctx, dy);
+    gv_vec_free(ctx, dx);
+    return out;
+}
+
+std::vector<std::vector<double>> data::pvals_calc(std::vector<std::vector<double>> z1, std::vector<double> y,
+                                                  std::vector<std::vector<double>> x1_hat,
+                                                  std::vector<std::string> filepath) {
+    std::vector<std::vector<double>> pv = pvals_host(this, ctx, M, mbytes, z1, y, x1_hat, false);
+    for (size_t ie = 0; ie < pv.size() && ie < filepath.size(); ie++) mpi_store_vec_to_file(filepath[ie], pv[ie], S, M);
+    return pv;
+}
+
+std::vector<std::vector<double>> data::pvals_calc_LOCO(std::vector<std::vector<double>> z1, std::vector<double> y,
+                                                       std::vector<std::vector<double>> x1_hat,
+                                                       std::vector<std::string> filepath) {
+    std::vector<std::vector<double>> pv = pvals_host(this, ctx, M, mbytes, z1, y, x1_hat, true);
+    for (size_t ie = 0; ie < pv.size() && ie < filepath.size(); ie++)
+        mpi_store_vec_to_file(filepath[ie] + "_pvals_LOCO.bin", pv[ie], S, M);          // data.cpp:1347-1350
+    return pv;
 }
 
 // length 4*mbytes (the reference returns N entries and lets ATx read past the end when N % 4 != 0)

@@ -67,4 +67,13 @@ public:
     std::vector<double> ATx(double* __restrict__ phen);   // data.cpp:810 : 4*mbytes doubles -> M
     std::vector<double> filter_pheno();                   // data.cpp:1065-1079
     std::vector<double> filter_pheno(int* nonnan);        // data.cpp:1081-1097
+    // data.cpp:1108-1226 / :1235-1353 -- leave-one-out / leave-one-chromosome-out t-test p-values, one vector per
+    // estimator; written to filepath[ie] (LOO) or filepath[ie] + "_pvals_LOCO.bin" (LOCO) at byte offset S*8.
+    std::vector<std::vector<double>> pvals_calc(std::vector<std::vector<double>> z1, std::vector<double> y,
+                                                std::vector<std::vector<double>> x1_hat, std::vector<std::string> filepath);
+    std::vector<std::vector<double>> pvals_calc_LOCO(std::vector<std::vector<double>> z1, std::vector<double> y,
+                                                     std::vector<std::vector<double>> x1_hat,
+                                                     std::vector<std::string> filepath);
+    // the same on device handles (what vamp::infere_linear calls): z1, y N-space; x1_hat M-space
+    std::vector<double> pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco);
 };

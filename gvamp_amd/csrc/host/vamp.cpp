@@ -397,8 +397,19 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             std::cout << "total iteration time = " << st.seconds << " (Ax " << st.n_ax << ", ATx " << st.n_atx << ")"
                       << std::endl << std::endl;
     }
-    if (store_pvals == 1 && rank == 0)
-        std::cout << "NOTE: --store-pvals 1: LOO / LOCO p-values are not built yet (SURVEY 8f next-3)" << std::endl;
+    if (store_pvals == 1) {                                                 // vamp.cpp:761-776
+        // z1 / x1_hat of the last completed iteration, y = filtered phenotype (all still resident on the device)
+        const double t0 = now_s();
+        std::vector<double> pv = dataset->pvals_calc_dev(z1, y, x1_hat, false);
+        mpi_store_vec_to_file(pre + "_pvals.bin", pv, S, M);
+        if (verbose && rank == 0) std::cout << "filepath_out_pvals = " << pre + "_pvals.bin" << std::endl;
+        if (dataset->get_bimfp() != "") {
+            std::vector<double> pl = dataset->pvals_calc_dev(z1, y, x1_hat, true);
+            mpi_store_vec_to_file(pre + "_pvals_LOCO.bin", pl, S, M);
+            if (verbose && rank == 0) std::cout << "filepath_out_pvals_LOCO = " << pre << std::endl;
+        }
+        if (verbose && rank == 0) std::cout << "p-values took " << now_s() - t0 << " seconds." << std::endl;
+    }
     if (store_iterates && rank == 0) {                                      // :779-794 (rank 0 only, App. B)
         store_vec_to_file(pre + "_gam1s.csv", gam1s);
         store_vec_to_file(pre + "_gam2s.csv", gam2s);

@@ -44,6 +44,10 @@ int64_t gv_mbytes(const gv_ctx* ctx);  /* ceil(N/4), data.cpp:40 */
 /* bed: M*mbytes bytes, marker-major PLINK 2-bit, WITHOUT the 3 magic bytes: what read_genotype_data
  * (data.cpp:201-234) leaves in bed_data.  Copied to HBM (row pitch padded to 64 B) and kept resident. */
 int gv_upload_bed(gv_ctx* ctx, const uint8_t* bed, size_t nbytes);
+/* The same from a file, streamed through a bounded pinned buffer (host memory stays O(8192 * mbytes) however large
+ * the shard): M*mbytes bytes starting at byte `offset` of `path` -- offset = 3 + S*mbytes for a PLINK .bed
+ * (data.cpp:215).  The magic bytes are skipped, not validated, as in the reference. */
+int gv_upload_bed_file(gv_ctx* ctx, const char* path, int64_t offset);
 /* Synthetic shard generated on the device (bench / tests; SURVEY 8d recipe with an integer hash so that
  * gvamp_amd.synth.synth_bed() reproduces it bit for bit on the host).  miss_ppm: missing rate in 1e-6. */
 int gv_synth_bed(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm);
@@ -114,6 +118,17 @@ int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, 
  * sums[2+2j] = sum_i beta_ij (m_ij^2 + v_j) pi_i for j = 0..L-2 (local sums; caller all-reduces 1+2(L-1)). */
 int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
                    const double* vars, int L, double* sums);
+/* ---- association tests after the loop (vamp.cpp:761-776) ------------------------------------------------------
+ * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,
+ * pvals[M].  z1 = A x1_hat and y (filtered phenotype) are N-space handles, x1_hat the M-space estimate (the
+ * sqrt(N)-scaled x1_hat of vamp.cpp, as passed at :765).  One pass over the genotype shard (two digit vectors, y_mod
+ * and y_mod^2, share the 16 MFMA columns) + exact per-marker genotype counts; Student-t tail evaluated on the host. */
+int gv_pvals_loo(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, double* pvals);
+/* data::pvals_calc_LOCO (data.cpp:1235-1353): chrom[M] in 1..23 (read_chromosome_info, data.cpp:346-380); per
+ * chromosome one Ax (with its cross-rank all-reduce) + one marker pass.  Markers of other chromosomes get 0. */
+int gv_pvals_loco(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom,
+                  double* pvals);
+
 /* SUM all-reduce of n host doubles over the attached communicator (identity when none): MPI_Allreduce of
  * scalars in vamp.cpp:313,990,1012-1013 */
 int gv_allreduce_host(gv_ctx* ctx, double* buf, int n);

@@ -111,6 +111,72 @@ double calc_stdev(const std::vector<double>& vec) {
     return std::sqrt((sq_sum - vec_len * mean * mean) / (vec_len - 1));
 }
 
+// Student-t two-sided tail through the regularised incomplete beta function.
+static double betacf(double a, double b, double x) {
+    const double tiny = 1e-300, eps = 1e-16;
+    double qab = a + b, qap = a + 1, qam = a - 1, c = 1, d = 1 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1 / d;
+    double h = d;
+    for (int m = 1; m <= 100000; m++) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1) < eps) break;
+    }
+    return h;
+}
+static double betai(double a, double b, double x) {
+    if (!(x > 0)) return 0;
+    if (!(x < 1)) return 1;
+    // ln B(a,b)^-1: for b = 1/2 and large a (a = nu/2 of the t-test) lgamma(a + 1/2) - lgamma(a) cancels ~10 digits;
+    // use its asymptotic series (DLMF 5.11.13) there instead
+    double lg_ratio;
+    if (b == 0.5 && a >= 30.0) {
+        const double ia = 1 / a, ia2 = ia * ia;
+        lg_ratio = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
+    } else
+        lg_ratio = lgamma(a + b) - lgamma(a) - lgamma(b);
+    double bt = exp(lg_ratio + a * log(x) + b * log1p(-x));
+    if (x < (a + 1) / (a + b + 2)) return bt * betacf(a, b, x) / a;
+    return 1 - bt * betacf(b, a, 1 - x) / b;
+}
+double student_t_two_sided(double t, double nu) {
+    if (std::isnan(t) || !(nu > 0)) return NAN;
+    if (t == 0) return 1.0;
+    if (std::isinf(t)) return 0.0;
+    // x = nu / (nu + t^2) with its logarithms formed from w = t^2 / nu (a * log(x) would lose a * eps otherwise)
+    const double a = 0.5 * nu, b = 0.5, w = t * t / nu, x = 1 / (1 + w);
+    const double lx = -log1p(w), l1mx = log(w) - log1p(w);
+    double lg_ratio;
+    if (a >= 30.0) {
+        const double ia = 1 / a, ia2 = ia * ia;
+        lg_ratio = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
+    } else
+        lg_ratio = lgamma(a + b) - lgamma(a) - lgamma(b);
+    const double bt = exp(lg_ratio + a * lx + b * l1mx);
+    if (x < (a + 1) / (a + b + 2)) return bt * betacf(a, b, x) / a;
+    return 1 - bt * betacf(b, a, w / (1 + w)) / b;
+}
+// utilities.cpp:321-334
+double linear_reg1d_pvals(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, int n) {
+    double s2y = (sumsqy - sumy * sumy / n) / (n - 1);
+    double s2x = (sumsqx - sumx * sumx / n) / (n - 1);
+    double sxy = (sumxy - sumx * sumy / n) / (n - 1);
+    double rxy = sxy / sqrt(s2x * s2y);
+    double t = rxy * sqrt((n - 2) / (1 - rxy * rxy));
+    return student_t_two_sided(t > 0 ? t : (0 - t), n - 2);   // = 2 * cdf(complement(students_t(n-2), |t|))
+}
+
 // ================================ data.cpp ======================================================
 
 // data.cpp:86-100 -- vector-phenotype ctor: every individual present, pad bits of the last nibble cleared.
@@ -263,6 +329,82 @@ std::vector<double> Data::filter_pheno() const {
             if ((int)(4 * j + k) < N)
                 if (lut_na(mask4[j], k) == 0) y[4 * j + k] = 0;
     return y;
+}
+
+// data.cpp:1108-1226, one estimator.  y_mod = y - z1; for marker k the marker's own contribution is added back
+// (y_mark = y_mod + A_k x_k) and y_mark is regressed on the standardised column.
+std::vector<double> Data::pvals_calc(const std::vector<double>& z1, const std::vector<double>& y,
+                                     const std::vector<double>& x1_hat) {
+    std::vector<double> pvals(M, 0.0), y_mod(4 * mbytes, 0.0);
+    for (int i = 0; i < N; i++) y_mod[i] = y[i] - z1[i];
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int k = 0; k < M; k++) {
+        const uint8_t* bedk = &bed[size_t(k) * mbytes];
+        double sumx = 0, sumsqx = 0, sumxy = 0, sumy = 0, sumsqy = 0;
+        int count = 0;
+        for (size_t i = 0; i < mbytes; i++)
+            for (int j = 0; j < 4; j++) {
+                double bm = lut_b(bedk[i], j) * lut_na(mask4[i], j);
+                double value = (lut_a(bedk[i], j) - mave[k]) * msig[k] * bm;
+                double gen_part = value / sqrt(N);
+                double ym = y_mod[4 * i + j] + gen_part * x1_hat[k];
+                sumx += value;
+                sumsqx += value * value;
+                sumxy += value * ym;
+                sumy += ym * bm;
+                sumsqy += ym * ym * bm;
+                count += (int)bm;
+            }
+        pvals[k] = linear_reg1d_pvals(sumx, sumsqx, sumxy, sumy, sumsqy, count);
+    }
+    return pvals;
+}
+
+// data.cpp:1235-1353, one estimator.  For chromosome ch the whole chromosome's predictor (all ranks, :1268-1272) is
+// added back to y_mod, then its markers are tested against that.
+std::vector<double> Data::pvals_calc_LOCO(const std::vector<double>& z1, const std::vector<double>& y,
+                                          const std::vector<double>& x1_hat, const std::vector<int>& chrom) {
+    std::vector<double> pvals(M, 0.0), y_mod(4 * mbytes, 0.0);
+    for (int i = 0; i < N; i++) y_mod[i] = y[i] - z1[i];
+    for (int ch = 1; ch <= 23; ch++) {
+        std::vector<double> y_chrom(4 * mbytes, 0.0);
+        for (int m = 0; m < M; m++) {
+            if (chrom[m] != ch) continue;
+            const uint8_t* bedm = &bed[size_t(m) * mbytes];
+            for (size_t i = 0; i < mbytes; i++)
+                for (int j = 0; j < 4; j++) {
+                    double gen_part = (lut_a(bedm[i], j) - mave[m]) * msig[m] * lut_b(bedm[i], j) * lut_na(mask4[i], j) / sqrt(N);
+                    y_chrom[4 * i + j] += gen_part * x1_hat[m];
+                }
+        }
+        if (comm) comm->allreduce_sum(y_chrom.data(), y_chrom.size());
+        for (size_t i = 0; i < y_chrom.size(); i++) y_chrom[i] += y_mod[i];
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+        for (int m = 0; m < M; m++) {
+            if (chrom[m] != ch) continue;
+            const uint8_t* bedm = &bed[size_t(m) * mbytes];
+            double sumx = 0, sumsqx = 0, sumxy = 0, sumy = 0, sumsqy = 0;
+            int count = 0;
+            for (size_t i = 0; i < mbytes; i++)
+                for (int j = 0; j < 4; j++) {
+                    double bm = lut_b(bedm[i], j) * lut_na(mask4[i], j);
+                    double value = (lut_a(bedm[i], j) - mave[m]) * msig[m] * bm;
+                    double yc = y_chrom[4 * i + j];
+                    sumx += value;
+                    sumsqx += value * value;
+                    sumxy += value * yc;
+                    sumy += yc * bm;
+                    sumsqy += yc * yc * bm;
+                    count += (int)bm;
+                }
+            pvals[m] = linear_reg1d_pvals(sumx, sumsqx, sumxy, sumy, sumsqy, count);
+        }
+    }
+    return pvals;
 }
 
 // ================================ vamp.cpp ======================================================

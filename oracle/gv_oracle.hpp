@@ -50,6 +50,11 @@ void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int
 double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync, Comm* c);  // :190-210
 double l2_norm2(const std::vector<double>& u, int sync, Comm* c);                             // :212-214
 double calc_stdev(const std::vector<double>& v);                                              // :235-257 (sync=0)
+// utilities.cpp:321-334 -- two-sided t-test of a simple regression slope.  The reference takes the Student-t survival
+// function from Boost (absent here); restated with the regularised incomplete beta function (published algorithm:
+// P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2), continued fraction of Numerical Recipes 6.4 / DLMF 8.17.22).
+double student_t_two_sided(double t, double nu);
+double linear_reg1d_pvals(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, int n);
 
 // ---- class data (data.hpp:93-140) --------------------------------------------------------------
 struct Data {
@@ -72,6 +77,12 @@ struct Data {
     std::vector<double> Ax(const double* x);                      // data.cpp:951-1007 (scalar path, masked)
     std::vector<double> ATx(const double* p);                     // data.cpp:810-835 + :758-779
     std::vector<double> filter_pheno() const;                     // data.cpp:1065-1079
+    // data.cpp:1108-1226 (nE = 1): leave-one-out t-test p-value of every local marker
+    std::vector<double> pvals_calc(const std::vector<double>& z1, const std::vector<double>& y,
+                                   const std::vector<double>& x1_hat);
+    // data.cpp:1235-1353 (nE = 1): leave-one-chromosome-out; chrom[m] in 1..23 (read_chromosome_info, :346-380)
+    std::vector<double> pvals_calc_LOCO(const std::vector<double>& z1, const std::vector<double>& y,
+                                        const std::vector<double>& x1_hat, const std::vector<int>& chrom);
 };
 
 // ---- class vamp (vamp.hpp) : linear model only -------------------------------------------------

@@ -138,6 +138,22 @@ int gvo_atx(const unsigned char* bed, int N, int M, const double* mave, const do
     return 0;
 }
 
+// data::pvals_calc / pvals_calc_LOCO (data.cpp:1108-1353), single full-mask or masked shard, one estimator.
+// chrom == NULL: leave-one-out; else leave-one-chromosome-out.
+int gvo_pvals(const unsigned char* bed, int N, int M, const unsigned char* mask4, int nonas, const double* z1,
+              const double* y, const double* x1_hat, const int* chrom, int nthreads, double* pvals) {
+    Data d;
+    fill_data(d, bed, N, M, mask4, nonas, 1.0, nthreads);
+    d.compute_markers_statistics();
+    std::vector<double> zz(z1, z1 + N), yy(y, y + N), xx(x1_hat, x1_hat + M);
+    std::vector<double> r;
+    if (chrom) r = d.pvals_calc_LOCO(zz, yy, xx, std::vector<int>(chrom, chrom + M));
+    else r = d.pvals_calc(zz, yy, xx);
+    memcpy(pvals, r.data(), sizeof(double) * M);
+    return 0;
+}
+double gvo_student_t_two_sided(double t, double nu) { return student_t_two_sided(t, nu); }
+
 // g1 / g1d on a grid; vars already multiplied by N (as inside infere).
 void gvo_g1_g1d(const double* r, long n, double gam1, const double* probs, const double* vars, int L, double* g1,
                 double* g1d) {

@@ -71,6 +71,9 @@ def lib():
         L.gvo_cg_solve.restype = C.c_int
         L.gvo_cg_solve.argtypes = [up, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_int, dp, dp]
+        L.gvo_pvals.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp]
+        L.gvo_student_t_two_sided.restype = C.c_double
+        L.gvo_student_t_two_sided.argtypes = [C.c_double, C.c_double]
         L.gvo_sim_phen.argtypes = [up, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, C.c_int, dp, dp]
         L.gvo_bern_vec.argtypes = [C.c_ulong, C.c_int, C.c_int, C.c_int, dp]
         L.gvo_divide_work.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -152,6 +155,21 @@ def cg_solve(bed, N, M, v, mu_start, tau, gam2, denoiser, CG_max_iter, nthreads=
     n = lib().gvo_cg_solve(_up(bed), N, M, _dp(v), _dp(ms) if ms is not None else None, tau, gam2, denoiser,
                            CG_max_iter, nthreads, _dp(mu), _dp(rr))
     return mu, rr[:n].copy()
+
+
+def pvals(bed, N, M, z1, y, x1_hat, chrom=None, mask4=None, nonas=None, nthreads=1):
+    """data::pvals_calc (chrom None) / pvals_calc_LOCO; z1, y length >= N (y already filtered), x1_hat length M."""
+    bed, z1, y, x1_hat = _u8(bed), _f64(z1), _f64(y), _f64(x1_hat)
+    out = np.empty(M)
+    m4 = _u8(mask4) if mask4 is not None else None
+    ch = np.ascontiguousarray(chrom, dtype=np.int32) if chrom is not None else None
+    lib().gvo_pvals(_up(bed), N, M, _up(m4) if m4 is not None else None, N if nonas is None else nonas, _dp(z1), _dp(y),
+                    _dp(x1_hat), ch.ctypes.data_as(C.POINTER(C.c_int)) if ch is not None else None, nthreads, _dp(out))
+    return out
+
+
+def student_t_two_sided(t, nu):
+    return lib().gvo_student_t_two_sided(t, nu)
 
 
 def sim_phen(bed, N, Mt, h2, CV, seed, nthreads=1):

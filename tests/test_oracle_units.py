@@ -103,3 +103,32 @@ def test_infere_stops_on_criterion_and_counts_matvecs(oracle):
     t = r.trace[1]
     # per iteration (it > 1): Ax = K1 + K2 + 8 incl. warm start, ATx = K1 + K2 + 3
     assert t["n_ax"] == t["cg_iters"] + t["onsager_iters"] + 1 + 7 and t["n_atx"] == t["cg_iters"] + t["onsager_iters"] + 3
+
+
+def test_student_t_against_scipy(oracle):
+    import scipy.stats as ss
+    for nu in (1, 3, 58, 1998, 399998):
+        for t in (1e-6, 0.5, 2.0, 5.0, 12.0, 40.0):
+            assert np.isclose(oracle.student_t_two_sided(t, nu), 2 * ss.t.sf(t, nu), rtol=5e-10, atol=0)
+    assert oracle.student_t_two_sided(0.0, 10) == 1.0
+
+
+def test_pvals_loo_against_scipy_linregress(oracle):
+    """data::pvals_calc (data.cpp:1108-1226): regress y - A_{-k} x_{-k} on the standardised column k."""
+    import scipy.stats as ss
+    N, M = 300, 25
+    rng = np.random.default_rng(2)
+    bed = synth.synth_bed(N, M, seed=13, miss_ppm=20000)
+    a, b = decode(bed, N, M)
+    mave, msig = oracle.marker_stats(bed, N, M)
+    A = ((a - mave[:, None]) * msig[:, None] * b).T                  # N x M, not divided by sqrt(N)
+    x1 = rng.standard_normal(M)
+    z1 = oracle.ax(bed, N, M, mave, msig, x1)
+    y = np.zeros(z1.size)
+    y[:N] = z1[:N] + rng.standard_normal(N)
+    pv = oracle.pvals(bed, N, M, z1, y, x1)
+    for k in (0, 7, 24):
+        keep = b[k] > 0                                              # individuals with a genotype at marker k
+        ymark = (y[:N] - z1[:N]) + A[:, k] / np.sqrt(N) * x1[k]
+        ref = ss.linregress(A[keep, k], ymark[keep]).pvalue
+        assert np.isclose(pv[k], ref, rtol=1e-8)
