@@ -271,7 +271,7 @@ void free_dataset(gv_ctx* c) {
     F(c->plan.scal); F(c->plan.partial);
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
-    for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d})
+    for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p})
         if (*v) {
             (void)hipFree((*v)->d);
             delete *v;
@@ -755,6 +755,121 @@ int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, cons
     gvk::prior_estep(c->stream, r1->d, c->M, gam1, lambda, pr, c->red_partial, c->red_out);
     KCHK(c);
     return read_scalars(c, 1 + 2 * (L - 1), sums);
+}
+
+// ---- --use-XXT-denoiser 1: LMMSE through CG in N-space (denoiserXXT.cpp), matrix-free ------------------------------
+// data::compute_people_statistics (data.cpp:558-716): three table passes of the fp64 Ax kernel over the raw rows.
+int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double* numb_people) {
+    NEED(c, c->have_stats && c->mask2, "gv_people_stats: marker statistics must be computed first");
+    NEED(c, c->have_raw, "gv_people_stats: needs the raw row layout (gv_set_layout(raw_rows = 1))");
+    if (ensure_work(c)) return 1;
+    for (gv_vec** v : {&c->mave_p, &c->msig_p, &c->numb_p})
+        if (!*v && vec_new(c, GV_SPACE_N, v)) return 1;
+    gv_vec* dst[3] = {c->mave_p, c->numb_p, c->msig_p};   // kinds 0 (sum value), 1 (count), 2 (sum value^2)
+    for (int kind = 0; kind < 3; kind++) {
+        gvk::people_table(c->stream, c->mave, c->msig, c->M, kind, c->t3);
+        gvk::ax_f64(c->stream, c->bed, c->M, c->pitch, c->t3, c->ax_chunks, c->ax_partial, c->npad);
+        gvk::ax_reduce(c->stream, c->ax_partial, c->ax_chunks, c->npad, c->mask2, 1.0, dst[kind]->d);
+        KCHK(c);
+        if (comm_allreduce(c, dst[kind]->d, c->npad)) return 1;     // data.cpp:604-606
+    }
+    gvk::people_finish(c->stream, c->mave_p->d, c->msig_p->d, c->numb_p->d, c->mask2, c->N, c->npad);
+    KCHK(c);
+    const size_t n4 = sizeof(double) * 4 * c->mbytes;
+    if (mave_people) HIPCHK(c, hipMemcpyAsync(mave_people, c->mave_p->d, n4, hipMemcpyDeviceToHost, c->stream));
+    if (msig_people) HIPCHK(c, hipMemcpyAsync(msig_people, c->msig_p->d, n4, hipMemcpyDeviceToHost, c->stream));
+    if (numb_people) HIPCHK(c, hipMemcpyAsync(numb_people, c->numb_p->d, n4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// vamp::lmmse_multAAT (denoiserXXT.cpp:15-35): out = tau A A^T u + gam2 u on N-space device pointers
+static int lmmse_aat_device(gv_ctx* c, const double* u, double tau, double gam2, double* tmpM, double* out) {
+    if (atx_device(c, u, tmpM)) return 1;
+    if (ax_device(c, tmpM, out)) return 1;
+    gvk::axpby(c->stream, out, tau, out, gam2, u, c->npad);
+    KCHK(c);
+    return 0;
+}
+
+// vamp::CG_solverAAT (denoiserXXT.cpp:52-130): per-individual diagonal preconditioner, tolerance 1e-4, inner
+// products not all-reduced (N-vectors are replicated).  mu_start may be NULL (zeros).
+int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int max_iter,
+                    gv_vec* mu_out, gv_cg_stats* st, double* relres) {
+    NEED(c, v->space == GV_SPACE_N && mu_out->space == GV_SPACE_N, "gv_cg_solve_aat: N-space vectors required");
+    NEED(c, mu_out != v && mu_out != mu_start, "gv_cg_solve_aat: mu_out must not alias v or mu_start");
+    NEED(c, c->mave_p, "gv_cg_solve_aat: gv_people_stats must run first");
+    if (ensure_work(c)) return 1;
+    hipStream_t s = c->stream;
+    const int64_t n = c->npad;
+    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr;
+    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG}) if (x) { (void)hipFree(x->d); delete x; } };
+    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
+        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
+    double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_out->d, *tmpM = c->cg_d->d;
+    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
+    int rc = 0, iters = 0, converged = 0, n_relres = 0;
+    double sc[2], rel_err = 0;
+#define AAT_TRY(expr) do { if ((expr) != 0) { rc = 1; goto done; } } while (0)
+#define AAT_HIP(expr) do { if ((expr) != hipSuccess) { rc = fail(c, "%s failed", #expr); goto done; } } while (0)
+    {
+        gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
+        if (mu_start) {
+            AAT_HIP(hipMemcpyAsync(mu, mu_start->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            AAT_TRY(lmmse_aat_device(c, mu, tau, gam2, tmpM, r));
+            gvk::axpby(s, r, 1.0, v->d, -1.0, r, n);                       // r = v - Q mu (:71-73)
+        } else {
+            gvk::fill(s, mu, n, 0.0);
+            AAT_HIP(hipMemcpyAsync(r, v->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        }
+        gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);   // z = r / diag (:76-77)
+        AAT_TRY(read_scalars(c, 2, sc));
+        double rz = sc[0];
+        const double* vv[1] = {v->d};
+        gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
+        double vn2;
+        AAT_TRY(read_scalars(c, 1, &vn2));
+        AAT_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        for (int i = 0; i < max_iter; i++) {
+            iters = i + 1;
+            AAT_TRY(lmmse_aat_device(c, p, tau, gam2, tmpM, d));              // d = Q p (:86)
+            const double* xs[1] = {d};
+            const double* ys[1] = {p};
+            gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
+            double dp;
+            AAT_TRY(read_scalars(c, 1, &dp));
+            const double alpha = rz / dp;                                     // :88
+            gvk::axpby(s, mu, 1.0, mu, alpha, p, n);                           // mu += alpha p (:90-93)
+            gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);   // :95-105
+            AAT_TRY(read_scalars(c, 2, sc));
+            const double beta = sc[0] / rz;                                    // :98,:107
+            rz = sc[0];
+            gvk::axpby(s, p, 1.0, z, beta, p, n);                              // :109-110
+            rel_err = sqrt(sc[1] / vn2);                                       // :113-114
+            if (relres) relres[i] = rel_err;
+            n_relres = i + 1;
+            if (rel_err < 1e-4) {                                              // :117,:120
+                converged = 1;
+                break;
+            }
+        }
+        AAT_HIP(hipGetLastError());
+    }
+done:
+#undef AAT_TRY
+#undef AAT_HIP
+    if (st) {
+        st->iters = iters;
+        st->converged = converged;
+        st->rel_res = rel_err;
+        st->onsager = 0;
+        st->n_ax = (int)(c->cnt.n_ax - ax0);
+        st->n_atx = (int)(c->cnt.n_atx - atx0);
+        st->n_relres = n_relres;
+    }
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    return rc;
 }
 
 // ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------

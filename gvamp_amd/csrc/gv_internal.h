@@ -49,6 +49,7 @@ struct gv_ctx {
     double* red_partial = nullptr; // RED_BLOCKS * RED_MAXK block partials
     double* red_out = nullptr;     // RED_MAXK device scalars
     double* host_pin = nullptr;    // pinned, RED_MAXK doubles
+    gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
     gv_vec *w_n = nullptr;                                   // N-space scratch (lmmse_mult)
     gv_vec *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_d = nullptr;  // CG work vectors
 
@@ -86,6 +87,13 @@ void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int6
                   double alpha_scale, double* mave, double* msig, uint32_t* counts);
 void marker_sums2_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p1, const double* p2,
                       double* out4);
+void people_table(hipStream_t s, const double* mave, const double* msig, int64_t M, int kind, double* t3);
+void people_finish(hipStream_t s, double* s1, double* s2, const double* cnt, const uint32_t* mask2, int64_t N,
+                   int64_t npad);
+void aat_diag(hipStream_t s, const double* mave_p, const double* msig_p, const double* numb_p, double tau, double gam2,
+              double Nd, int64_t npad, double* diag);
+void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, const double* diag, double* z, int64_t n,
+                    double* partial, double* out);   // out = <r,z>, <r,r>
 void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n);
 void select_eq(hipStream_t s, double* out, const double* x, const int* key, int value, int64_t n);
 void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3);

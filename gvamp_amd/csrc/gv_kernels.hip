@@ -250,6 +250,69 @@ __global__ __launch_bounds__(256) void k_marker_sums2_f64(const uint32_t* __rest
     }
 }
 
+// ---- data::compute_people_statistics (data.cpp:558-716): per-marker tables for three k_ax_f64 passes -----------------
+// kind 0: value = (a - mu) sigma          -> {(2-mu)s, (1-mu)s, (0-mu)s}
+// kind 1: b (count of non-missing)        -> {1, 1, 1}
+// kind 2: value^2
+__global__ void k_people_table(const double* __restrict__ mave, const double* __restrict__ msig, int64_t M, int kind,
+                               double* __restrict__ t3) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double mu = mave[i], s = msig[i];
+    double v2 = (2.0 - mu) * s, v1 = (1.0 - mu) * s, v0 = (0.0 - mu) * s;
+    if (kind == 1) v2 = v1 = v0 = 1.0;
+    if (kind == 2) { v2 *= v2; v1 *= v1; v0 *= v0; }
+    t3[3 * i] = v2;
+    t3[3 * i + 1] = v1;
+    t3[3 * i + 2] = v0;
+}
+// mean = S1 / cnt ; msig = sqrt((cnt - 1) / (S2 - cnt mean^2)) for individuals with a phenotype, else 0 (data.cpp:608-624)
+__global__ void k_people_finish(double* __restrict__ s1, double* __restrict__ s2, const double* __restrict__ cnt,
+                                const uint32_t* __restrict__ mask2, int64_t N, int64_t npad) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npad) return;
+    const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+    if (n < N && present) {
+        const double c = cnt[n], mean = s1[n] / c;
+        s1[n] = mean;
+        s2[n] = sqrt((c - 1) / (s2[n] - c * mean * mean));
+    } else {
+        s1[n] = 0.0;
+        s2[n] = 0.0;
+    }
+}
+// preconditioner of CG_solverAAT (denoiserXXT.cpp:59-66)
+__global__ void k_aat_diag(const double* __restrict__ mave_p, const double* __restrict__ msig_p,
+                           const double* __restrict__ numb_p, double tau, double gam2, double Nd, int64_t npad,
+                           double* __restrict__ diag) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npad) return;
+    diag[n] = tau * ((numb_p[n] - 1) / msig_p[n] / msig_p[n] + mave_p[n] * mave_p[n] * numb_p[n]) / Nd + gam2;
+}
+// denoiserXXT.cpp:100-118: r -= alpha d ; z = r / diag[n] ; partials of <r,z>, <r,r>.  alpha == 0: initialisation pass.
+__global__ __launch_bounds__(256) void k_cg_b_diag(double* __restrict__ r, const double* __restrict__ d, double alpha,
+                                                   const double* __restrict__ diag, double* __restrict__ z, int64_t n,
+                                                   double* __restrict__ partial) {
+    __shared__ double sh[4];
+    int64_t stride = (int64_t)gridDim.x * 256;
+    double s0 = 0, s1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double ri = r[i];
+        if (alpha != 0.0) ri -= d[i] * alpha;
+        double zi = ri / diag[i];
+        r[i] = ri;
+        z[i] = zi;
+        s0 += ri * zi;
+        s1 += ri * ri;
+    }
+    s0 = block_sum_256(s0, sh);
+    s1 = block_sum_256(s1, sh);
+    if (threadIdx.x == 0) {
+        partial[(int64_t)blockIdx.x * 2] = s0;
+        partial[(int64_t)blockIdx.x * 2 + 1] = s1;
+    }
+}
+
 // out = x * y (element-wise) and out = a where mask (chrom[i] == ch) else 0 helpers of the p-value passes
 __global__ void k_mul(double* out, const double* x, const double* y, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,6 +552,25 @@ void marker_sums2_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitc
     if (M == 0) return;
     hipLaunchKernelGGL(k_marker_sums2_f64, dim3(nblk(M, 16)), dim3(256), 0, s, (const uint32_t*)bed, M, pitch / 4, p1, p2,
                        out4);
+}
+
+void people_table(hipStream_t s, const double* mave, const double* msig, int64_t M, int kind, double* t3) {
+    if (M == 0) return;
+    hipLaunchKernelGGL(k_people_table, dim3(nblk(M, 256)), dim3(256), 0, s, mave, msig, M, kind, t3);
+}
+void people_finish(hipStream_t s, double* s1, double* s2, const double* cnt, const uint32_t* mask2, int64_t N,
+                   int64_t npad) {
+    hipLaunchKernelGGL(k_people_finish, dim3(nblk(npad, 256)), dim3(256), 0, s, s1, s2, cnt, mask2, N, npad);
+}
+void aat_diag(hipStream_t s, const double* mave_p, const double* msig_p, const double* numb_p, double tau, double gam2,
+              double Nd, int64_t npad, double* diag) {
+    hipLaunchKernelGGL(k_aat_diag, dim3(nblk(npad, 256)), dim3(256), 0, s, mave_p, msig_p, numb_p, tau, gam2, Nd, npad, diag);
+}
+void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, const double* diag, double* z, int64_t n,
+                    double* partial, double* out) {
+    int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_cg_b_diag, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 2, out);
 }
 
 void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n) {

@@ -52,6 +52,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     Options opt;   // carries the knobs the reference reads from the command line
     opt.set_solver(o->EM_max_iter, o->CG_max_iter, o->EM_err_thr, o->stop_criteria_thr, o->learn_vars,
                    (unsigned int)o->seed, o->use_lmmse_damp, o->diagnostics, (o->out_prefix && o->out_prefix[0]) ? 1 : 0);
+    opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
     vamp vm(N, M, Mt, o->gam1, o->gamw, o->iterations, o->rho, vars, probs, ts, rank, "",
             o->out_prefix ? o->out_prefix : "", "linear", opt);
     vm.set_verbose(o->verbose);

@@ -78,6 +78,7 @@ public:
         stop_criteria_thr = stop_criteria_thr_; learn_vars = learn_vars_; seed = seed_;
         use_lmmse_damp = use_lmmse_damp_; diagnostics = diagnostics_; store_iterates = store_iterates_;
     }
+    void set_use_XXT_denoiser(unsigned int v) { use_XXT_denoiser = v; }
 
 private:
     std::string bed_file = "", bed_file_test = "", estimate_file = "", freeze_index_file = "", cov_estimate_file = "",

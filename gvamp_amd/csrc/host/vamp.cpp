@@ -63,7 +63,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2})
+                      tN, tN2, mu_CG_last_N})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -103,9 +103,9 @@ int vamp::cg(gv_vec* v, gv_vec* mu_start, double tau, int denoiser, gv_vec* mu_o
 
 std::vector<double> vamp::infere(data* dataset) {
     for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;   // design matrix is scaled by 1/sqrt(N) (vamp.cpp:154-155)
-    if (reverse == 1) {
-        std::cout << "FATAL: --use-XXT-denoiser 1 is not built yet (SURVEY 8f next-2)" << std::endl;
-        exit(EXIT_FAILURE);
+    if (reverse == 1) {                                       // vamp.cpp:169-170
+        ctx = dataset->get_ctx();
+        ck(gv_people_stats(ctx, nullptr, nullptr, nullptr), "gv_people_stats (--use-XXT-denoiser needs --kernel-mode 0 or both layouts)");
     }
     if (!strcmp(model.c_str(), "linear")) return infere_linear(dataset);
     throw "invalid model specification!";   // vamp.cpp:180 (bin_class / robust: SURVEY 8f)
@@ -335,11 +335,28 @@ std::vector<double> vamp::infere_linear(data* dataset) {
 
         // ---- LMMSE step (:547-620)
         if (verbose && rank == 0) std::cout << "______________________" << std::endl << "->LMMSE" << std::endl;
-        ck(gv_atx_dev(ctx, y, vM), "gv_atx_dev");                          // v = gamw A^T y + gam2 r2 (:588-591)
-        ck(gv_vec_axpby(ctx, vM, gamw, vM, gam2, r2), "gv_vec_axpby");
-        cg(vM, (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last, gamw, 1, x2_hat, &st.cg_iters);   // :593-596
-        ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");           // :1225-1226
-        have_mu_CG_last = true;
+        if (reverse == 0) {
+            ck(gv_atx_dev(ctx, y, vM), "gv_atx_dev");                      // v = gamw A^T y + gam2 r2 (:588-591)
+            ck(gv_vec_axpby(ctx, vM, gamw, vM, gam2, r2), "gv_vec_axpby");
+            cg(vM, (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last, gamw, 1, x2_hat, &st.cg_iters);   // :593-596
+            ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");       // :1225-1226
+            have_mu_CG_last = true;
+        } else {
+            // lmmse_denoiserAAT (denoiserXXT.cpp:37-50): (gamw A A^T + gam2 I) u = y - A r2 ; x2 = r2 + gamw A^T u
+            if (!mu_CG_last_N) ck(gv_vec_alloc(ctx, GV_SPACE_N, &mu_CG_last_N), "gv_vec_alloc");
+            ck(gv_ax_dev(ctx, r2, tN), "gv_ax_dev");
+            ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, tN), "gv_vec_axpby");
+            gv_cg_stats cst;
+            std::vector<double> relres(CG_max_iter > 0 ? CG_max_iter : 1);
+            ck(gv_cg_solve_aat(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, gamw, gam2, CG_max_iter, tN2, &cst, relres.data()),
+               "gv_cg_solve_aat");
+            st.cg_iters = cst.iters;
+            if (verbose && rank == 0)
+                for (int i = 0; i < cst.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, relres[i]);
+            ck(gv_vec_copy(ctx, mu_CG_last_N, tN2), "gv_vec_copy");
+            ck(gv_atx_dev(ctx, tN2, x2_hat), "gv_atx_dev");
+            ck(gv_vec_axpby(ctx, x2_hat, gamw, x2_hat, 1.0, r2), "gv_vec_axpby");
+        }
         t0 = now_s();
         store_scaled(pre + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat, &x2_hist);
         t_io += now_s() - t0;

@@ -39,7 +39,7 @@ private:
     gv_ctx* ctx = nullptr;
     gv_vec *x1_hat = nullptr, *x1_hat_prev = nullptr, *x2_hat = nullptr, *r1 = nullptr, *r2 = nullptr, *r2_prev = nullptr,
            *z1 = nullptr, *y = nullptr, *mu_CG_last = nullptr, *bern_vec = nullptr, *invQ_bern_vec = nullptr,
-           *vM = nullptr, *tM = nullptr, *tN = nullptr, *tN2 = nullptr;
+           *vM = nullptr, *tM = nullptr, *tN = nullptr, *tN2 = nullptr, *mu_CG_last_N = nullptr;
     bool have_mu_CG_last = false;
     std::vector<vamp_iter_stats> stats;
     std::vector<std::vector<double>> x1_hist, x2_hist, r1_hist;   // per iteration, already / sqrt(N) (if keep_history)

@@ -21,7 +21,7 @@ class Opts(C.Structure):
                 ("learn_vars", C.c_int), ("seed", C.c_ulong), ("use_lmmse_damp", C.c_int),
                 ("gam1", C.c_double), ("gamw", C.c_double), ("L", C.c_int),
                 ("probs", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
-                ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double)]
+                ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double), ("use_XXT_denoiser", C.c_int)]
 
 
 class Iter(C.Structure):
@@ -65,7 +65,7 @@ class Result:
 def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_max_iter=2, EM_err_thr=1e-2,
                   stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1, use_lmmse_damp=0, gam1=1e-8, gamw=2.0,
                   true_signal=None, out_prefix=None, verbose=0, diagnostics=0, alpha_scale=1.0, mask4=None,
-                  nonas=None, history=True, rank=0):
+                  nonas=None, history=True, rank=0, use_XXT_denoiser=0):
     L = load()
     y = np.ascontiguousarray(y, dtype=np.float64)
     o = Opts()
@@ -81,6 +81,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
         o.L = 0
     o.out_prefix = out_prefix.encode() if out_prefix else None
     o.verbose, o.diagnostics, o.alpha_scale = verbose, diagnostics, alpha_scale
+    o.use_XXT_denoiser = use_XXT_denoiser
     M = shard.M
     ts = np.ascontiguousarray(true_signal, dtype=np.float64) if true_signal is not None else None
     m4 = np.ascontiguousarray(mask4, dtype=np.uint8) if mask4 is not None else None

@@ -118,6 +118,16 @@ int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, 
  * sums[2+2j] = sum_i beta_ij (m_ij^2 + v_j) pi_i for j = 0..L-2 (local sums; caller all-reduces 1+2(L-1)). */
 int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
                    const double* vars, int L, double* sums);
+/* ---- --use-XXT-denoiser 1 (vamp.cpp:169-170, :599-606; denoiserXXT.cpp): LMMSE through CG in N-space, matrix-free --
+ * data::compute_people_statistics (data.cpp:558-716): per-individual mean, inverse std and count of the standardised
+ * genotypes, all-reduced over ranks; kept on the device for gv_cg_solve_aat.  Host copies (4*mbytes doubles each) are
+ * optional (NULL).  Needs the raw row layout. */
+int gv_people_stats(gv_ctx* ctx, double* mave_people, double* msig_people, double* numb_people);
+/* vamp::CG_solverAAT (denoiserXXT.cpp:52-130): solves (tau A A^T + gam2 I) mu = v in N-space with the per-individual
+ * diagonal preconditioner, stopping at ||r||/||v|| < 1e-4.  mu_start may be NULL (zeros). */
+int gv_cg_solve_aat(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int max_iter,
+                    gv_vec* mu_out, gv_cg_stats* stats, double* relres);
+
 /* ---- association tests after the loop (vamp.cpp:761-776) ------------------------------------------------------
  * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,
  * pvals[M].  z1 = A x1_hat and y (filtered phenotype) are N-space handles, x1_hat the M-space estimate (the

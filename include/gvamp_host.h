@@ -24,6 +24,7 @@ typedef struct {                 /* the knobs vamp reads from Options (options.h
     int verbose;
     int diagnostics;              /* 1: also run the 3 print-only Ax of vamp.cpp:646-681 */
     double alpha_scale;
+    int use_XXT_denoiser;         /* --use-XXT-denoiser (options.cpp:208-216) */
 } gvh_opts;
 
 typedef struct {

@@ -331,6 +331,44 @@ std::vector<double> Data::filter_pheno() const {
     return y;
 }
 
+// data.cpp:558-716 (bed branch): sums over the LOCAL markers, all-reduced over ranks (:604-606), then
+// mean = S1 / cnt, msig = sqrt((cnt - 1) / (S2 - cnt * mean^2)); individuals without a phenotype get 0 / 0.
+void Data::compute_people_statistics() {
+    std::vector<double> s1(4 * mbytes, 0.0), s2(4 * mbytes, 0.0), cnt(4 * mbytes, 0.0);
+    for (int i = 0; i < M; i++) {
+        const uint8_t* bedm = &bed[size_t(i) * mbytes];
+        for (size_t j = 0; j < mbytes; j++)
+            for (int k = 0; k < 4; k++) {
+                double bm = lut_b(bedm[j], k) * lut_na(mask4[j], k);
+                double value = (lut_a(bedm[j], k) - mave[i]) * msig[i] * bm;
+                s1[4 * j + k] += value;
+                cnt[4 * j + k] += bm;
+                s2[4 * j + k] += value * value;
+            }
+    }
+    if (comm) {
+        comm->allreduce_sum(s1.data(), s1.size());
+        comm->allreduce_sum(cnt.data(), cnt.size());
+        comm->allreduce_sum(s2.data(), s2.size());
+    }
+    for (size_t j = 0; j < mbytes; j++)
+        for (int k = 0; k < 4; k++) {
+            size_t n = 4 * j + k;
+            if ((int)n >= N) continue;
+            if (lut_na(mask4[j], k) == 1) {
+                s1[n] /= cnt[n];
+                s2[n] = (cnt[n] - 1) / (s2[n] - cnt[n] * s1[n] * s1[n]);
+            } else {
+                s1[n] = 0;
+                s2[n] = 0;
+            }
+        }
+    mave_people = s1;
+    msig_people = s2;
+    numb_people = cnt;
+    for (int i = 0; i < N; i++) msig_people[i] = sqrt(msig_people[i]);
+}
+
 // data.cpp:1108-1226, one estimator.  y_mod = y - z1; for marker k the marker's own contribution is added back
 // (y_mark = y_mod + A_k x_k) and y_mark is regressed on the standardised column.
 std::vector<double> Data::pvals_calc(const std::vector<double>& z1, const std::vector<double>& y,
@@ -608,6 +646,79 @@ std::vector<double> Vamp::precondCG_solver(const std::vector<double>& v, const s
     return mu;
 }
 
+// denoiserXXT.cpp:15-35: (tau A A^T + gam2 I) u, matrix-free (ATx then Ax)
+std::vector<double> Vamp::lmmse_multAAT(const std::vector<double>& u, double tau) {
+    size_t phen_size = 4 * d->mbytes;
+    bool all_zero = true;
+    for (double x : u) if (x != 0.0) { all_zero = false; break; }
+    if (all_zero) return std::vector<double>(phen_size, 0.0);
+    std::vector<double> up(u);
+    up.resize(phen_size, 0.0);
+    std::vector<double> res_temp = d->ATx(up.data());
+    std::vector<double> res = d->Ax(res_temp.data());
+    for (int i = 0; i < N; i++) {
+        res[i] *= tau;
+        res[i] += gam2 * u[i];
+    }
+    return res;
+}
+
+// denoiserXXT.cpp:52-130: CG in N-space with the per-individual diagonal preconditioner, tolerance 1e-4,
+// un-synchronised inner products (N-vectors are replicated over ranks).
+std::vector<double> Vamp::CG_solverAAT(const std::vector<double>& v, const std::vector<double>& mu_start, double tau,
+                                       int save) {
+    int mbytes4 = 4 * (int)d->mbytes;
+    const std::vector<double>&mave_people = d->mave_people, &msig_people = d->msig_people, &numb_people = d->numb_people;
+    std::vector<double> diag(N, 1.0);
+    for (int i = 0; i < N; i++)
+        diag[i] = tau * ((numb_people[i] - 1) / msig_people[i] / msig_people[i] + mave_people[i] * mave_people[i] * numb_people[i]) / N + gam2;
+    std::vector<double> mu = mu_start;
+    mu.resize(mbytes4, 0.0);
+    std::vector<double> dd;
+    std::vector<double> r = lmmse_multAAT(mu, tau);
+    for (int i0 = 0; i0 < N; i0++) r[i0] = v[i0] - r[i0];
+    std::vector<double> z(mbytes4, 0.0);
+    for (int i0 = 0; i0 < N; i0++) z[i0] = r[i0] / diag[i0];
+    std::vector<double> p = z, Apalpha(mbytes4, 0.0), palpha(mbytes4, 0.0);
+    double alpha, beta;
+    std::vector<double> vpad(v);
+    vpad.resize(mbytes4, 0.0);
+    std::vector<double> relres;
+    int iters = 0;
+    for (int i = 0; i < o.CG_max_iter; i++) {
+        iters = i + 1;
+        dd = lmmse_multAAT(p, tau);
+        alpha = inner_prod(r, z, 0, comm) / inner_prod(dd, p, 0, comm);
+        for (int j = 0; j < N; j++) palpha[j] = alpha * p[j];
+        for (size_t j = 0; j < mu.size(); j++) mu[j] += palpha[j];
+        for (int j = 0; j < N; j++) Apalpha[j] = dd[j] * alpha;
+        beta = pow(inner_prod(r, z, 0, comm), -1);
+        for (size_t j = 0; j < r.size(); j++) r[j] -= Apalpha[j];
+        for (int j = 0; j < N; j++) z[j] = r[j] / diag[j];
+        beta *= inner_prod(r, z, 0, comm);
+        for (int j = 0; j < N; j++) p[j] = z[j] + beta * p[j];
+        double rel_err = sqrt(l2_norm2(r, 0, comm) / l2_norm2(vpad, 0, comm));
+        relres.push_back(rel_err);
+        if (o.verbose && (!comm || comm->rank == 0)) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rel_err);
+        if (rel_err < 1e-4) break;
+    }
+    last_cg_iters = iters;
+    cg_relres.push_back(relres);
+    if (save == 1) mu_CG_last = mu;
+    return mu;
+}
+
+// denoiserXXT.cpp:37-50: x2 = r2 + gamw A^T u, (gamw A A^T + gam2 I) u = y - A r2
+std::vector<double> Vamp::lmmse_denoiserAAT(const std::vector<double>& r2_, const std::vector<double>& mu_last) {
+    std::vector<double> z2 = d->Ax(r2_.data());
+    std::vector<double> v(N, 0.0);
+    for (int i = 0; i < N; i++) v[i] = y[i] - z2[i];
+    std::vector<double> u = CG_solverAAT(v, mu_last, gamw, 1);
+    std::vector<double> res = d->ATx(u.data());
+    for (int i = 0; i < M; i++) res[i] = gamw * res[i] + r2_[i];
+    return res;
+}
+
 // vamp.cpp:871-889 -- Hutchinson probe u in {+-1/sqrt(Mt)}^M from mt19937{seed + S} + bernoulli(0.5).
 double Vamp::g2d_onsager(double gam2_, double tau) {
     std::mt19937 rd{o.seed + (unsigned long)d->S};
@@ -667,6 +778,7 @@ static void store_bin(const std::string& path, const std::vector<double>& v, int
 std::vector<double> Vamp::infere() {
     y = d->phen;
     for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;
+    if (o.use_XXT_denoiser == 1) d->compute_people_statistics();        // vamp.cpp:169-170
 
     std::vector<double> x1_hat_d(M, 0.0), x1_hat_stored(M, 0.0), x1_hat_prev(M, 0.0);
     alpha1 = 0;
@@ -751,10 +863,15 @@ std::vector<double> Vamp::infere() {
         }
 
         // ---- LMMSE step (:584-596)
-        std::vector<double> v = d->ATx(y.data());
-        for (int i = 0; i < M; i++) v[i] = gamw * v[i] + gam2 * r2[i];
-        if (it == 1) x2_hat = precondCG_solver(v, std::vector<double>(M, 0.0), gamw, 1);
-        else x2_hat = precondCG_solver(v, mu_CG_last, gamw, 1);
+        if (o.use_XXT_denoiser == 0) {
+            std::vector<double> v = d->ATx(y.data());
+            for (int i = 0; i < M; i++) v[i] = gamw * v[i] + gam2 * r2[i];
+            if (it == 1) x2_hat = precondCG_solver(v, std::vector<double>(M, 0.0), gamw, 1);
+            else x2_hat = precondCG_solver(v, mu_CG_last, gamw, 1);
+        } else {                                                        // vamp.cpp:599-606
+            if (it == 1) mu_CG_last = std::vector<double>(4 * d->mbytes, 0.0);
+            x2_hat = lmmse_denoiserAAT(r2, mu_CG_last);
+        }
         tr.cg_iters = last_cg_iters;
         std::vector<double> x2_hat_stored = x2_hat;
         for (size_t i0 = 0; i0 < x2_hat_stored.size(); i0++) x2_hat_stored[i0] = x2_hat[i0] / scale;

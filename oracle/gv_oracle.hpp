@@ -77,6 +77,9 @@ struct Data {
     std::vector<double> Ax(const double* x);                      // data.cpp:951-1007 (scalar path, masked)
     std::vector<double> ATx(const double* p);                     // data.cpp:810-835 + :758-779
     std::vector<double> filter_pheno() const;                     // data.cpp:1065-1079
+    // data.cpp:558-716 -- per-individual mean / inverse std / count of the standardised genotypes (bed branch)
+    std::vector<double> mave_people, msig_people, numb_people;    // 4*mbytes each
+    void compute_people_statistics();
     // data.cpp:1108-1226 (nE = 1): leave-one-out t-test p-value of every local marker
     std::vector<double> pvals_calc(const std::vector<double>& z1, const std::vector<double>& y,
                                    const std::vector<double>& x1_hat);
@@ -99,6 +102,7 @@ struct VampOpts {
     std::vector<double> true_signal;      // local shard, may be empty (treated as zeros)
     std::string out_prefix;               // "" = no files; else out_dir+out_name as in vamp.cpp:435
     int verbose = 0;
+    int use_XXT_denoiser = 0;             // vamp.cpp:68,169-170,599-606: LMMSE via CG in N-space (denoiserXXT.cpp)
 };
 
 struct IterTrace {
@@ -130,6 +134,10 @@ struct Vamp {
     std::vector<double> precondCG_solver(const std::vector<double>& v, const std::vector<double>& mu_start,
                                          double tau, int denoiser);                        // :1130-1229
     double g2d_onsager(double gam2, double tau);                   // :871-889
+    std::vector<double> lmmse_multAAT(const std::vector<double>& u, double tau);            // denoiserXXT.cpp:15-35
+    std::vector<double> CG_solverAAT(const std::vector<double>& v, const std::vector<double>& mu_start, double tau,
+                                     int save);                                            // denoiserXXT.cpp:52-130
+    std::vector<double> lmmse_denoiserAAT(const std::vector<double>& r2, const std::vector<double>& mu_last);  // :37-50
     void updateNoisePrec();                                        // :892-927
     void err_measures(int ind);                                    // :1232-1318
     std::vector<double> infere();                                  // :149-183 + :190-803 (linear)

@@ -80,6 +80,7 @@ struct gvo_params {
     const unsigned char* is_na; // N flags, phen_mode 1 only
     allreduce_cb_t cb;          // shard_rank >= 0 && nshards > 1
     void* cb_user;
+    int use_XXT_denoiser;       // vamp.cpp:169-170, :599-606
 };
 
 struct gvo_run {
@@ -153,6 +154,19 @@ int gvo_pvals(const unsigned char* bed, int N, int M, const unsigned char* mask4
     return 0;
 }
 double gvo_student_t_two_sided(double t, double nu) { return student_t_two_sided(t, nu); }
+
+// data::compute_people_statistics (data.cpp:558-716) on a single shard: three vectors of 4*mbytes doubles
+int gvo_people_stats(const unsigned char* bed, int N, int M, const unsigned char* mask4, int nonas, double* mave_p,
+                     double* msig_p, double* numb_p) {
+    Data d;
+    fill_data(d, bed, N, M, mask4, nonas, 1.0, 1);
+    d.compute_markers_statistics();
+    d.compute_people_statistics();
+    memcpy(mave_p, d.mave_people.data(), sizeof(double) * 4 * d.mbytes);
+    memcpy(msig_p, d.msig_people.data(), sizeof(double) * 4 * d.mbytes);
+    memcpy(numb_p, d.numb_people.data(), sizeof(double) * 4 * d.mbytes);
+    return 0;
+}
 
 // g1 / g1d on a grid; vars already multiplied by N (as inside infere).
 void gvo_g1_g1d(const double* r, long n, double gam1, const double* probs, const double* vars, int L, double* g1,
@@ -266,6 +280,7 @@ static void run_shard(const gvo_params* p, const unsigned char* bed_full, const 
     if (p->true_signal) o.true_signal.assign(p->true_signal + S, p->true_signal + S + M);
     if (p->out_prefix) o.out_prefix = p->out_prefix;
     o.verbose = p->verbose;
+    o.use_XXT_denoiser = p->use_XXT_denoiser;
     Vamp v(&d, o);
     std::vector<double> x = v.infere();
     std::lock_guard<std::mutex> lk(*mu);

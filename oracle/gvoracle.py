@@ -28,7 +28,7 @@ class Params(C.Structure):
                 ("true_signal", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
                 ("verbose", C.c_int), ("nthreads", C.c_int), ("alpha_scale", C.c_double),
                 ("phen_mode", C.c_int), ("is_na", C.POINTER(C.c_ubyte)),
-                ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p)]
+                ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int)]
 
 
 def build(force=False):
@@ -72,6 +72,7 @@ def lib():
         L.gvo_cg_solve.argtypes = [up, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_int, dp, dp]
         L.gvo_pvals.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp]
+        L.gvo_people_stats.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp]
         L.gvo_student_t_two_sided.restype = C.c_double
         L.gvo_student_t_two_sided.argtypes = [C.c_double, C.c_double]
         L.gvo_sim_phen.argtypes = [up, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, C.c_int, dp, dp]
@@ -168,6 +169,17 @@ def pvals(bed, N, M, z1, y, x1_hat, chrom=None, mask4=None, nonas=None, nthreads
     return out
 
 
+def people_stats(bed, N, M, mask4=None, nonas=None):
+    """data::compute_people_statistics: (mave_people, msig_people, numb_people), each 4*ceil(N/4) long."""
+    bed = _u8(bed)
+    n4 = 4 * mbytes(N)
+    a, b, c = np.empty(n4), np.empty(n4), np.empty(n4)
+    m4 = _u8(mask4) if mask4 is not None else None
+    lib().gvo_people_stats(_up(bed), N, M, _up(m4) if m4 is not None else None, N if nonas is None else nonas,
+                           _dp(a), _dp(b), _dp(c))
+    return a, b, c
+
+
 def student_t_two_sided(t, nu):
     return lib().gvo_student_t_two_sided(t, nu)
 
@@ -221,7 +233,7 @@ class Run:
 def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterations=1, CG_max_iter=60,
            EM_max_iter=2, EM_err_thr=1e-2, stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1,
            use_lmmse_damp=0, gam1=1e-8, gamw=2.0, true_signal=None, out_prefix=None, verbose=0, nthreads=1,
-           alpha_scale=1.0, is_na=None, allreduce=None):
+           alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0):
     """vamp::infere (linear) on `nshards` marker shards.  `allreduce(np_array)` is an in-place SUM callback
     used when shard_rank >= 0 (one shard per process, e.g. torch.distributed gloo)."""
     bed_full, y = _u8(bed_full), _f64(y)
@@ -244,6 +256,7 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
         p.true_signal = _dp(ts)
     p.out_prefix = out_prefix.encode() if out_prefix else None
     p.verbose, p.nthreads, p.alpha_scale = verbose, nthreads, alpha_scale
+    p.use_XXT_denoiser = use_XXT_denoiser
     if is_na is not None:
         na = _u8(is_na)
         keep.append(na)
