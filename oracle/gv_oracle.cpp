@@ -786,6 +786,17 @@ std::vector<double> Vamp::infere() {
     std::vector<double> y = d->filter_pheno();
     r1 = std::vector<double>(M, 0.0);
     const int rank0 = (!comm || comm->rank == 0);
+    if (!o.r1_init.empty()) {            // restart (vamp.cpp:226-233): gam1 / gamw come from the options (ctor), and the
+        r1 = o.r1_init;                  // stored r1 / sqrt(N) is divided by sqrt(N) once more
+        for (int i = 0; i < M; i++) r1[i] /= sqrt(N);
+    }
+    const bool init_est = !o.x_init.empty();
+    if (init_est) {                      // vamp.cpp:244-258
+        std::vector<double> x_est = o.x_init;
+        for (size_t i0 = 0; i0 < x_est.size(); i0++) x_est[i0] *= sqrt((double)N);
+        x1_hat = x_est;
+        r1 = x_est;
+    }
 
     for (int it = 1; it <= o.iterations; it++) {
         double t_start = now_s();
@@ -798,6 +809,7 @@ std::vector<double> Vamp::infere() {
         int it_revar = 1;
         for (; it_revar <= auto_var_max_iter; it_revar++) {            // :289-338
             for (int i = 0; i < M; i++) x1_hat[i] = g1(r1[i], gam1);
+            if (it == 1 && init_est) x1_hat = r1;                          // :295-296
             std::vector<double> x1_hat_m_r1 = x1_hat;
             for (size_t i0 = 0; i0 < x1_hat_m_r1.size(); i0++) x1_hat_m_r1[i0] = x1_hat_m_r1[i0] - r1[i0];
             double sum_d = 0;

@@ -103,6 +103,8 @@ struct VampOpts {
     std::string out_prefix;               // "" = no files; else out_dir+out_name as in vamp.cpp:435
     int verbose = 0;
     int use_XXT_denoiser = 0;             // vamp.cpp:68,169-170,599-606: LMMSE via CG in N-space (denoiserXXT.cpp)
+    std::vector<double> r1_init;          // restart (vamp.cpp:226-233): local shard of the r1 file, non-empty = restart
+    std::vector<double> x_init;           // --init-est 1 (vamp.cpp:244-258): local shard of the estimate file
 };
 
 struct IterTrace {

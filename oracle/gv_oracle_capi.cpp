@@ -81,6 +81,8 @@ struct gvo_params {
     allreduce_cb_t cb;          // shard_rank >= 0 && nshards > 1
     void* cb_user;
     int use_XXT_denoiser;       // vamp.cpp:169-170, :599-606
+    const double* r1_init;      // Mt or NULL: restart (vamp.cpp:226-233)
+    const double* x_init;       // Mt or NULL: --init-est 1 (vamp.cpp:244-258)
 };
 
 struct gvo_run {
@@ -281,6 +283,8 @@ static void run_shard(const gvo_params* p, const unsigned char* bed_full, const 
     if (p->out_prefix) o.out_prefix = p->out_prefix;
     o.verbose = p->verbose;
     o.use_XXT_denoiser = p->use_XXT_denoiser;
+    if (p->r1_init) o.r1_init.assign(p->r1_init + S, p->r1_init + S + M);
+    if (p->x_init) o.x_init.assign(p->x_init + S, p->x_init + S + M);
     Vamp v(&d, o);
     std::vector<double> x = v.infere();
     std::lock_guard<std::mutex> lk(*mu);

@@ -28,7 +28,8 @@ class Params(C.Structure):
                 ("true_signal", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
                 ("verbose", C.c_int), ("nthreads", C.c_int), ("alpha_scale", C.c_double),
                 ("phen_mode", C.c_int), ("is_na", C.POINTER(C.c_ubyte)),
-                ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int)]
+                ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int),
+                ("r1_init", C.POINTER(C.c_double)), ("x_init", C.POINTER(C.c_double))]
 
 
 def build(force=False):
@@ -233,7 +234,7 @@ class Run:
 def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterations=1, CG_max_iter=60,
            EM_max_iter=2, EM_err_thr=1e-2, stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1,
            use_lmmse_damp=0, gam1=1e-8, gamw=2.0, true_signal=None, out_prefix=None, verbose=0, nthreads=1,
-           alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0):
+           alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0, r1_init=None, x_init=None):
     """vamp::infere (linear) on `nshards` marker shards.  `allreduce(np_array)` is an in-place SUM callback
     used when shard_rank >= 0 (one shard per process, e.g. torch.distributed gloo)."""
     bed_full, y = _u8(bed_full), _f64(y)
@@ -257,6 +258,14 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
     p.out_prefix = out_prefix.encode() if out_prefix else None
     p.verbose, p.nthreads, p.alpha_scale = verbose, nthreads, alpha_scale
     p.use_XXT_denoiser = use_XXT_denoiser
+    if r1_init is not None:
+        ri = _f64(r1_init)
+        keep.append(ri)
+        p.r1_init = _dp(ri)
+    if x_init is not None:
+        xi = _f64(x_init)
+        keep.append(xi)
+        p.x_init = _dp(xi)
     if is_na is not None:
         na = _u8(is_na)
         keep.append(na)

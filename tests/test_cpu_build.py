@@ -75,8 +75,8 @@ def test_cli_errors_before_device_work(built):
     r = subprocess.run([exe, "--bed-file"], capture_output=True, text=True)
     assert r.returncode != 0 and "missing argument" in r.stdout              # options.cpp:441-444
     exe2 = os.path.join(ROOT, "gvamp_amd", "gvamp_main_real")
-    r = subprocess.run([exe2, "--run-mode", "predict", "--bed-file", "x"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not built yet" in r.stdout
+    r = subprocess.run([exe2, "--run-mode", "nonsense", "--bed-file", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown --run-mode" in r.stdout
 
 
 def test_synth_bed_is_stable_and_plausible():
