@@ -757,6 +757,16 @@ int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, cons
     return read_scalars(c, 1 + 2 * (L - 1), sums);
 }
 
+// ---- probit: z-side denoiser of vamp::infere_bin_class (vamp_probit.cpp:335-352) -------------------------------------
+int gv_probit_denoise(gv_ctx* c, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
+                      double* sums2) {
+    NEED(c, p1->space == GV_SPACE_N && y->space == GV_SPACE_N && z1_out->space == GV_SPACE_N,
+         "gv_probit_denoise: N-space vectors required");
+    gvk::probit_denoise(c->stream, p1->d, y->d, c->N, c->npad, tau1, probit_var, z1_out->d, c->red_partial, c->red_out);
+    KCHK(c);
+    return read_scalars(c, 2, sums2);
+}
+
 // ---- --use-XXT-denoiser 1: LMMSE through CG in N-space (denoiserXXT.cpp), matrix-free ------------------------------
 // data::compute_people_statistics (data.cpp:558-716): three table passes of the fp64 Ax kernel over the raw rows.
 int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double* numb_people) {

@@ -53,8 +53,9 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     opt.set_solver(o->EM_max_iter, o->CG_max_iter, o->EM_err_thr, o->stop_criteria_thr, o->learn_vars,
                    (unsigned int)o->seed, o->use_lmmse_damp, o->diagnostics, (o->out_prefix && o->out_prefix[0]) ? 1 : 0);
     opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
+    opt.set_probit_var(o->probit_var);
     vamp vm(N, M, Mt, o->gam1, o->gamw, o->iterations, o->rho, vars, probs, ts, rank, "",
-            o->out_prefix ? o->out_prefix : "", "linear", opt);
+            o->out_prefix ? o->out_prefix : "", o->bin_class ? "bin_class" : "linear", opt);
     vm.set_verbose(o->verbose);
     vm.set_keep_history((x1_hist || x2_hist || r1_hist) ? 1 : 0);
     std::vector<double> x = vm.infere(&ds);
@@ -69,6 +70,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
         t.eta2 = s.eta2; t.gam2_reest = s.gam2_reest; t.gam1_next = s.gam1_next; t.gamw = s.gamw; t.rho = s.rho;
         t.R2_denoise = s.R2_denoise; t.R2_lmmse = s.R2_lmmse;
         t.cg_iters = s.cg_iters; t.onsager_iters = s.onsager_iters; t.revar_rounds = s.revar_rounds; t.L_after = s.L_after;
+        t.beta1 = s.beta1; t.tau2 = s.tau2; t.tau1_next = s.tau1_next;
         t.n_ax = s.n_ax; t.n_atx = s.n_atx; t.seconds = s.seconds; t.seconds_io = s.seconds_io;
     }
     auto dump = [&](const std::vector<std::vector<double>>& h, double* dst) {

@@ -41,6 +41,7 @@ void vamp::common_init(const Options& opt) {
     store_pvals = opt.get_store_pvals();   // the reference's ctor 1 leaves 1 here (vamp.hpp:53); --store-pvals is honoured
     diagnostics = opt.get_diagnostics();
     store_iterates = opt.get_store_iterates();
+    probit_var = opt.get_probit_var();
     nranks = gv_env_nranks();
     initialize_prior(this->probs, this->vars, N, Mt, rank);
 }
@@ -108,6 +109,13 @@ std::vector<double> vamp::infere(data* dataset) {
         ck(gv_people_stats(ctx, nullptr, nullptr, nullptr), "gv_people_stats (--use-XXT-denoiser needs --kernel-mode 0 or both layouts)");
     }
     if (!strcmp(model.c_str(), "linear")) return infere_linear(dataset);
+    if (!strcmp(model.c_str(), "bin_class")) {
+        if (C > 0) {
+            std::cout << "FATAL: --model bin_class with covariates (--C > 0) is not built yet" << std::endl;
+            exit(EXIT_FAILURE);
+        }
+        return infere_bin_class(dataset);
+    }
     throw "invalid model specification!";   // vamp.cpp:180 (bin_class / robust: SURVEY 8f)
 }
 
@@ -433,4 +441,149 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         store_vec_to_file(pre + "_R2trains.csv", R2trains);
     }
     return x1_hat_stored;   // x1_hat / sqrt(N) of the last iteration (:802)
+}
+
+// vamp::infere_bin_class (vamp_probit.cpp:20-658) without covariates (C == 0): generalised VAMP for y in {0, 1}.
+// Signal side shared with the linear model (gv_denoise, updatePrior, gv_cg_solve, g2d_onsager); the z side is
+// gv_probit_denoise over the N individuals.  probit_err_measures and the "true ..." prints of the reference are
+// diagnostics against a known signal and are not reproduced.
+std::vector<double> vamp::infere_bin_class(data* dataset) {
+    ctx = dataset->get_ctx();
+    S = dataset->get_S();
+    auto newM = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_M, v), "gv_vec_alloc"); };
+    auto newN = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_N, v), "gv_vec_alloc"); };
+    for (gv_vec** v : {&x1_hat, &x1_hat_prev, &x2_hat, &r1, &r2, &bern_vec, &invQ_bern_vec, &vM, &tM}) newM(v);
+    gv_vec *p1 = nullptr, *p2 = nullptr, *z1_hat = nullptr;
+    for (gv_vec** v : {&y, &tN, &tN2, &p1, &p2, &z1_hat}) newN(v);
+    {
+        std::vector<double> yh = dataset->get_phen();
+        yh.resize(N, 0.0);
+        ck(gv_set_phen(ctx, y, yh.data()), "gv_set_phen");
+        // p1 = simulate(N, {1}, {1}) with the default seed 1 (vamp_probit.cpp:52, utilities.hpp:23)
+        std::vector<double> p1h = simulate(N, std::vector<double>{1.0 / 1}, std::vector<double>{1}, 1);
+        p1h.resize(4 * dataset->get_mbytes(), 0.0);
+        ck(gv_vec_upload(ctx, p1, p1h.data()), "gv_vec_upload");
+    }
+    double tau1 = gam1, tau2 = 0;
+    alpha1 = 0;
+    const double sqrtN = sqrt((double)N);
+    const std::string pre = out_dir + out_name;
+    std::vector<double> x1_host(M > 0 ? M : 0, 0.0);
+
+    for (int it = 1; it <= max_iter; it++) {
+        const double t_start = now_s();
+        double t_io = 0;
+        gv_counters c0;
+        gv_get_counters(ctx, &c0);
+        vamp_iter_stats st;
+        memset(&st, 0, sizeof(st));
+        if (verbose && rank == 0)
+            std::cout << std::endl << "********************" << std::endl << "iteration = " << it << std::endl
+                      << "********************" << std::endl << "->DENOISING" << std::endl;
+        const double rho_it = 1;                                          // :71
+        ck(gv_vec_copy(ctx, x1_hat_prev, x1_hat), "gv_vec_copy");
+        const double alpha1_prev = alpha1;
+        int it_revar = 1;
+        for (; it_revar <= 50; it_revar++) {                              // :117-160
+            double sums[2];
+            ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, nullptr, sums), "gv_denoise");
+            ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");
+            alpha1 = sums[0] / Mt;
+            eta1 = gam1 / alpha1;
+            if (it <= 1) break;
+            const double prev = gam1;
+            gam1 = std::min(std::max(1 / (1 / eta1 + sums[1] / Mt), gamma_min), gamma_max);
+            if (verbose && rank == 0) std::cout << "it_revar = " << it_revar << ": gam1 = " << gam1 << std::endl;
+            updatePrior(0);
+            if (std::abs(gam1 - prev) < 1e-3) break;
+        }
+        st.gam1_denoise = gam1;
+        st.revar_rounds = std::max(it_revar - 1, 1);
+        if (it > 1) {                                                     // :197-203
+            ck(gv_vec_axpby(ctx, x1_hat, rho, x1_hat, 1 - rho, x1_hat_prev), "gv_vec_axpby");
+            alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
+        }
+        double t0 = now_s();
+        {   // :205-224
+            ck(gv_vec_download(ctx, x1_hat, x1_host.data()), "gv_vec_download");
+            std::vector<double> stored = x1_host;
+            for (double& v : stored) v /= sqrtN;
+            if (store_iterates) mpi_store_vec_to_file(pre + "_probit_it_" + std::to_string(it) + ".bin", stored, S, M);
+            if (keep_history) x1_hist.push_back(stored);
+        }
+        store_scaled(pre + "_probit_r1_it_" + std::to_string(it) + ".bin", r1, &r1_hist);
+        t_io += now_s() - t0;
+        if (verbose && rank == 0) std::cout << "alpha1 = " << alpha1 << std::endl;
+
+        gam_before = gam2;
+        gam2 = std::min(std::max(eta1 - gam1, gamma_min), gamma_max);    // :283
+        if (verbose && rank == 0) std::cout << "eta1 = " << eta1 << std::endl << "gam2 = " << gam2 << std::endl;
+        ck(gv_vec_axpby(ctx, r2, eta1 / gam2, x1_hat, -gam1 / gam2, r1), "gv_vec_axpby");   // :291-292
+        st.alpha1 = alpha1; st.eta1 = eta1; st.gam2 = gam2; st.rho = rho;
+
+        double zs[2];                                                     // :335-379 (one round)
+        ck(gv_probit_denoise(ctx, p1, y, tau1, probit_var, z1_hat, zs), "gv_probit_denoise");
+        const double beta1 = zs[0] / N;
+        if (verbose && rank == 0) std::cout << "beta1 = " << beta1 << std::endl;
+        const double zeta1 = tau1 / beta1;
+        if (it > 1) tau1 = std::min(std::max(1 / (1 / zeta1 + zs[1] / N), gamma_min), gamma_max);
+        ck(gv_vec_axpby(ctx, p2, 1.0 / (1 - beta1), z1_hat, -beta1 / (1 - beta1), p1), "gv_vec_axpby");   // :447-448
+        tau2 = tau1 * (1 - beta1) / beta1;                                // :460
+        st.beta1 = beta1;
+        if (verbose && rank == 0) std::cout << "tau2 = " << tau2 << std::endl << "probit_var = " << probit_var << std::endl;
+
+        if (verbose && rank == 0) std::cout << std::endl << "->LMMMSE" << std::endl;
+        ck(gv_atx_dev(ctx, p2, vM), "gv_atx_dev");                         // :492-495
+        ck(gv_vec_axpby(ctx, vM, tau2, vM, gam2, r2), "gv_vec_axpby");
+        cg(vM, nullptr, tau2, 1, x2_hat, &st.cg_iters);                    // :497 (always from zero)
+        store_scaled("", x2_hat, &x2_hist);
+        alpha2 = g2d_onsager(gam2, tau2, dataset, &st.onsager_iters);     // :512
+        st.alpha2 = alpha2;
+        if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
+        eta2 = gam2 / alpha2;
+        if (it > 1) {                                                     // :520-526
+            ck(gv_vec_axpby(ctx, tM, 1.0, x2_hat, -1.0, r2), "gv_vec_axpby");
+            gam2 = std::min(std::max(1 / (1 / eta2 + dotM(tM, tM) / Mt), gamma_min), gamma_max);
+        }
+        st.eta2 = eta2; st.gam2_reest = gam2;
+        if (verbose && rank == 0) std::cout << "gam2 after reest = " << gam2 << std::endl;
+        // r1 = rho_it (x2 - alpha2 r2) / (1 - alpha2) + (1 - rho_it) r1_prev, rho_it = 1 (:533-535)
+        ck(gv_vec_axpby(ctx, r1, rho_it / (1 - alpha2), x2_hat, -rho_it * alpha2 / (1 - alpha2), r2), "gv_vec_axpby");
+        gam1 = gam2 * (1 - alpha2) / alpha2;                              // :548-549
+        st.gam1_next = gam1;
+        if (verbose && rank == 0) std::cout << "gam1 = " << gam1 << std::endl;
+        ck(gv_ax_dev(ctx, x2_hat, tN), "gv_ax_dev");                       // z2_hat (:555)
+        const double beta2 = (double)Mt / N * (1 - alpha2);               // :561
+        const double zeta2 = tau2 / beta2;
+        if (it > 1) {                                                     // :565-574
+            ck(gv_vec_axpby(ctx, tN2, 1.0, tN, -1.0, p2), "gv_vec_axpby");
+            tau2 = 1.0 / (1.0 / zeta2 + dotN(tN2, tN2) / N);
+        }
+        if (verbose && rank == 0) std::cout << "beta2 = " << beta2 << std::endl << "tau2 after reest = " << tau2 << std::endl;
+        ck(gv_vec_axpby(ctx, p1, rho_it / (1 - beta2), tN, -rho_it * beta2 / (1 - beta2), p2), "gv_vec_axpby");   // :579-581
+        tau1 = tau2 * (1 - beta2) / beta2;                                // :594-595
+        st.tau2 = tau2; st.tau1_next = tau1;
+        if (verbose && rank == 0) std::cout << "tau1 = " << tau1 << std::endl;
+
+        st.L_after = (int)probs.size();
+        gv_counters c1;
+        gv_get_counters(ctx, &c1);
+        st.n_ax = (long)(c1.n_ax - c0.n_ax);
+        st.n_atx = (long)(c1.n_atx - c0.n_atx);
+        ck(gv_vec_axpby(ctx, tM, 1.0, x1_hat_prev, -1.0, x1_hat), "gv_vec_axpby");   // :624-640
+        const gv_vec* xs[2] = {tM, x1_hat_prev};
+        const gv_vec* ys[2] = {tM, x1_hat_prev};
+        double d2[2];
+        ck(gv_vec_dots(ctx, 2, xs, ys, 1, d2), "gv_vec_dots");
+        st.seconds_io = t_io;
+        st.seconds = now_s() - t_start - t_io;
+        stats.push_back(st);
+        if (it > 1 && sqrt(d2[0] / d2[1]) < stop_criteria_thr) {
+            if (verbose && rank == 0)
+                std::cout << "probitVAMP stopping criteria fulfilled with threshold = " << stop_criteria_thr << "." << std::endl;
+            break;
+        }
+    }
+    for (gv_vec* v : {p1, p2, z1_hat}) gv_vec_free(ctx, v);
+    return x1_host;   // unscaled x1_hat (:657)
 }

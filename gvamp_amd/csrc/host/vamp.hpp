@@ -13,6 +13,7 @@ struct vamp_iter_stats {     // one row per VAMP iteration (what the reference p
     double gam1_denoise, alpha1, eta1, gam2, alpha2, eta2, gam2_reest, gam1_next, gamw, rho, R2_denoise, R2_lmmse;
     int cg_iters, onsager_iters, revar_rounds, L_after;
     long n_ax, n_atx;
+    double beta1, tau2, tau1_next;   // bin_class only
     double seconds, seconds_io;
 };
 
@@ -34,6 +35,7 @@ private:
     double gam1_init = -1, gamw_init = 0;
     std::string r1_init_file, estimate_file;
     int diagnostics = 0, store_iterates = 1, verbose = 1;
+    double probit_var = 1;   // options.hpp:124
 
     // device state (allocated in infere_linear)
     gv_ctx* ctx = nullptr;
@@ -61,6 +63,7 @@ public:
 
     std::vector<double> infere(data* dataset);           // vamp.cpp:149-183
     std::vector<double> infere_linear(data* dataset);    // vamp.cpp:190-803
+    std::vector<double> infere_bin_class(data* dataset); // vamp_probit.cpp:20-658 (no covariates)
     double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
     void updatePrior(int verbose);                       // vamp.cpp:929-1072
     void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)

@@ -118,6 +118,12 @@ int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, 
  * sums[2+2j] = sum_i beta_ij (m_ij^2 + v_j) pi_i for j = 0..L-2 (local sums; caller all-reduces 1+2(L-1)). */
 int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
                    const double* vars, int L, double* sums);
+/* ---- --model bin_class (vamp_probit.cpp): the z-side probit denoiser over the N individuals ------------------------
+ * vamp::g1_bin_class / g1d_bin_class (vamp_probit.cpp:661-705; loops :335-352), no covariates: z1 = E[z | y, cavity
+ * N(p1, 1/tau1)], sums2[0] = sum_n g1d_bin_class, sums2[1] = sum_n (z1 - p1)^2.  y holds 0 / 1 (N-space handle). */
+int gv_probit_denoise(gv_ctx* ctx, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
+                      double* sums2);
+
 /* ---- --use-XXT-denoiser 1 (vamp.cpp:169-170, :599-606; denoiserXXT.cpp): LMMSE through CG in N-space, matrix-free --
  * data::compute_people_statistics (data.cpp:558-716): per-individual mean, inverse std and count of the standardised
  * genotypes, all-reduced over ranks; kept on the device for gv_cg_solve_aat.  Host copies (4*mbytes doubles each) are

@@ -135,21 +135,6 @@ static double betacf(double a, double b, double x) {
     }
     return h;
 }
-static double betai(double a, double b, double x) {
-    if (!(x > 0)) return 0;
-    if (!(x < 1)) return 1;
-    // ln B(a,b)^-1: for b = 1/2 and large a (a = nu/2 of the t-test) lgamma(a + 1/2) - lgamma(a) cancels ~10 digits;
-    // use its asymptotic series (DLMF 5.11.13) there instead
-    double lg_ratio;
-    if (b == 0.5 && a >= 30.0) {
-        const double ia = 1 / a, ia2 = ia * ia;
-        lg_ratio = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
-    } else
-        lg_ratio = lgamma(a + b) - lgamma(a) - lgamma(b);
-    double bt = exp(lg_ratio + a * log(x) + b * log1p(-x));
-    if (x < (a + 1) / (a + b + 2)) return bt * betacf(a, b, x) / a;
-    return 1 - bt * betacf(b, a, 1 - x) / b;
-}
 double student_t_two_sided(double t, double nu) {
     if (std::isnan(t) || !(nu > 0)) return NAN;
     if (t == 0) return 1.0;
@@ -448,6 +433,7 @@ std::vector<double> Data::pvals_calc_LOCO(const std::vector<double>& z1, const s
 // ================================ vamp.cpp ======================================================
 
 static const double gamma_min = 1e-11, gamma_max = 1e11;   // vamp.hpp:31-32
+static void store_bin(const std::string& path, const std::vector<double>& v, int S);
 static const int auto_var_max_iter = 5;                    // vamp.hpp:37
 
 // vamp.cpp:32-82 (ctor 1) / :89-139 (ctor 2): state initialisation; initialize_prior at :78/:136.
@@ -646,6 +632,166 @@ std::vector<double> Vamp::precondCG_solver(const std::vector<double>& v, const s
     return mu;
 }
 
+// exp(x^2) erfc(x).  |x| < 25: libm erfc and exp are both accurate to an ulp or two and neither under/overflows;
+// beyond: asymptotic series 1/(x sqrt(pi)) * sum_k (-1)^k (2k-1)!! / (2x^2)^k, whose terms fall below 1e-17 within 12 terms.
+double erfcx(double x) {
+    if (std::isnan(x)) return x;
+    const double a = fabs(x);
+    double r;
+    if (a < 25.0)
+        r = exp(a * a) * erfc(a);
+    else {
+        const double inv2 = 1.0 / (2.0 * a * a);
+        double term = 1.0, sum = 1.0;
+        for (int k = 1; k <= 12; k++) {
+            term *= -(2.0 * k - 1.0) * inv2;
+            sum += term;
+        }
+        r = sum / (a * sqrt(M_PI));
+    }
+    if (x < 0) {
+        const double e = exp(a * a);
+        r = std::isinf(e) ? e : 2.0 * e - r;
+    }
+    return r;
+}
+
+// vamp_probit.cpp:661-687 -- posterior mean of z given the probit likelihood and the cavity N(p, 1/tau1)
+double Vamp::g1_bin_class(double p, double tau1, double y, double m_cov) const {
+    double c = (p + m_cov) / sqrt(o.probit_var + 1.0 / tau1);
+    double normalPdf_normalCdf = 2.0 / sqrt(2 * M_PI) / erfcx(-(2 * y - 1) * c / sqrt(2));
+    return p + (2 * y - 1) * normalPdf_normalCdf / tau1 / sqrt(o.probit_var + 1.0 / tau1);
+}
+// vamp_probit.cpp:689-705
+double Vamp::g1d_bin_class(double p, double tau1, double y, double m_cov) const {
+    double c = (p + m_cov) / sqrt(o.probit_var + 1.0 / tau1);
+    double Nc_phiyc = 2.0 / sqrt(2 * M_PI) / erfcx(-(2 * y - 1) * c / sqrt(2));
+    return 1 - Nc_phiyc / (1 + tau1 * o.probit_var) * ((2 * y - 1) * c + Nc_phiyc);
+}
+
+// vamp_probit.cpp:20-658 with C == 0 (no covariates): generalised VAMP for y in {0,1}.  The signal side (g1/g1d,
+// updatePrior, CG, Onsager probe) is shared with the linear model; the z side adds the probit denoiser over N.
+// Diagnostics against the true signal (probit_err_measures, "true gam" prints) are not restated: they only print.
+std::vector<double> Vamp::infere_bin_class() {
+    double tau1 = gam1, tau2 = 0;
+    double sqrtN = sqrt(N);
+    std::vector<double> x1_hat_prev(M, 0.0);
+    std::vector<double> p1 = simulate(N, std::vector<double>{1.0 / 1}, std::vector<double>{1}, 1);   // :52, default seed 1
+    r1 = std::vector<double>(M, 0.0);
+    r2 = r1;
+    alpha1 = 0;
+    std::vector<double> z1_hat(N, 0.0), p2(4 * d->mbytes, 0.0), z2_hat;
+    const int rank0 = (!comm || comm->rank == 0);
+    for (int it = 1; it <= o.iterations; it++) {
+        double t_start = now_s();
+        long ax0 = d->n_ax, atx0 = d->n_atx;
+        IterTrace tr;
+        memset(&tr, 0, sizeof(tr));
+        double rho_it = 1;                                               // :71 (overrides :66-70)
+        x1_hat_prev = x1_hat;
+        double rho_it2 = o.rho, alpha1_prev = alpha1, gam1_reEst_prev;
+        int it_revar = 1;
+        for (; it_revar <= 50; it_revar++) {                            // :117-160 (auto_var_max_iter = 50)
+            for (int i = 0; i < M; i++) x1_hat[i] = g1(r1[i], gam1);
+            std::vector<double> x1_hat_m_r1 = x1_hat;
+            for (int i0 = 0; i0 < M; i0++) x1_hat_m_r1[i0] -= r1[i0];
+            double sum_d = 0;
+            for (int i = 0; i < M; i++) sum_d += g1d(r1[i], gam1);
+            alpha1 = sum_d;
+            if (comm) comm->allreduce_sum(&alpha1, 1);
+            alpha1 /= Mt;
+            eta1 = gam1 / alpha1;
+            if (it <= 1) break;
+            gam1_reEst_prev = gam1;
+            gam1 = std::min(std::max(1 / (1 / eta1 + l2_norm2(x1_hat_m_r1, 1, comm) / Mt), gamma_min), gamma_max);
+            updatePrior(0);
+            if (std::abs(gam1 - gam1_reEst_prev) < 1e-3) break;
+        }
+        tr.gam1_denoise = gam1;
+        tr.revar_rounds = std::max(it_revar - 1, 1);
+        if (it > 1) {                                                   // :197-203
+            for (int i = 0; i < M; i++) x1_hat[i] = rho_it2 * x1_hat[i] + (1 - rho_it2) * x1_hat_prev[i];
+            alpha1 = rho_it2 * alpha1 + (1 - rho_it2) * alpha1_prev;
+        }
+        {   // :205-224: _probit_it_<it>.bin, _probit_r1_it_<it>.bin hold x1_hat / sqrt(N), r1 / sqrt(N)
+            std::vector<double> xs = x1_hat, rs = r1;
+            for (double& v : xs) v /= sqrtN;
+            for (double& v : rs) v /= sqrtN;
+            x1_hist.push_back(xs);
+            r1_hist.push_back(rs);
+            if (!o.out_prefix.empty()) {
+                store_bin(o.out_prefix + "_probit_it_" + std::to_string(it) + ".bin", xs, d->S);
+                store_bin(o.out_prefix + "_probit_r1_it_" + std::to_string(it) + ".bin", rs, d->S);
+            }
+        }
+        gam_before = gam2;
+        gam2 = std::min(std::max(eta1 - gam1, gamma_min), gamma_max);   // :283
+        for (int i = 0; i < M; i++) r2[i] = (eta1 * x1_hat[i] - gam1 * r1[i]) / gam2;
+        tr.alpha1 = alpha1; tr.eta1 = eta1; tr.gam2 = gam2;
+        std::vector<double> y = d->filter_pheno();
+        double beta1 = 0;
+        {   // :335-379, auto_var_max_iter = 1: one round
+            for (int i = 0; i < N; i++) z1_hat[i] = g1_bin_class(p1[i], tau1, y[i], 0);
+            std::vector<double> z1_hat_m_p1 = z1_hat;
+            for (int i0 = 0; i0 < N; i0++) z1_hat_m_p1[i0] -= p1[i0];
+            for (int i = 0; i < N; i++) beta1 += g1d_bin_class(p1[i], tau1, y[i], 0);
+            beta1 /= N;
+            double zeta1 = tau1 / beta1;
+            if (it > 1) tau1 = std::min(std::max(1 / (1 / zeta1 + l2_norm2(z1_hat_m_p1, 0, comm) / N), gamma_min), gamma_max);
+        }
+        for (int i = 0; i < N; i++) p2[i] = (z1_hat[i] - beta1 * p1[i]) / (1 - beta1);      // :447-448
+        tau2 = tau1 * (1 - beta1) / beta1;                              // :460
+        tr.beta1 = beta1;
+        if (o.verbose && rank0) printf("beta1 = %.10g\ntau2 = %.10g\n", beta1, tau2);
+        std::vector<double> v = d->ATx(p2.data());                       // :492-497
+        for (int i = 0; i < M; i++) v[i] = tau2 * v[i] + gam2 * r2[i];
+        x2_hat = precondCG_solver(v, std::vector<double>(M, 0.0), tau2, 1);
+        tr.cg_iters = last_cg_iters;
+        {
+            std::vector<double> xs = x2_hat;
+            for (double& u : xs) u /= sqrtN;
+            x2_hist.push_back(xs);
+        }
+        double alpha2_ = g2d_onsager(gam2, tau2);                        // :512
+        tr.onsager_iters = last_cg_iters;
+        tr.alpha2 = alpha2_;
+        eta2 = gam2 / alpha2_;
+        std::vector<double> x2_hat_m_r2 = x2_hat;
+        for (int i0 = 0; i0 < M; i0++) x2_hat_m_r2[i0] -= r2[i0];
+        if (it > 1) gam2 = std::min(std::max(1 / (1 / eta2 + l2_norm2(x2_hat_m_r2, 1, comm) / Mt), gamma_min), gamma_max);
+        tr.eta2 = eta2; tr.gam2_reest = gam2;
+        std::vector<double> r1_prev = r1;
+        for (int i = 0; i < M; i++) r1[i] = rho_it * (x2_hat[i] - alpha2_ * r2[i]) / (1 - alpha2_) + (1 - rho_it) * r1_prev[i];
+        double gam1_prev = gam1;
+        gam1 = gam2 * (1 - alpha2_) / alpha2_;                           // :548-549
+        gam1 = rho_it * gam1 + (1 - rho_it) * gam1_prev;
+        tr.gam1_next = gam1;
+        z2_hat = d->Ax(x2_hat.data());                                   // :555
+        double beta2 = (double)Mt / N * (1 - alpha2_);                   // :561
+        std::vector<double> z2_hat_m_p2 = z2_hat;
+        for (int i0 = 0; i0 < N; i0++) z2_hat_m_p2[i0] -= p2[i0];
+        z2_hat_m_p2.resize(N);
+        double zeta2 = tau2 / beta2;
+        if (it > 1) tau2 = 1.0 / (1.0 / zeta2 + l2_norm2(z2_hat_m_p2, 0, comm) / N);   // :573-574
+        std::vector<double> p1_prev = p1;
+        for (int i = 0; i < N; i++) p1[i] = rho_it * (z2_hat[i] - beta2 * p2[i]) / (1 - beta2) + (1 - rho_it) * p1_prev[i];
+        double tau1_prev = tau1;
+        tau1 = tau2 * (1 - beta2) / beta2;                               // :594-595
+        tau1 = rho_it * tau1 + (1 - rho_it) * tau1_prev;
+        tr.tau2 = tau2; tr.tau1_next = tau1;
+        tr.L_after = (int)probs.size();
+        tr.n_ax = d->n_ax - ax0;
+        tr.n_atx = d->n_atx - atx0;
+        tr.seconds = now_s() - t_start;
+        trace.push_back(tr);
+        std::vector<double> x1_hat_diff(M, 0.0);
+        for (int i0 = 0; i0 < M; i0++) x1_hat_diff[i0] = x1_hat_prev[i0] - x1_hat[i0];
+        double rel_err_x1 = sqrt(l2_norm2(x1_hat_diff, 1, comm) / l2_norm2(x1_hat_prev, 1, comm));
+        if (it > 1 && rel_err_x1 < o.stop_criteria_thr) break;           // :636-640
+    }
+    return x1_hat;                                                        // unscaled (:657)
+}
+
 // denoiserXXT.cpp:15-35: (tau A A^T + gam2 I) u, matrix-free (ATx then Ax)
 std::vector<double> Vamp::lmmse_multAAT(const std::vector<double>& u, double tau) {
     size_t phen_size = 4 * d->mbytes;
@@ -779,6 +925,7 @@ std::vector<double> Vamp::infere() {
     y = d->phen;
     for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;
     if (o.use_XXT_denoiser == 1) d->compute_people_statistics();        // vamp.cpp:169-170
+    if (o.bin_class) return infere_bin_class();                         // vamp.cpp:175-176
 
     std::vector<double> x1_hat_d(M, 0.0), x1_hat_stored(M, 0.0), x1_hat_prev(M, 0.0);
     alpha1 = 0;

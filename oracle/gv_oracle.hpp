@@ -54,6 +54,10 @@ double calc_stdev(const std::vector<double>& v);                                
 // function from Boost (absent here); restated with the regularised incomplete beta function (published algorithm:
 // P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2), continued fraction of Numerical Recipes 6.4 / DLMF 8.17.22).
 double student_t_two_sided(double t, double nu);
+// utilities.cpp:345-409 -- scaled complementary error function exp(x^2) erfc(x).  Restated from its definition
+// (libm erfc / exp where they are accurate, the asymptotic series beyond, the reflection 2 exp(x^2) - erfcx(-x) for x < 0)
+// instead of the reference's polynomial.
+double erfcx(double x);
 double linear_reg1d_pvals(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, int n);
 
 // ---- class data (data.hpp:93-140) --------------------------------------------------------------
@@ -103,6 +107,8 @@ struct VampOpts {
     std::string out_prefix;               // "" = no files; else out_dir+out_name as in vamp.cpp:435
     int verbose = 0;
     int use_XXT_denoiser = 0;             // vamp.cpp:68,169-170,599-606: LMMSE via CG in N-space (denoiserXXT.cpp)
+    int bin_class = 0;                    // --model bin_class: vamp::infere_bin_class (vamp_probit.cpp:20-658), C = 0
+    double probit_var = 1.0;              // options.hpp:124
     std::vector<double> r1_init;          // restart (vamp.cpp:226-233): local shard of the r1 file, non-empty = restart
     std::vector<double> x_init;           // --init-est 1 (vamp.cpp:244-258): local shard of the estimate file
 };
@@ -112,6 +118,7 @@ struct IterTrace {
     int cg_iters, onsager_iters, revar_rounds, L_after;
     long n_ax, n_atx;
     double seconds;
+    double beta1, tau2, tau1_next;   // bin_class only (vamp_probit.cpp:361-372, :460, :579-581)
 };
 
 struct Vamp {
@@ -136,6 +143,9 @@ struct Vamp {
     std::vector<double> precondCG_solver(const std::vector<double>& v, const std::vector<double>& mu_start,
                                          double tau, int denoiser);                        // :1130-1229
     double g2d_onsager(double gam2, double tau);                   // :871-889
+    double g1_bin_class(double p, double tau1, double y, double m_cov) const;              // vamp_probit.cpp:661-687
+    double g1d_bin_class(double p, double tau1, double y, double m_cov) const;             // vamp_probit.cpp:689-705
+    std::vector<double> infere_bin_class();                                                // vamp_probit.cpp:20-658 (C = 0)
     std::vector<double> lmmse_multAAT(const std::vector<double>& u, double tau);            // denoiserXXT.cpp:15-35
     std::vector<double> CG_solverAAT(const std::vector<double>& v, const std::vector<double>& mu_start, double tau,
                                      int save);                                            // denoiserXXT.cpp:52-130

@@ -83,6 +83,8 @@ struct gvo_params {
     int use_XXT_denoiser;       // vamp.cpp:169-170, :599-606
     const double* r1_init;      // Mt or NULL: restart (vamp.cpp:226-233)
     const double* x_init;       // Mt or NULL: --init-est 1 (vamp.cpp:244-258)
+    int bin_class;              // --model bin_class (vamp_probit.cpp), C = 0
+    double probit_var;
 };
 
 struct gvo_run {
@@ -285,6 +287,8 @@ static void run_shard(const gvo_params* p, const unsigned char* bed_full, const 
     o.use_XXT_denoiser = p->use_XXT_denoiser;
     if (p->r1_init) o.r1_init.assign(p->r1_init + S, p->r1_init + S + M);
     if (p->x_init) o.x_init.assign(p->x_init + S, p->x_init + S + M);
+    o.bin_class = p->bin_class;
+    o.probit_var = p->probit_var;
     Vamp v(&d, o);
     std::vector<double> x = v.infere();
     std::lock_guard<std::mutex> lk(*mu);
@@ -361,6 +365,27 @@ void gvo_run_trace(const gvo_run* r, int it, double* out16) {
     memcpy(out16, v, sizeof(v));
 }
 double gvo_run_seconds(const gvo_run* r, int it) { return r->trace[it].seconds; }
+// bin_class extras: beta1, tau2 (after re-estimation), tau1 entering the next iteration
+void gvo_run_trace_probit(const gvo_run* r, int it, double* out3) {
+    out3[0] = r->trace[it].beta1;
+    out3[1] = r->trace[it].tau2;
+    out3[2] = r->trace[it].tau1_next;
+}
+// vamp::g1_bin_class / g1d_bin_class on a grid (y in {0,1}), and erfcx
+void gvo_probit_g(const double* p, const double* y, long n, double tau1, double probit_var, double* g, double* gd) {
+    Data d;
+    d.N = 4; d.M = 1; d.Mt = 1;
+    VampOpts o;
+    o.probs = {1.0};
+    o.vars = {0.0};
+    o.probit_var = probit_var;
+    Vamp v(&d, o);
+    for (long i = 0; i < n; i++) {
+        g[i] = v.g1_bin_class(p[i], tau1, y[i], 0);
+        gd[i] = v.g1d_bin_class(p[i], tau1, y[i], 0);
+    }
+}
+double gvo_erfcx(double x) { return erfcx(x); }
 int gvo_run_R2trains(const gvo_run* r, double* out, int cap) {
     for (int i = 0; i < (int)r->R2trains.size() && i < cap; i++) out[i] = r->R2trains[i];
     return (int)r->R2trains.size();

@@ -29,7 +29,8 @@ class Params(C.Structure):
                 ("verbose", C.c_int), ("nthreads", C.c_int), ("alpha_scale", C.c_double),
                 ("phen_mode", C.c_int), ("is_na", C.POINTER(C.c_ubyte)),
                 ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int),
-                ("r1_init", C.POINTER(C.c_double)), ("x_init", C.POINTER(C.c_double))]
+                ("r1_init", C.POINTER(C.c_double)), ("x_init", C.POINTER(C.c_double)),
+                ("bin_class", C.c_int), ("probit_var", C.c_double)]
 
 
 def build(force=False):
@@ -74,6 +75,10 @@ def lib():
                                    C.c_int, dp, dp]
         L.gvo_pvals.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp]
         L.gvo_people_stats.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp]
+        L.gvo_run_trace_probit.argtypes = [C.c_void_p, C.c_int, dp]
+        L.gvo_probit_g.argtypes = [dp, dp, C.c_long, C.c_double, C.c_double, dp, dp]
+        L.gvo_erfcx.restype = C.c_double
+        L.gvo_erfcx.argtypes = [C.c_double]
         L.gvo_student_t_two_sided.restype = C.c_double
         L.gvo_student_t_two_sided.argtypes = [C.c_double, C.c_double]
         L.gvo_sim_phen.argtypes = [up, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, C.c_int, dp, dp]
@@ -170,6 +175,18 @@ def pvals(bed, N, M, z1, y, x1_hat, chrom=None, mask4=None, nonas=None, nthreads
     return out
 
 
+def probit_g(p, y, tau1, probit_var=1.0):
+    """vamp::g1_bin_class / g1d_bin_class (vamp_probit.cpp:661-705) element-wise, m_cov = 0."""
+    p, y = _f64(p), _f64(y)
+    g, gd = np.empty(p.size), np.empty(p.size)
+    lib().gvo_probit_g(_dp(p), _dp(y), p.size, tau1, probit_var, _dp(g), _dp(gd))
+    return g, gd
+
+
+def erfcx(x):
+    return lib().gvo_erfcx(float(x))
+
+
 def people_stats(bed, N, M, mask4=None, nonas=None):
     """data::compute_people_statistics: (mave_people, msig_people, numb_people), each 4*ceil(N/4) long."""
     bed = _u8(bed)
@@ -217,6 +234,9 @@ class Run:
             L.gvo_run_trace(h, i, _dp(buf))
             t = dict(zip(TRACE_FIELDS, buf.tolist()))
             t["seconds"] = L.gvo_run_seconds(h, i)
+            b3 = np.empty(3)
+            L.gvo_run_trace_probit(h, i, _dp(b3))
+            t["beta1"], t["tau2"], t["tau1_next"] = b3.tolist()
             self.trace.append(t)
         nl = L.gvo_run_L(h)
         self.probs = np.ctypeslib.as_array(L.gvo_run_probs(h), (nl,)).copy()
@@ -234,7 +254,8 @@ class Run:
 def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterations=1, CG_max_iter=60,
            EM_max_iter=2, EM_err_thr=1e-2, stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1,
            use_lmmse_damp=0, gam1=1e-8, gamw=2.0, true_signal=None, out_prefix=None, verbose=0, nthreads=1,
-           alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0, r1_init=None, x_init=None):
+           alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0, r1_init=None, x_init=None,
+           model="linear", probit_var=1.0):
     """vamp::infere (linear) on `nshards` marker shards.  `allreduce(np_array)` is an in-place SUM callback
     used when shard_rank >= 0 (one shard per process, e.g. torch.distributed gloo)."""
     bed_full, y = _u8(bed_full), _f64(y)
@@ -258,6 +279,7 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
     p.out_prefix = out_prefix.encode() if out_prefix else None
     p.verbose, p.nthreads, p.alpha_scale = verbose, nthreads, alpha_scale
     p.use_XXT_denoiser = use_XXT_denoiser
+    p.bin_class, p.probit_var = int(model == "bin_class"), probit_var
     if r1_init is not None:
         ri = _f64(r1_init)
         keep.append(ri)

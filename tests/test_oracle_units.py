@@ -132,3 +132,23 @@ def test_pvals_loo_against_scipy_linregress(oracle):
         ymark = (y[:N] - z1[:N]) + A[:, k] / np.sqrt(N) * x1[k]
         ref = ss.linregress(A[keep, k], ymark[keep]).pvalue
         assert np.isclose(pv[k], ref, rtol=1e-8)
+
+
+def test_erfcx_and_probit_denoiser(oracle):
+    from scipy.special import erfcx as s_erfcx
+    from scipy.stats import norm
+    for x in (-20.0, -3.0, -0.2, 0.0, 0.7, 5.0, 24.99, 25.01, 300.0, 1e6):
+        assert np.isclose(oracle.erfcx(x), s_erfcx(x), rtol=1e-13)
+    # g1_bin_class = posterior mean of z ~ N(p, 1/tau) given y = 1{z + N(0, probit_var) > 0} (vamp_probit.cpp:661-687)
+    p, tau, pv = np.array([-1.2, 0.0, 0.4, 2.5]), 0.8, 1.0
+    for yv in (0.0, 1.0):
+        g, gd = oracle.probit_g(p, np.full(4, yv), tau, pv)
+        s = np.sqrt(pv + 1 / tau)
+        sgn = 2 * yv - 1
+        c = p / s
+        ref = p + sgn * norm.pdf(c) / norm.cdf(sgn * c) / tau / s
+        assert np.allclose(g, ref, rtol=1e-12)
+        h = 1e-5                                                       # g1d = d g1 / dp
+        gp, _ = oracle.probit_g(p + h, np.full(4, yv), tau, pv)
+        gm, _ = oracle.probit_g(p - h, np.full(4, yv), tau, pv)
+        assert np.allclose(gd, (gp - gm) / (2 * h), rtol=1e-6)
