@@ -232,10 +232,13 @@ def main():
             "iters_per_s": round(len(tail) / tot, 4) if tot > 0 else None,
             "seconds_per_iter": [round(t["seconds"], 4) for t in its], "wall_s_all_iterations": round(t_total, 3),
             "n_ax": [t["n_ax"] for t in its], "n_atx": [t["n_atx"] for t in its],
+            "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
             "cg_iters": [t["cg_iters"] for t in its], "onsager_iters": [t["onsager_iters"] for t in its],
             "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "L_after": [t["L_after"] for t in its],
             "config": "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, "
-                      "%d iterations; iters/s over iterations 2.., file output off" % (CV, a.CG_max_iter, len(its)),
+                      "%d iterations; iters/s over iterations 2.., file output off; n_ax / n_atx = vector products, "
+                      "n_*_pass = passes over the genotype shard (the LMMSE and the Onsager CG share passes)"
+                      % (CV, a.CG_max_iter, len(its)),
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)

@@ -19,7 +19,7 @@ EXPORTS = [
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
-    "gv_ax_dev", "gv_atx_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_denoise", "gv_prior_estep",
+    "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
 ]
@@ -37,7 +37,8 @@ class CgStats(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_ax", C.c_int64), ("n_atx", C.c_int64), ("ms_ax", C.c_double), ("ms_atx", C.c_double),
                 ("ms_allreduce", C.c_double), ("n_ax_kernel", C.c_int64), ("n_atx_kernel", C.c_int64),
-                ("ms_ax_kernel", C.c_double), ("ms_atx_kernel", C.c_double)]
+                ("ms_ax_kernel", C.c_double), ("ms_atx_kernel", C.c_double), ("n_ax_pass", C.c_int64),
+                ("n_atx_pass", C.c_int64)]
 
 
 def load():
@@ -85,6 +86,10 @@ def load():
     L.gv_vec_dots.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, dp]
     L.gv_ax_dev.argtypes = [vp, vp, vp]
     L.gv_atx_dev.argtypes = [vp, vp, vp]
+    L.gv_ax2_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.gv_atx2_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.gv_cg_solve2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
+                               C.POINTER(CgStats), dp, dp]
     L.gv_set_phen.argtypes = [vp, vp, dp]
     L.gv_lmmse_mult.argtypes = [vp, vp, C.c_double, C.c_double, vp]
     L.gv_cg_solve.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.POINTER(CgStats), dp]
@@ -291,6 +296,20 @@ class Shard:
                                     max_iter, mu_out.h, C.byref(st), _dp(rr)))
         return st, rr[:st.n_relres].copy()
 
+    def ax2_dev(self, xa, xb, outa, outb):
+        self._ck(self.L.gv_ax2_dev(self.h, xa.h, xb.h, outa.h, outb.h))
+
+    def atx2_dev(self, pa, pb, outa, outb):
+        self._ck(self.L.gv_atx2_dev(self.h, pa.h, pb.h, outa.h, outb.h))
+
+    def cg_solve2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b):
+        """LMMSE solve (a) and Onsager probe solve (b) in lock-step; returns ((stats_a, relres_a), (stats_b, relres_b))."""
+        sa, sb = CgStats(), CgStats()
+        ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
+        self._ck(self.L.gv_cg_solve2(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
+                                     max_iter, mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb)))
+        return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
+
     def denoise(self, r1, gam1, probs, vars_scaled, x1_out, d_out=None):
         probs = np.ascontiguousarray(probs, dtype=np.float64)
         vs = np.ascontiguousarray(vars_scaled, dtype=np.float64)
@@ -359,7 +378,7 @@ class Shard:
             self._ck(self.L.gv_reset_counters(self.h))
         return dict(n_ax=c.n_ax, n_atx=c.n_atx, ms_ax=c.ms_ax, ms_atx=c.ms_atx, ms_allreduce=c.ms_allreduce,
                     n_ax_kernel=c.n_ax_kernel, n_atx_kernel=c.n_atx_kernel, ms_ax_kernel=c.ms_ax_kernel,
-                    ms_atx_kernel=c.ms_atx_kernel)
+                    ms_atx_kernel=c.ms_atx_kernel, n_ax_pass=c.n_ax_pass, n_atx_pass=c.n_atx_pass)
 
     def synchronize(self):
         self._ck(self.L.gv_synchronize(self.h))

@@ -219,6 +219,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
         t.stop();
     }
     c->cnt.n_ax++;
+    c->cnt.n_ax_pass++;
     if (multi) {   // data.cpp:995 MPI_Allreduce, then the 1/sqrt(N) of :998-1005
         Timer t(c, &c->cnt.ms_allreduce);
         if (comm_allreduce(c, out, c->npad)) return 1;
@@ -249,6 +250,56 @@ int atx_device(gv_ctx* c, const double* p, double* out) {
     KCHK(c);
     t.stop();
     c->cnt.n_atx++;
+    c->cnt.n_atx_pass++;
+    return 0;
+}
+
+// two-vector forms: ONE pass over the shard in kernel mode 1, two single passes otherwise
+int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb) {
+    if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
+        if (ax_device(c, xa, outa)) return 1;
+        return ax_device(c, xb, outb);
+    }
+    NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
+    const double scale = 1.0 / sqrt((double)c->N);
+    const bool multi = is_multi(c);
+    {
+        Timer t(c, &c->cnt.ms_ax);
+        gv_ctx::EvRec* er = ev_next(c, 0);
+        c->plan.ev0 = er ? er->a : nullptr;
+        c->plan.ev1 = er ? er->b : nullptr;
+        gvm::ax2(c->stream, c->plan, xa, xb, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, outa, outb);
+        KCHK(c);
+        t.stop();
+    }
+    c->cnt.n_ax += 2;
+    c->cnt.n_ax_pass += 1;
+    if (multi) {
+        Timer t(c, &c->cnt.ms_allreduce);
+        if (comm_allreduce(c, outa, c->npad)) return 1;
+        if (comm_allreduce(c, outb, c->npad)) return 1;
+        gvk::scale_vec(c->stream, outa, c->npad, scale);
+        gvk::scale_vec(c->stream, outb, c->npad, scale);
+        KCHK(c);
+        t.stop();
+    }
+    return 0;
+}
+int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb) {
+    if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
+        if (atx_device(c, pa, outa)) return 1;
+        return atx_device(c, pb, outb);
+    }
+    NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
+    Timer t(c, &c->cnt.ms_atx);
+    gv_ctx::EvRec* er = ev_next(c, 1);
+    c->plan.ev0 = er ? er->a : nullptr;
+    c->plan.ev1 = er ? er->b : nullptr;
+    gvm::atx2(c->stream, c->plan, pa, pb, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, outa, outb);
+    KCHK(c);
+    t.stop();
+    c->cnt.n_atx += 2;
+    c->cnt.n_atx_pass += 1;
     return 0;
 }
 
@@ -271,7 +322,8 @@ void free_dataset(gv_ctx* c) {
     F(c->plan.scal); F(c->plan.partial);
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
-    for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p})
+    for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p, &c->w_n2,
+                      &c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
         if (*v) {
             (void)hipFree((*v)->d);
             delete *v;
@@ -393,10 +445,11 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
         HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
+        HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
-        size_t pa = (size_t)pl.ks_m * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 2 * pl.nrg_n * 64 * 8 * 4;
+        size_t pa = (size_t)pl.ks_m * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 4 * pl.nrg_n * 64 * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
@@ -591,6 +644,19 @@ int gv_atx_dev(gv_ctx* c, const gv_vec* p, gv_vec* out) {
     return atx_device(c, p->d, out->d);
 }
 
+int gv_ax2_dev(gv_ctx* c, const gv_vec* xa, const gv_vec* xb, gv_vec* outa, gv_vec* outb) {
+    NEED(c, xa->space == GV_SPACE_M && xb->space == GV_SPACE_M && outa->space == GV_SPACE_N && outb->space == GV_SPACE_N &&
+                outa != outb, "gv_ax2_dev: x M-space, out N-space, distinct outputs");
+    if (ensure_work(c)) return 1;
+    return ax2_device(c, xa->d, xb->d, outa->d, outb->d);
+}
+int gv_atx2_dev(gv_ctx* c, const gv_vec* pa, const gv_vec* pb, gv_vec* outa, gv_vec* outb) {
+    NEED(c, pa->space == GV_SPACE_N && pb->space == GV_SPACE_N && outa->space == GV_SPACE_M && outb->space == GV_SPACE_M &&
+                outa != outb, "gv_atx2_dev: p N-space, out M-space, distinct outputs");
+    if (ensure_work(c)) return 1;
+    return atx2_device(c, pa->d, pb->d, outa->d, outb->d);
+}
+
 int gv_ax(gv_ctx* c, const double* x, double* out) {
     if (ensure_work(c)) return 1;
     HIPCHK(c, hipMemcpyAsync(c->cg_d->d, x, sizeof(double) * c->M, hipMemcpyHostToDevice, c->stream));
@@ -627,101 +693,206 @@ int gv_lmmse_mult(gv_ctx* c, const gv_vec* v, double tau, double gam2, gv_vec* o
     return lmmse_device(c, v->d, tau, gam2, out->d);
 }
 
-// vamp::precondCG_solver (vamp.cpp:1130-1229).  Deviations, all result-neutral: <r,z> and ||v||
-// are computed once per step instead of three times / every step; lmmse_mult's all-zero shortcut (:1079) is
-// replaced by "mu_start == NULL"; the scalar reductions of one step travel in packed all-reduces.
+// vamp::precondCG_solver (vamp.cpp:1130-1229) as a small state machine, so that TWO solves on the same operator
+// (the LMMSE solve and the Onsager probe solve of one VAMP iteration, vamp.cpp:593-596 / :884) can share every pass
+// over the genotype shard: each round gathers the pending operator applications Q p of the active systems and runs
+// them as one two-vector Ax / ATx pair.  Per system the recurrences, stopping rules and results are exactly those of
+// a stand-alone solve.  Deviations from the reference, all result-neutral: <r,z> and ||v|| are
+// computed once per step instead of three times / every step; lmmse_mult's all-zero shortcut (:1079) is replaced by
+// "mu_start == NULL"; the scalar reductions of one step travel in packed all-reduces.
+struct CgSys {
+    const double* v = nullptr;
+    const double* mu0 = nullptr;   // warm start or NULL
+    double *mu = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *d = nullptr;
+    int denoiser = 1;
+    double* relres = nullptr;
+    // state
+    bool active = true;
+    int phase = 1;                 // 0: waiting for Q mu0 (initial residual), 1: waiting for Q p
+    double rz = 0, norm_v = 0, prev_onsager = 0, onsager = 0, rel_err = 0;
+    int iters = 0, n_relres = 0, converged = 0;
+    const double* req = nullptr;   // operand of the pending operator application
+    double* res = nullptr;         // where its result goes
+};
+
+static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
+    // z = r / diag (:1152), <r,z>, ||v||^2 ; p = z (:1154)
+    const int64_t M = c->M;
+    double sc[4];
+    gvk::cg_step_b(c->stream, s.r, s.d, 0.0, diag, s.z, s.mu, M, c->red_partial, c->red_out);
+    KCHK(c);
+    if (read_scalars(c, 4, sc)) return 1;
+    const double* vv[1] = {s.v};
+    gvk::dots(c->stream, 1, vv, vv, M, c->red_partial, c->red_out);
+    KCHK(c);
+    double vn2;
+    if (read_scalars(c, 1, &vn2)) return 1;
+    double pk[2] = {sc[0], vn2};
+    if (multi && allreduce_scalars(c, pk, 2)) return 1;
+    s.rz = pk[0];
+    s.norm_v = sqrt(pk[1]);
+    HIPCHK(c, hipMemcpyAsync(s.p, s.z, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+    s.phase = 1;
+    s.req = s.p;
+    s.res = s.d;
+    return 0;
+}
+
+static int cg_consume(gv_ctx* c, CgSys& s, double gam2, double diag, int max_iter, bool multi) {
+    const int64_t M = c->M;
+    hipStream_t st = c->stream;
+    if (s.phase == 0) {                                                   // r = v - Q mu0 (:1142-1145)
+        gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
+        KCHK(c);
+        return cg_finish_init(c, s, diag, multi);
+    }
+    const int i = s.iters;
+    s.iters = i + 1;
+    const double* xs[1] = {s.d};
+    const double* ys[1] = {s.p};
+    gvk::dots(st, 1, xs, ys, M, c->red_partial, c->red_out);
+    KCHK(c);
+    double dp;
+    if (read_scalars(c, 1, &dp)) return 1;
+    if (multi && allreduce_scalars(c, &dp, 1)) return 1;
+    const double alpha = s.rz / dp;                                       // :1167
+    gvk::cg_step_a(st, s.mu, s.p, alpha, s.v, M, c->red_partial, c->red_out);   // mu += alpha p (:1169-1172)
+    KCHK(c);
+    if (s.denoiser == 0) {                                                // :1174-1193
+        double vm;
+        if (read_scalars(c, 1, &vm)) return 1;
+        if (multi && allreduce_scalars(c, &vm, 1)) return 1;
+        s.onsager = gam2 * vm;
+        const double oerr = (s.onsager != 0) ? fabs((s.onsager - s.prev_onsager) / s.onsager) : 1.0;
+        if (oerr < 1e-8) {
+            s.converged = 1;
+            s.active = false;
+            return 0;
+        }
+        s.prev_onsager = s.onsager;
+    }
+    double sc[4];
+    gvk::cg_step_b(st, s.r, s.d, alpha, diag, s.z, s.mu, M, c->red_partial, c->red_out);   // :1195-1216
+    KCHK(c);
+    if (read_scalars(c, 4, sc)) return 1;
+    if (multi && allreduce_scalars(c, sc, 4)) return 1;
+    const double beta = sc[0] / s.rz;                                     // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
+    s.rz = sc[0];
+    gvk::axpby(st, s.p, 1.0, s.z, beta, s.p, M);                          // p = z + beta p (:1209-1210)
+    KCHK(c);
+    s.rel_err = sqrt(sc[2]) / s.norm_v;                                   // :1215
+    if (s.relres) s.relres[i] = s.rel_err;
+    s.n_relres = i + 1;
+    if (s.rel_err < 1e-5) {                                               // :1217,:1222
+        s.converged = 1;
+        s.active = false;
+    } else if (s.iters >= max_iter)
+        s.active = false;
+    return 0;
+}
+
+// two-vector operator: outa = tau A^T A xa + gam2 xa, outb likewise, ONE Ax pass and ONE ATx pass (kernel mode 1)
+static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double tau, double gam2, double* outa,
+                         double* outb) {
+    if (ensure_work(c)) return 1;
+    if (!c->w_n2 && vec_new(c, GV_SPACE_N, &c->w_n2)) return 1;
+    if (ax2_device(c, xa, xb, c->w_n->d, c->w_n2->d)) return 1;
+    if (atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb)) return 1;
+    gvk::axpby(c->stream, outa, tau, outa, gam2, xa, c->M);
+    gvk::axpby(c->stream, outb, tau, outb, gam2, xb, c->M);
+    KCHK(c);
+    return 0;
+}
+
+static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter) {
+    const int64_t M = c->M;
+    const bool multi = is_multi(c);
+    const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
+    for (int k = 0; k < nsys; k++) {
+        CgSys& s = sys[k];
+        if (s.mu0) {
+            HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            s.phase = 0;
+            s.req = s.mu;
+            s.res = s.r;
+        } else {
+            gvk::fill(c->stream, s.mu, M, 0.0);
+            HIPCHK(c, hipMemcpyAsync(s.r, s.v, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            if (cg_finish_init(c, s, diag, multi)) return 1;
+        }
+        if (max_iter <= 0 && s.phase == 1) s.active = false;
+    }
+    for (;;) {
+        CgSys* act[2];
+        int na = 0;
+        for (int k = 0; k < nsys; k++)
+            if (sys[k].active) act[na++] = &sys[k];
+        if (na == 0) break;
+        if (na == 2) {
+            if (lmmse2_device(c, act[0]->req, act[1]->req, tau, gam2, act[0]->res, act[1]->res)) return 1;
+        } else if (lmmse_device(c, act[0]->req, tau, gam2, act[0]->res))
+            return 1;
+        for (int k = 0; k < na; k++) {
+            const bool was_init = act[k]->phase == 0;
+            if (cg_consume(c, *act[k], gam2, diag, max_iter, multi)) return 1;
+            if (was_init && max_iter <= 0) act[k]->active = false;
+        }
+    }
+    return 0;
+}
+
+static void cg_fill_stats(const CgSys& s, gv_cg_stats* st) {
+    if (!st) return;
+    st->iters = s.iters;
+    st->converged = s.converged;
+    st->rel_res = s.rel_err;
+    st->onsager = s.onsager;
+    st->n_relres = s.n_relres;
+}
+
 int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int denoiser,
                 int max_iter, gv_vec* mu_out, gv_cg_stats* st, double* relres) {
     NEED(c, v->space == GV_SPACE_M && mu_out->space == GV_SPACE_M, "gv_cg_solve: M-space vectors required");
     NEED(c, mu_out != v && mu_out != mu_start, "gv_cg_solve: mu_out must not alias v or mu_start");
     if (ensure_work(c)) return 1;
-    const int64_t M = c->M;
-    hipStream_t s = c->stream;
-    double *r = c->cg_r->d, *z = c->cg_z->d, *p = c->cg_p->d, *d = c->cg_d->d, *mu = mu_out->d;
-    const bool multi = is_multi(c);
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
-    const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
-    double sc[4];
-
-    if (mu_start) {
-        HIPCHK(c, hipMemcpyAsync(mu, mu_start->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
-        if (lmmse_device(c, mu, tau, gam2, r)) return 1;
-        gvk::axpby(s, r, 1.0, v->d, -1.0, r, M);          // r = v - Q mu   (:1142-1145)
-    } else {
-        gvk::fill(s, mu, M, 0.0);
-        HIPCHK(c, hipMemcpyAsync(r, v->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
-    }
-    // alpha = 0 pass: z = r / diag (:1152) and red_out = <r,z>, <z,z>, <r,r>, <mu,mu>
-    gvk::cg_step_b(s, r, d, 0.0, diag, z, mu, M, c->red_partial, c->red_out);
-    KCHK(c);
-    if (read_scalars(c, 4, sc)) return 1;
-    double rz = sc[0];
-    const double* vv[1] = {v->d};
-    gvk::dots(s, 1, vv, vv, M, c->red_partial, c->red_out);
-    KCHK(c);
-    double vn2;
-    if (read_scalars(c, 1, &vn2)) return 1;
-    if (multi) {
-        double pk[2] = {rz, vn2};
-        if (allreduce_scalars(c, pk, 2)) return 1;
-        rz = pk[0];
-        vn2 = pk[1];
-    }
-    const double norm_v = sqrt(vn2);
-    HIPCHK(c, hipMemcpyAsync(p, z, sizeof(double) * M, hipMemcpyDeviceToDevice, s));   // p = z (:1154)
-
-    double prev_onsager = 0, onsager = 0, rel_err = 0;
-    int iters = 0, converged = 0, n_relres = 0;
-    for (int i = 0; i < max_iter; i++) {
-        iters = i + 1;
-        if (lmmse_device(c, p, tau, gam2, d)) return 1;                   // d = Q p (:1165)
-        const double* xs[1] = {d};
-        const double* ys[1] = {p};
-        gvk::dots(s, 1, xs, ys, M, c->red_partial, c->red_out);
-        KCHK(c);
-        double dp;
-        if (read_scalars(c, 1, &dp)) return 1;
-        if (multi && allreduce_scalars(c, &dp, 1)) return 1;
-        const double alpha = rz / dp;                                      // :1167
-        gvk::cg_step_a(s, mu, p, alpha, v->d, M, c->red_partial, c->red_out);   // mu += alpha p (:1169-1172)
-        KCHK(c);
-        if (denoiser == 0) {                                               // :1174-1193
-            double vm;
-            if (read_scalars(c, 1, &vm)) return 1;
-            if (multi && allreduce_scalars(c, &vm, 1)) return 1;
-            onsager = gam2 * vm;
-            double oerr = (onsager != 0) ? fabs((onsager - prev_onsager) / onsager) : 1.0;
-            if (oerr < 1e-8) {
-                converged = 1;
-                break;
-            }
-            prev_onsager = onsager;
-        }
-        gvk::cg_step_b(s, r, d, alpha, diag, z, mu, M, c->red_partial, c->red_out);   // :1195-1216
-        KCHK(c);
-        if (read_scalars(c, 4, sc)) return 1;
-        if (multi && allreduce_scalars(c, sc, 4)) return 1;
-        const double beta = sc[0] / rz;                                    // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
-        rz = sc[0];
-        gvk::axpby(s, p, 1.0, z, beta, p, M);                              // p = z + beta p (:1209-1210)
-        KCHK(c);
-        rel_err = sqrt(sc[2]) / norm_v;                                    // :1215
-        if (relres) relres[i] = rel_err;
-        n_relres = i + 1;
-        if (rel_err < 1e-5) {                                              // :1217,:1222
-            converged = 1;
-            break;
-        }
-    }
+    CgSys s;
+    s.v = v->d; s.mu0 = mu_start ? mu_start->d : nullptr; s.mu = mu_out->d;
+    s.r = c->cg_r->d; s.z = c->cg_z->d; s.p = c->cg_p->d; s.d = c->cg_d->d;
+    s.denoiser = denoiser; s.relres = relres;
+    if (cg_run(c, &s, 1, tau, gam2, max_iter)) return 1;
+    cg_fill_stats(s, st);
     if (st) {
-        st->iters = iters;
-        st->converged = converged;
-        st->rel_res = rel_err;
-        st->onsager = onsager;
         st->n_ax = (int)(c->cnt.n_ax - ax0);
         st->n_atx = (int)(c->cnt.n_atx - atx0);
-        st->n_relres = n_relres;
     }
+    return 0;
+}
+
+// The LMMSE solve (denoiser = 1, optional warm start) and the Onsager probe solve (denoiser = 0, zero start) of one VAMP
+// iteration in lock-step.  n_ax / n_atx of the stats count vector products (2 per shared pass).
+int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                 int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
+                 double* relres_b) {
+    NEED(c, v_a->space == GV_SPACE_M && v_b->space == GV_SPACE_M && mu_a->space == GV_SPACE_M && mu_b->space == GV_SPACE_M,
+         "gv_cg_solve2: M-space vectors required");
+    NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && mu_a != mu_b, "gv_cg_solve2: outputs must not alias inputs");
+    if (ensure_work(c)) return 1;
+    for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
+        if (!*w && vec_new(c, GV_SPACE_M, w)) return 1;
+    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
+    CgSys s[2];
+    s[0].v = v_a->d; s[0].mu0 = mu_start_a ? mu_start_a->d : nullptr; s[0].mu = mu_a->d;
+    s[0].r = c->cg_r->d; s[0].z = c->cg_z->d; s[0].p = c->cg_p->d; s[0].d = c->cg_d->d;
+    s[0].denoiser = 1; s[0].relres = relres_a;
+    s[1].v = v_b->d; s[1].mu0 = nullptr; s[1].mu = mu_b->d;
+    s[1].r = c->cg2_r->d; s[1].z = c->cg2_z->d; s[1].p = c->cg2_p->d; s[1].d = c->cg2_d->d;
+    s[1].denoiser = 0; s[1].relres = relres_b;
+    if (cg_run(c, s, 2, tau, gam2, max_iter)) return 1;
+    cg_fill_stats(s[0], st_a);
+    cg_fill_stats(s[1], st_b);
+    if (st_a) { st_a->n_ax = (int)(c->cnt.n_ax - ax0); st_a->n_atx = (int)(c->cnt.n_atx - atx0); }
+    if (st_b) { st_b->n_ax = st_a ? st_a->n_ax : 0; st_b->n_atx = st_a ? st_a->n_atx : 0; }
     return 0;
 }
 

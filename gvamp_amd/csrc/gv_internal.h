@@ -50,7 +50,8 @@ struct gv_ctx {
     double* red_out = nullptr;     // RED_MAXK device scalars
     double* host_pin = nullptr;    // pinned, RED_MAXK doubles
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
-    gv_vec *w_n = nullptr;                                   // N-space scratch (lmmse_mult)
+    gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
+    gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
     gv_vec *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_d = nullptr;  // CG work vectors
 
     // communicator ---------------------------------------------------------------------------------

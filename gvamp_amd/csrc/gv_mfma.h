@@ -39,4 +39,10 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
         int64_t npad, double post, double* red_partial, double* out);
 
+// two vectors per pass (the LMMSE and the Onsager CG of one VAMP iteration share the operator, vamp.cpp:593-596,:884)
+void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
+          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb);
+void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
+         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb);
+
 }  // namespace gvm

@@ -422,13 +422,14 @@ __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, 
 __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                  const double* __restrict__ scal, const double* __restrict__ mave,
                                                  const double* __restrict__ msig, double inv_sqrt_n,
-                                                 double* __restrict__ out) {
+                                                 double* __restrict__ out, int ppk, int p0) {
+    // ppk = planes per K-split in `partial` (2, or 4 for the two-vector kernels), p0 = first plane of this vector
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int ks = 0; ks < ksplit; ks++) {
-        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + 0) * rows_p + m) * 8);
-        const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + 1) * rows_p + m) * 8);
+        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
+        const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
         int4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
         sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
         sy[0] += y0.x; sy[1] += y0.y; sy[2] += y0.z; sy[3] += y0.w; sy[4] += y1.x; sy[5] += y1.y; sy[6] += y1.z;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal,
                                                 const uint32_t* __restrict__ mask2, double post,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out, int ppk, int p0) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= npad) return;
     const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int ks = 0; ks < ksplit; ks++) {
         for (int plane = 0; plane < 2; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
-            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 2 + plane) * rows_p + n) * 8);
+            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + plane) * rows_p + n) * 8);
             int4 x0 = px[0], x1 = px[1];
             sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
         }
@@ -466,6 +467,101 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     combine(sx, xh, xl);
     const double T = ((double)xh * 4294967296.0 + (double)xl) * scal[3];
     out[n] = (T - scal[1]) * post;
+}
+
+// ---- two vectors per pass ---------------------------------------------------------------------------------------------
+// The LMMSE solve and the Onsager probe solve of one VAMP iteration are CG runs on the SAME operator
+// (vamp.cpp:593-596 and :884), so their matvecs can share the stream over the genotype shard.
+//   ATx of two N-vectors: k_mfma_matvec<2> -- digits(p_a) in columns 0..7, digits(p_b) in columns 8..15: free.
+//   Ax of two M-vectors: k_mfma_ax2 -- digit blocks [c_a|e_a] and [c_b|e_b], four MFMAs per (tile, dword) instead
+//   of two; the HBM stream, the expansion VALU work and the supertile registers are shared.
+__device__ __forceinline__ void compute_step2(const ABuf& a, const BBuf& ba, const BBuf& bb, v4i (&xa)[4], v4i (&ya)[4],
+                                              v4i (&xb)[4], v4i (&yb)[4]) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const v4i BA = {(int)ba.d[d].x, (int)ba.d[d].y, (int)ba.d[d].z, (int)ba.d[d].w};
+        const v4i BB = {(int)bb.d[d].x, (int)bb.d[d].y, (int)bb.d[d].z, (int)bb.d[d].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w = a.t[i][d];
+            const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
+                           e3 = (w >> 6) & 0x03030303u;
+            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            xa[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BA, xa[i], 0, 0, 0);
+            xb[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BB, xb[i], 0, 0, 0);
+            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            ya[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BA, ya[i], 0, 0, 0);
+            yb[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BB, yb[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// partial layout: [(ks * 4 + 2 v + plane) * rows_p + row] * 8 + digit, v = vector (0, 1), plane as in MODE 1
+__global__ __launch_bounds__(256, 2) void k_mfma_ax2(const u32x4* __restrict__ stripes, const u32x4* __restrict__ diga,
+                                                     const u32x4* __restrict__ digb, int64_t nrg, int64_t nkb, int ksplit,
+                                                     int32_t* __restrict__ partial) {
+    constexpr int KBS = 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= nrg * ksplit) return;
+    const int64_t rg = wg % nrg;
+    const int ks = (int)(wg / nrg);
+    const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
+    const int c = lane & 15, g = lane >> 4;
+    const int bofs = g * 16 + c;
+    v4i xa[4], ya[4], xb[4], yb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] = (v4i){0, 0, 0, 0};
+        ya[i] = (v4i){0, 0, 0, 0};
+        xb[i] = (v4i){0, 0, 0, 0};
+        yb[i] = (v4i){0, 0, 0, 0};
+    }
+    const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
+    const u32x4* bpa = diga + kb0 * KBS + bofs;
+    const u32x4* bpb = digb + kb0 * KBS + bofs;
+    const int64_t nsteps = kb1 - kb0;
+    if (nsteps <= 0) return;
+    const int64_t last = nsteps - 1;
+    ABuf a0, a1, a2;
+    BBuf ba0, ba1, bb0, bb1;
+    load_a(a0, ap);
+    load_b<1>(ba0, bpa);
+    load_b<1>(bb0, bpb);
+    load_a(a1, ap + (last < 1 ? last : 1) * 256);
+#pragma unroll 1
+    for (int64_t st = 0; st < nsteps; st++) {
+        const int64_t n2 = st + 2 < last ? st + 2 : last, n1 = st + 1 < last ? st + 1 : last;
+        load_a(a2, ap + n2 * 256);
+        load_b<1>(ba1, bpa + n1 * KBS);
+        load_b<1>(bb1, bpb + n1 * KBS);
+        compute_step2(a0, ba0, bb0, xa, ya, xb, yb);
+        a0 = a1;
+        a1 = a2;
+        ba0 = ba1;
+        bb0 = bb1;
+    }
+    const int64_t rows_p = nrg * 64;
+    const int cd = c & 7;
+    const bool lo = c < 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+            if (lo) {
+                partial[(((int64_t)ks * 4 + 0) * rows_p + row) * 8 + cd] = xa[i][reg];
+                partial[(((int64_t)ks * 4 + 2) * rows_p + row) * 8 + cd] = xb[i][reg];
+            } else {
+                partial[(((int64_t)ks * 4 + 1) * rows_p + row) * 8 + cd] = ya[i][reg];
+                partial[(((int64_t)ks * 4 + 3) * rows_p + row) * 8 + cd] = yb[i][reg];
+            }
+        }
+    }
 }
 
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
@@ -511,7 +607,30 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
                        (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, out);
+                       pl.scal, mave, msig, inv_sqrt_n, out, 2, 0);
+}
+
+// data::ATx of TWO N-vectors in one pass over stripes_m
+void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
+          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb) {
+    int nb = prep_blocks(npad);
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, pa, npad, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, pb, npad, red_partial);
+    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal + 4);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, pa, npad, pl.nkb_m, pl.scal,
+                       (uint32_t*)pl.dig0, 16, 0);
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, pb, npad, pl.nkb_m, pl.scal + 4,
+                       (uint32_t*)pl.dig0, 16, 8);
+    int64_t waves = pl.nrg_m * pl.ks_m;
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    hipLaunchKernelGGL(k_mfma_matvec<2>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
+                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, outa, 4, 0);
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal + 4, mave, msig, inv_sqrt_n, outb, 4, 2);
 }
 
 // one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
@@ -548,7 +667,31 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
                        (const u32x4*)pl.dig0, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, out);
+                       pl.scal, mask2, post, out, 2, 0);
+}
+
+// data::Ax of TWO M-vectors in one pass over stripes_n (dig0 / dig1 hold [c|e] of vector a / b)
+void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
+         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb) {
+    int nb = prep_blocks(pl.M);
+    const int qb = nblk(pl.nkb_n * 64, 256);
+    for (int v = 0; v < 2; v++) {   // cv / ev are reused: vector b is prepared after vector a's digits are written
+        double* sc = pl.scal + 4 * v;
+        void* dg = v ? pl.dig1 : pl.dig0;
+        hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, v ? xb : xa, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
+        hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, sc);
+        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, sc, (uint32_t*)dg, 16, 0);
+        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, sc, (uint32_t*)dg, 16, 8);
+    }
+    int64_t waves = pl.nrg_n * pl.ks_n;
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    hipLaunchKernelGGL(k_mfma_ax2, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_n, (const u32x4*)pl.dig0,
+                       (const u32x4*)pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, outa, 4, 0);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal + 4, mask2, post, outb, 4, 2);
 }
 
 }  // namespace gvm

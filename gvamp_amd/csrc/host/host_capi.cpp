@@ -54,6 +54,8 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
                    (unsigned int)o->seed, o->use_lmmse_damp, o->diagnostics, (o->out_prefix && o->out_prefix[0]) ? 1 : 0);
     opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
     opt.set_probit_var(o->probit_var);
+    opt.set_fuse_solves(o->fuse_solves);
+    gv_host_set_quiet(!o->verbose);
     vamp vm(N, M, Mt, o->gam1, o->gamw, o->iterations, o->rho, vars, probs, ts, rank, "",
             o->out_prefix ? o->out_prefix : "", o->bin_class ? "bin_class" : "linear", opt);
     vm.set_verbose(o->verbose);
@@ -71,7 +73,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
         t.R2_denoise = s.R2_denoise; t.R2_lmmse = s.R2_lmmse;
         t.cg_iters = s.cg_iters; t.onsager_iters = s.onsager_iters; t.revar_rounds = s.revar_rounds; t.L_after = s.L_after;
         t.beta1 = s.beta1; t.tau2 = s.tau2; t.tau1_next = s.tau1_next;
-        t.n_ax = s.n_ax; t.n_atx = s.n_atx; t.seconds = s.seconds; t.seconds_io = s.seconds_io;
+        t.n_ax = s.n_ax; t.n_atx = s.n_atx; t.n_ax_pass = s.n_ax_pass; t.n_atx_pass = s.n_atx_pass; t.seconds = s.seconds; t.seconds_io = s.seconds_io;
     }
     auto dump = [&](const std::vector<std::vector<double>>& h, double* dst) {
         if (!dst) return;

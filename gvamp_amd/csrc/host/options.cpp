@@ -116,6 +116,7 @@ void Options::read_command_line_options(int argc, char** argv) {
     uns("--synth-miss-ppm", synth_miss_ppm, NONNEG, "a non-negative integer");
     H["--diagnostics"] = [&](const char* a) { diagnostics = atoi(a); };
     H["--store-iterates"] = [&](const char* a) { store_iterates = atoi(a); };
+    H["--fuse-solves"] = [&](const char* a) { fuse_solves = atoi(a); };
 
     std::stringstream ss;
     ss << "\nardyh command line options:\n";

@@ -69,6 +69,7 @@ public:
     long get_synth_seed() const { return synth_seed; }         // --synth-seed S: on-device synthetic .bed (no --bed-file)
     unsigned int get_synth_miss_ppm() const { return synth_miss_ppm; }   // --synth-miss-ppm (default 5000)
     int get_diagnostics() const { return diagnostics; }        // --diagnostics 1: the 3 print-only Ax of vamp.cpp:646-681
+    int get_fuse_solves() const { return fuse_solves; }        // --fuse-solves 0: separate LMMSE / Onsager CG passes
     int get_store_iterates() const { return store_iterates; }  // --store-iterates 0: skip the per-iteration .bin/.csv dumps
     // [ext] programmatic construction (host_capi.cpp): the solver knobs that `vamp` reads through the getters above
     void set_solver(unsigned int EM_max_iter_, unsigned int CG_max_iter_, double EM_err_thr_, double stop_criteria_thr_,
@@ -79,6 +80,7 @@ public:
         use_lmmse_damp = use_lmmse_damp_; diagnostics = diagnostics_; store_iterates = store_iterates_;
     }
     void set_use_XXT_denoiser(unsigned int v) { use_XXT_denoiser = v; }
+    void set_fuse_solves(int v) { fuse_solves = v; }
 
 private:
     std::string bed_file = "", bed_file_test = "", estimate_file = "", freeze_index_file = "", cov_estimate_file = "",
@@ -97,7 +99,7 @@ private:
     double rho = 0.15, h2 = -1;
     unsigned int iterations = 1;
     std::vector<std::string> phen_files, phen_files_test, true_signal_files;
-    int device = -1, kernel_mode = 1, diagnostics = 0, store_iterates = 1;
+    int device = -1, kernel_mode = 1, diagnostics = 0, store_iterates = 1, fuse_solves = 1;
     long synth_seed = -1;
     unsigned int synth_miss_ppm = 5000;
 

@@ -18,6 +18,8 @@ static int env_int(const char* k, int dflt) {
     const char* v = getenv(k);
     return v ? atoi(v) : dflt;
 }
+static bool g_quiet = false;
+void gv_host_set_quiet(bool quiet) { g_quiet = quiet; }
 int gv_env_rank() { return env_int("RANK", 0); }
 int gv_env_nranks() { return env_int("WORLD_SIZE", 1); }
 int gv_env_local_rank() { return env_int("LOCAL_RANK", gv_env_rank()); }
@@ -73,7 +75,7 @@ void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int
     vars.push_back(0);
     for (int k = 1; k < L; k++, v *= ratio) vars.push_back(v);
     for (double& x : vars) x /= N;
-    if (rank == 0) {
+    if (rank == 0 && !g_quiet) {
         std::cout << "probs = ";
         for (double x : probs) std::cout << x << ' ';
         std::cout << std::endl << "scaled variances = ";

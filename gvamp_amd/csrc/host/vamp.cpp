@@ -41,6 +41,7 @@ void vamp::common_init(const Options& opt) {
     store_pvals = opt.get_store_pvals();   // the reference's ctor 1 leaves 1 here (vamp.hpp:53); --store-pvals is honoured
     diagnostics = opt.get_diagnostics();
     store_iterates = opt.get_store_iterates();
+    fuse_solves = opt.get_fuse_solves();
     probit_var = opt.get_probit_var();
     nranks = gv_env_nranks();
     initialize_prior(this->probs, this->vars, N, Mt, rank);
@@ -64,7 +65,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N})
+                      tN, tN2, mu_CG_last_N, aty})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -121,28 +122,48 @@ std::vector<double> vamp::infere(data* dataset) {
 
 // vamp.cpp:871-889: u in {+-1/sqrt(Mt)}^M from mt19937{seed + S} + bernoulli(0.5) on the host (bit-comparable with the
 // reference at matched shard boundaries), CG on the device.
-double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
+void vamp::draw_onsager_probe(data* dataset) {
     std::mt19937 rd{seed + (long unsigned int)dataset->get_S()};
     std::bernoulli_distribution bern(0.5);
     std::vector<double> u(M > 0 ? M : 0);
     for (int i = 0; i < M; i++) u[i] = (2 * bern(rd) - 1) / sqrt(Mt);
     ck(gv_vec_upload(ctx, bern_vec, u.data()), "gv_vec_upload");
+}
+
+double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
+    draw_onsager_probe(dataset);
     cg(bern_vec, nullptr, tau, 0, invQ_bern_vec, iters);
     return gam2_ * dotM(bern_vec, invQ_bern_vec);
+}
+
+// The two CG solves of one iteration share the operator (tau A^T A + gam2 I): gv_cg_solve2 applies it to both pending
+// directions in one two-vector Ax + ATx pair per round.  Iterates, stopping rules and results per solve are unchanged.
+double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters) {
+    draw_onsager_probe(dataset);
+    gv_cg_stats sa, sb;
+    std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
+    ck(gv_cg_solve2(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data()),
+       "gv_cg_solve2");
+    if (verbose && rank == 0) {
+        for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
+        for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
+    }
+    if (cg_iters) *cg_iters = sa.iters;
+    if (onsager_iters) *onsager_iters = sb.iters;
+    return gam2 * dotM(bern_vec, invQ_bern_vec);
 }
 
 // vamp.cpp:892-927.  temp = A x2 - y is also what err_measures(2) recomputes (:1301-1314); its R2 is taken here so
 // that the duplicate Ax of the reference is not repeated.
 void vamp::updateNoisePrec(data* dataset, double* R2_out) {
     (void)dataset;
-    ck(gv_ax_dev(ctx, x2_hat, tN), "gv_ax_dev");
+    ck(gv_ax2_dev(ctx, x2_hat, invQ_bern_vec, tN, tN2), "gv_ax2_dev");     // A x2_hat (:897) and A invQ u (:913), one pass
     ck(gv_vec_axpby(ctx, tN, 1.0, tN, -1.0, y), "gv_vec_axpby");          // temp = A x2_hat - y
     const gv_vec* xs[2] = {tN, y};
     const gv_vec* ys[2] = {tN, y};
     double d2[2];
     ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
     const double temp_norm2 = d2[0];
-    ck(gv_ax_dev(ctx, invQ_bern_vec, tN2), "gv_ax_dev");
     ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
     const double trace_corr = dotM(bern_vec, tM) * Mt;
     if (verbose && rank == 0) {
@@ -244,6 +265,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     const std::string pre = out_dir + out_name;
     std::vector<double> x1_hat_stored(M > 0 ? M : 0, 0.0);
 
+    double fused_alpha2 = 0;
     for (int it = 1; it <= max_iter; it++) {
         const double t_start = now_s();
         double t_io = 0;
@@ -344,9 +366,17 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         // ---- LMMSE step (:547-620)
         if (verbose && rank == 0) std::cout << "______________________" << std::endl << "->LMMSE" << std::endl;
         if (reverse == 0) {
-            ck(gv_atx_dev(ctx, y, vM), "gv_atx_dev");                      // v = gamw A^T y + gam2 r2 (:588-591)
-            ck(gv_vec_axpby(ctx, vM, gamw, vM, gam2, r2), "gv_vec_axpby");
-            cg(vM, (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last, gamw, 1, x2_hat, &st.cg_iters);   // :593-596
+            if (!have_aty) {                                               // A^T y (:588) does not change: once
+                if (!aty) ck(gv_vec_alloc(ctx, GV_SPACE_M, &aty), "gv_vec_alloc");
+                ck(gv_atx_dev(ctx, y, aty), "gv_atx_dev");
+                have_aty = true;
+            }
+            ck(gv_vec_axpby(ctx, vM, gamw, aty, gam2, r2), "gv_vec_axpby");   // v = gamw A^T y + gam2 r2 (:590-591)
+            gv_vec* warm = (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last;
+            if (fuse_solves) {
+                fused_alpha2 = fused_solves(vM, warm, gamw, dataset, &st.cg_iters, &st.onsager_iters);
+            } else
+                cg(vM, warm, gamw, 1, x2_hat, &st.cg_iters);               // :593-596
             ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");       // :1225-1226
             have_mu_CG_last = true;
         } else {
@@ -369,7 +399,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         store_scaled(pre + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat, &x2_hist);
         t_io += now_s() - t0;
 
-        alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);     // :631
+        if (fuse_solves && reverse == 0) alpha2 = fused_alpha2;           // :631, solved together with x2_hat above
+        else alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);
         st.alpha2 = alpha2;
         if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
         if (it > 1 && diagnostics) {
@@ -403,6 +434,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         gv_get_counters(ctx, &c1);
         st.n_ax = (long)(c1.n_ax - c0.n_ax);
         st.n_atx = (long)(c1.n_atx - c0.n_atx);
+        st.n_ax_pass = (long)(c1.n_ax_pass - c0.n_ax_pass);
+        st.n_atx_pass = (long)(c1.n_atx_pass - c0.n_atx_pass);
 
         // stopping criterion (:741-749)
         ck(gv_vec_axpby(ctx, tM, 1.0, x1_hat_prev, -1.0, x1_hat), "gv_vec_axpby");
@@ -535,9 +568,13 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         if (verbose && rank == 0) std::cout << std::endl << "->LMMMSE" << std::endl;
         ck(gv_atx_dev(ctx, p2, vM), "gv_atx_dev");                         // :492-495
         ck(gv_vec_axpby(ctx, vM, tau2, vM, gam2, r2), "gv_vec_axpby");
-        cg(vM, nullptr, tau2, 1, x2_hat, &st.cg_iters);                    // :497 (always from zero)
+        if (fuse_solves)                                                   // :497 (always from zero) + :512 in lock-step
+            alpha2 = fused_solves(vM, nullptr, tau2, dataset, &st.cg_iters, &st.onsager_iters);
+        else {
+            cg(vM, nullptr, tau2, 1, x2_hat, &st.cg_iters);
+            alpha2 = g2d_onsager(gam2, tau2, dataset, &st.onsager_iters);
+        }
         store_scaled("", x2_hat, &x2_hist);
-        alpha2 = g2d_onsager(gam2, tau2, dataset, &st.onsager_iters);     // :512
         st.alpha2 = alpha2;
         if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
         eta2 = gam2 / alpha2;
@@ -570,6 +607,8 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         gv_get_counters(ctx, &c1);
         st.n_ax = (long)(c1.n_ax - c0.n_ax);
         st.n_atx = (long)(c1.n_atx - c0.n_atx);
+        st.n_ax_pass = (long)(c1.n_ax_pass - c0.n_ax_pass);
+        st.n_atx_pass = (long)(c1.n_atx_pass - c0.n_atx_pass);
         ck(gv_vec_axpby(ctx, tM, 1.0, x1_hat_prev, -1.0, x1_hat), "gv_vec_axpby");   // :624-640
         const gv_vec* xs[2] = {tM, x1_hat_prev};
         const gv_vec* ys[2] = {tM, x1_hat_prev};

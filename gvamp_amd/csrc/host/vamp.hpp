@@ -12,7 +12,8 @@
 struct vamp_iter_stats {     // one row per VAMP iteration (what the reference prints on rank 0)
     double gam1_denoise, alpha1, eta1, gam2, alpha2, eta2, gam2_reest, gam1_next, gamw, rho, R2_denoise, R2_lmmse;
     int cg_iters, onsager_iters, revar_rounds, L_after;
-    long n_ax, n_atx;
+    long n_ax, n_atx;                 // vector products
+    long n_ax_pass, n_atx_pass;       // passes over the genotype shard (two-vector kernels share a pass)
     double beta1, tau2, tau1_next;   // bin_class only
     double seconds, seconds_io;
 };
@@ -34,7 +35,7 @@ private:
     int store_pvals = 0, use_lmmse_damp = 0, reverse = 0;
     double gam1_init = -1, gamw_init = 0;
     std::string r1_init_file, estimate_file;
-    int diagnostics = 0, store_iterates = 1, verbose = 1;
+    int diagnostics = 0, store_iterates = 1, verbose = 1, fuse_solves = 1;
     double probit_var = 1;   // options.hpp:124
 
     // device state (allocated in infere_linear)
@@ -42,7 +43,8 @@ private:
     gv_vec *x1_hat = nullptr, *x1_hat_prev = nullptr, *x2_hat = nullptr, *r1 = nullptr, *r2 = nullptr, *r2_prev = nullptr,
            *z1 = nullptr, *y = nullptr, *mu_CG_last = nullptr, *bern_vec = nullptr, *invQ_bern_vec = nullptr,
            *vM = nullptr, *tM = nullptr, *tN = nullptr, *tN2 = nullptr, *mu_CG_last_N = nullptr;
-    bool have_mu_CG_last = false;
+    bool have_mu_CG_last = false, have_aty = false;
+    gv_vec* aty = nullptr;   // A^T y, constant over the iterations (computed once instead of at vamp.cpp:588 every time)
     std::vector<vamp_iter_stats> stats;
     std::vector<std::vector<double>> x1_hist, x2_hist, r1_hist;   // per iteration, already / sqrt(N) (if keep_history)
     int keep_history = 0;
@@ -65,6 +67,9 @@ public:
     std::vector<double> infere_linear(data* dataset);    // vamp.cpp:190-803
     std::vector<double> infere_bin_class(data* dataset); // vamp_probit.cpp:20-658 (no covariates)
     double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
+    void draw_onsager_probe(data* dataset);                                   // vamp.cpp:875-882 (host RNG)
+    // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2
+    double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters);
     void updatePrior(int verbose);                       // vamp.cpp:929-1072
     void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)
 

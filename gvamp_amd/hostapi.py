@@ -22,13 +22,14 @@ class Opts(C.Structure):
                 ("gam1", C.c_double), ("gamw", C.c_double), ("L", C.c_int),
                 ("probs", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
                 ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double), ("use_XXT_denoiser", C.c_int),
-                ("bin_class", C.c_int), ("probit_var", C.c_double)]
+                ("bin_class", C.c_int), ("probit_var", C.c_double), ("fuse_solves", C.c_int)]
 
 
 class Iter(C.Structure):
     _fields_ = [(f, C.c_double) for f in ITER_FIELDS] + \
                [("cg_iters", C.c_int), ("onsager_iters", C.c_int), ("revar_rounds", C.c_int), ("L_after", C.c_int),
-                ("n_ax", C.c_long), ("n_atx", C.c_long), ("beta1", C.c_double), ("tau2", C.c_double),
+                ("n_ax", C.c_long), ("n_atx", C.c_long), ("n_ax_pass", C.c_long), ("n_atx_pass", C.c_long),
+                ("beta1", C.c_double), ("tau2", C.c_double),
                 ("tau1_next", C.c_double), ("seconds", C.c_double), ("seconds_io", C.c_double)]
 
 
@@ -67,7 +68,7 @@ class Result:
 def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_max_iter=2, EM_err_thr=1e-2,
                   stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1, use_lmmse_damp=0, gam1=1e-8, gamw=2.0,
                   true_signal=None, out_prefix=None, verbose=0, diagnostics=0, alpha_scale=1.0, mask4=None,
-                  nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0):
+                  nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0, fuse_solves=1):
     L = load()
     y = np.ascontiguousarray(y, dtype=np.float64)
     o = Opts()
@@ -85,6 +86,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     o.verbose, o.diagnostics, o.alpha_scale = verbose, diagnostics, alpha_scale
     o.use_XXT_denoiser = use_XXT_denoiser
     o.bin_class, o.probit_var = int(model == "bin_class"), probit_var
+    o.fuse_solves = fuse_solves
     M = shard.M
     ts = np.ascontiguousarray(true_signal, dtype=np.float64) if true_signal is not None else None
     m4 = np.ascontiguousarray(mask4, dtype=np.uint8) if mask4 is not None else None
@@ -107,7 +109,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     for i in range(n.value):
         t = {f: getattr(iters[i], f) for f in ITER_FIELDS}
         for f in ("cg_iters", "onsager_iters", "revar_rounds", "L_after", "n_ax", "n_atx", "seconds", "seconds_io",
-                  "beta1", "tau2", "tau1_next"):
+                  "beta1", "tau2", "tau1_next", "n_ax_pass", "n_atx_pass"):
             t[f] = getattr(iters[i], f)
         r.trace.append(t)
     if history:

@@ -91,6 +91,10 @@ int gv_vec_dot(gv_ctx* ctx, const gv_vec* x, const gv_vec* y, int sync, double* 
 int gv_vec_dots(gv_ctx* ctx, int n, const gv_vec* const* x, const gv_vec* const* y, int sync, double* out);
 int gv_ax_dev(gv_ctx* ctx, const gv_vec* x, gv_vec* out);  /* data::Ax on handles */
 int gv_atx_dev(gv_ctx* ctx, const gv_vec* p, gv_vec* out); /* data::ATx on handles */
+/* Two vectors per pass over the shard (kernel mode 1; two single passes otherwise): outa = A xa, outb = A xb, and
+ * outa = A^T pa, outb = A^T pb.  Results are bit-identical to the one-vector calls (exact integer accumulation). */
+int gv_ax2_dev(gv_ctx* ctx, const gv_vec* xa, const gv_vec* xb, gv_vec* outa, gv_vec* outb);
+int gv_atx2_dev(gv_ctx* ctx, const gv_vec* pa, const gv_vec* pb, gv_vec* outa, gv_vec* outb);
 /* phenotype y (length N) -> N-space handle with NA / pad slots zeroed: data::filter_pheno (data.cpp:1065-1079) */
 int gv_set_phen(gv_ctx* ctx, gv_vec* y_out, const double* y_host);
 
@@ -108,6 +112,14 @@ typedef struct {
  * relres (may be NULL): max_iter doubles receiving ||r||/||v|| after every step. */
 int gv_cg_solve(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int denoiser,
                 int max_iter, gv_vec* mu_out, gv_cg_stats* stats, double* relres);
+
+/* The LMMSE solve (v_a, optional warm start, denoiser = 1 rules) and the Onsager probe solve (v_b, zero start, denoiser = 0
+ * rules) of one VAMP iteration run in lock-step on the shared operator (tau, gam2): every round applies the operator to
+ * the pending direction of each still-active solve in ONE two-vector Ax + ATx pair.  Per solve the iterates, stopping
+ * rules and results are those of gv_cg_solve. */
+int gv_cg_solve2(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                 int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
+                 double* relres_a, double* relres_b);
 
 /* ---- denoiser side (fused element-wise kernels) ------------------------------------------------------
  * vamp::g1 / g1d over a vector (vamp.cpp:805-869; loops :292-310): x1 = g1(r1), sums[0] = sum g1d(r1) (local),
@@ -169,6 +181,8 @@ typedef struct {
     double ms_allreduce;          /* HIP-event time of the N-vector all-reduces */
     int64_t n_ax_kernel, n_atx_kernel;   /* timing == 2: launches of the dominant matvec kernel measured ... */
     double ms_ax_kernel, ms_atx_kernel;  /* ... and their summed HIP-event durations */
+    int64_t n_ax_pass, n_atx_pass;       /* passes over the genotype shard (a two-vector product counts 2 in n_ax / n_atx
+                                          * and 1 here) */
 } gv_counters;
 /* timing: 0 off; 1 brackets every whole matvec (prep + kernel + epilogue) with HIP events and synchronises per
  * call (development); 2 records event pairs around the dominant matvec kernel only, WITHOUT synchronising --

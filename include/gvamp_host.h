@@ -27,12 +27,14 @@ typedef struct {                 /* the knobs vamp reads from Options (options.h
     int use_XXT_denoiser;         /* --use-XXT-denoiser (options.cpp:208-216) */
     int bin_class;                /* 1: --model bin_class (vamp_probit.cpp), y in {0,1}; x_est is then the UNSCALED x1_hat */
     double probit_var;            /* --probit-var (options.hpp:124) */
+    int fuse_solves;              /* 1: LMMSE and Onsager CG share every pass over the shard (gv_cg_solve2) */
 } gvh_opts;
 
 typedef struct {
     double gam1_denoise, alpha1, eta1, gam2, alpha2, eta2, gam2_reest, gam1_next, gamw, rho, R2_denoise, R2_lmmse;
     int cg_iters, onsager_iters, revar_rounds, L_after;
-    long n_ax, n_atx;
+    long n_ax, n_atx;              /* vector products */
+    long n_ax_pass, n_atx_pass;    /* passes over the genotype shard */
     double beta1, tau2, tau1_next; /* bin_class only */
     double seconds, seconds_io;   /* compute wall time of the iteration, and time spent writing / copying iterates */
 } gvh_iter;
