@@ -415,8 +415,13 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     pl.M = M; pl.N = N;
     pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
     pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
+    // K-splits per row group.  Measured on MI355X (N=400k): ~45k waves per launch (~15 rounds of the 3 x 1024 resident
+    // waves) hide the tail, but a wave should keep >= 256 K-blocks (1 MiB of stripes) to amortise its prologue,
+    // epilogue and partial sums: Mt=1M -> ks 3 (ATx) / 7 (Ax) = 6.5 / 6.2 TB/s; M=125k -> ks 6 / 1.
     auto pick_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks) {
-        int64_t ks = nrg > 0 ? (8192 + nrg - 1) / nrg : 1;
+        int64_t ks = nrg > 0 ? (45056 + nrg / 2) / nrg : 1;
+        const int64_t cap = (nkb + 128) / 256 > 1 ? (nkb + 128) / 256 : 1;
+        if (ks > cap) ks = cap;
         if (ks < min_ks) ks = min_ks;
         if (ks > 64) ks = 64;
         if (ks > nkb) ks = nkb;
@@ -424,6 +429,12 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     };
     pl.ks_m = pick_ks(pl.nrg_m, pl.nkb_m, 1);
     pl.ks_n = pick_ks(pl.nrg_n, pl.nkb_n, (M * 512 + 2147483646LL) / 2147483647LL);
+    // tuning overrides (development): GV_KS_M / GV_KS_N = K-splits of the ATx / Ax kernels
+    if (const char* e = getenv("GV_KS_M")) { int v = atoi(e); if (v >= 1 && v <= pl.nkb_m) pl.ks_m = v; }
+    if (const char* e = getenv("GV_KS_N")) {
+        int v = atoi(e);
+        if (v >= (M * 512 + 2147483646LL) / 2147483647LL && v >= 1 && v <= pl.nkb_n) pl.ks_n = v;
+    }
     return gv_set_mask(c, nullptr, N);
 }
 

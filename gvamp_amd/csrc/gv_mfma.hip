@@ -473,36 +473,34 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
 // The LMMSE solve and the Onsager probe solve of one VAMP iteration are CG runs on the SAME operator
 // (vamp.cpp:593-596 and :884), so their matvecs can share the stream over the genotype shard.
 //   ATx of two N-vectors: k_mfma_matvec<2> -- digits(p_a) in columns 0..7, digits(p_b) in columns 8..15: free.
-//   Ax of two M-vectors: k_mfma_ax2 -- digit blocks [c_a|e_a] and [c_b|e_b], four MFMAs per (tile, dword) instead
-//   of two; the HBM stream, the expansion VALU work and the supertile registers are shared.
-__device__ __forceinline__ void compute_step2(const ABuf& a, const BBuf& ba, const BBuf& bb, v4i (&xa)[4], v4i (&ya)[4],
-                                              v4i (&xb)[4], v4i (&yb)[4]) {
+//   Ax of two M-vectors: k_mfma_ax2 -- the r' plane multiplies the digit block [c_a | c_b], the miss plane the block
+//   [e_a | e_b]: still two MFMAs per (tile, dword), now with all 16 columns of both in use (the one-vector kernel
+//   wastes half of each).  Vector a = accX[:, 0:8] + accY[:, 0:8], vector b = accX[:, 8:16] + accY[:, 8:16].
+__device__ __forceinline__ void compute_step2(const ABuf& a, const BBuf& bc, const BBuf& be, v4i (&accX)[4], v4i (&accY)[4]) {
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const v4i BA = {(int)ba.d[d].x, (int)ba.d[d].y, (int)ba.d[d].z, (int)ba.d[d].w};
-        const v4i BB = {(int)bb.d[d].x, (int)bb.d[d].y, (int)bb.d[d].z, (int)bb.d[d].w};
+        const v4i BC = {(int)bc.d[d].x, (int)bc.d[d].y, (int)bc.d[d].z, (int)bc.d[d].w};
+        const v4i BE = {(int)be.d[d].x, (int)be.d[d].y, (int)be.d[d].z, (int)be.d[d].w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t w = a.t[i][d];
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
             const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
-            xa[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BA, xa[i], 0, 0, 0);
-            xb[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BB, xb[i], 0, 0, 0);
+            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BC, accX[i], 0, 0, 0);
             const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
-            ya[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BA, ya[i], 0, 0, 0);
-            yb[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BB, yb[i], 0, 0, 0);
+            accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BE, accY[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// partial layout: [(ks * 4 + 2 v + plane) * rows_p + row] * 8 + digit, v = vector (0, 1), plane as in MODE 1
-__global__ __launch_bounds__(256, 2) void k_mfma_ax2(const u32x4* __restrict__ stripes, const u32x4* __restrict__ diga,
-                                                     const u32x4* __restrict__ digb, int64_t nrg, int64_t nkb, int ksplit,
+// partial layout: [(ks * 4 + 2 v + plane) * rows_p + row] * 8 + digit, v = vector (0, 1), plane 0 = r'.c, 1 = miss.e
+__global__ __launch_bounds__(256, 3) void k_mfma_ax2(const u32x4* __restrict__ stripes, const u32x4* __restrict__ digc,
+                                                     const u32x4* __restrict__ dige, int64_t nrg, int64_t nkb, int ksplit,
                                                      int32_t* __restrict__ partial) {
     constexpr int KBS = 256;
     const int lane = threadIdx.x & 63;
@@ -513,53 +511,45 @@ __global__ __launch_bounds__(256, 2) void k_mfma_ax2(const u32x4* __restrict__ s
     const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
     const int c = lane & 15, g = lane >> 4;
     const int bofs = g * 16 + c;
-    v4i xa[4], ya[4], xb[4], yb[4];
+    v4i accX[4], accY[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        xa[i] = (v4i){0, 0, 0, 0};
-        ya[i] = (v4i){0, 0, 0, 0};
-        xb[i] = (v4i){0, 0, 0, 0};
-        yb[i] = (v4i){0, 0, 0, 0};
+        accX[i] = (v4i){0, 0, 0, 0};
+        accY[i] = (v4i){0, 0, 0, 0};
     }
     const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
-    const u32x4* bpa = diga + kb0 * KBS + bofs;
-    const u32x4* bpb = digb + kb0 * KBS + bofs;
+    const u32x4* bpc = digc + kb0 * KBS + bofs;
+    const u32x4* bpe = dige + kb0 * KBS + bofs;
     const int64_t nsteps = kb1 - kb0;
     if (nsteps <= 0) return;
     const int64_t last = nsteps - 1;
     ABuf a0, a1, a2;
-    BBuf ba0, ba1, bb0, bb1;
+    BBuf bc0, bc1, be0, be1;
     load_a(a0, ap);
-    load_b<1>(ba0, bpa);
-    load_b<1>(bb0, bpb);
+    load_b<1>(bc0, bpc);
+    load_b<1>(be0, bpe);
     load_a(a1, ap + (last < 1 ? last : 1) * 256);
 #pragma unroll 1
     for (int64_t st = 0; st < nsteps; st++) {
         const int64_t n2 = st + 2 < last ? st + 2 : last, n1 = st + 1 < last ? st + 1 : last;
         load_a(a2, ap + n2 * 256);
-        load_b<1>(ba1, bpa + n1 * KBS);
-        load_b<1>(bb1, bpb + n1 * KBS);
-        compute_step2(a0, ba0, bb0, xa, ya, xb, yb);
+        load_b<1>(bc1, bpc + n1 * KBS);
+        load_b<1>(be1, bpe + n1 * KBS);
+        compute_step2(a0, bc0, be0, accX, accY);
         a0 = a1;
         a1 = a2;
-        ba0 = ba1;
-        bb0 = bb1;
+        bc0 = bc1;
+        be0 = be1;
     }
     const int64_t rows_p = nrg * 64;
-    const int cd = c & 7;
-    const bool lo = c < 8;
+    const int cd = c & 7, pv = (c >> 3) * 2;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
-            if (lo) {
-                partial[(((int64_t)ks * 4 + 0) * rows_p + row) * 8 + cd] = xa[i][reg];
-                partial[(((int64_t)ks * 4 + 2) * rows_p + row) * 8 + cd] = xb[i][reg];
-            } else {
-                partial[(((int64_t)ks * 4 + 1) * rows_p + row) * 8 + cd] = ya[i][reg];
-                partial[(((int64_t)ks * 4 + 3) * rows_p + row) * 8 + cd] = yb[i][reg];
-            }
+            partial[(((int64_t)ks * 4 + pv + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
+            partial[(((int64_t)ks * 4 + pv + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
         }
     }
 }
@@ -677,11 +667,11 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
     const int qb = nblk(pl.nkb_n * 64, 256);
     for (int v = 0; v < 2; v++) {   // cv / ev are reused: vector b is prepared after vector a's digits are written
         double* sc = pl.scal + 4 * v;
-        void* dg = v ? pl.dig1 : pl.dig0;
         hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, v ? xb : xa, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
         hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, sc);
-        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, sc, (uint32_t*)dg, 16, 0);
-        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, sc, (uint32_t*)dg, 16, 8);
+        // dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
+        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig0, 16, 8 * v);
+        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig1, 16, 8 * v);
     }
     int64_t waves = pl.nrg_n * pl.ks_n;
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
