@@ -1,0 +1,64 @@
+"""Summarise the rocprofv3 PMC passes of bench.py into profiles/ (development tool).
+
+usage: python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r1 [N Mt]
+
+Reads <dir>/bench_counter_collection.csv of the two separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE), averages
+the counters per kernel and writes <prefix>_pmc_summary.csv and <prefix>_pmc_traffic.json.  HBM bytes per launch follow
+MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KB on gfx950 and FETCH_SIZE counts wide streaming reads at
+one half, so hbm_bytes = 2 * FETCH_SIZE_KB * 1024 + WRITE_SIZE_KB * 1024.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(path + "/bench_counter_collection.csv") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            a = acc[row["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    return {k: (n, s / n) for k, (n, s) in acc.items()}
+
+
+def main():
+    fdir, wdir, prefix = sys.argv[1:4]
+    N = int(sys.argv[4]) if len(sys.argv) > 4 else 400000
+    Mt = int(sys.argv[5]) if len(sys.argv) > 5 else 1000000
+    fetch = per_kernel(fdir, "FETCH_SIZE")
+    write = per_kernel(wdir, "WRITE_SIZE")
+    with open(prefix + "_pmc_summary.csv", "w") as f:
+        f.write("counter,kernel,dispatches,avg_value_KB\n")
+        for name, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            for k, (n, v) in sorted(tab.items(), key=lambda kv: -kv[1][1] * kv[1][0]):
+                f.write('%s,"%s",%d,%.3f\n' % (name, k[:110].replace('"', "'"), n, v))
+
+    def pick(tab, frag):
+        for k, v in tab.items():
+            if frag in k:
+                return v[1]
+        return None
+
+    out = {
+        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 "
+                "--no-cpu-baseline --vamp-iterations 2`; hbm_bytes = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950: "
+                "FETCH_SIZE counts wide streaming reads at half, MI355X_MICROARCH.md section HBM)",
+        "N": N, "Mt": Mt, "n_gpus": 1, "kernel_mode": 1,
+    }
+    for key, frag in (("ax", "k_mfma_matvec<1>"), ("atx", "k_mfma_matvec<0>"), ("ax2", "k_mfma_ax2"),
+                      ("atx2", "k_mfma_matvec<2>")):
+        fk, wk = pick(fetch, frag), pick(write, frag)
+        if fk is None or wk is None:
+            continue
+        out[key] = {"fetch_KB": round(fk, 3), "write_KB": round(wk, 3), "hbm_bytes": int(2 * fk * 1024 + wk * 1024)}
+    with open(prefix + "_pmc_traffic.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
