@@ -1,0 +1,97 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need the oracle to walk the whole matrix.
+
+* sampled columns: the synthetic .bed generator is an integer hash of (marker, individual), so any marker of the
+  400 000 x 1 000 000 matrix can be regenerated on the host on its own.  Marker statistics, A^T p and A x (x supported
+  on the sample) of the full-size resident shard are compared with the oracle run on just those markers;
+* adjoint identity <Ax, p> == <x, A^T p>: Ax reads the individual-major stripes, ATx the marker-major ones, so this
+  cross-checks the two independently built layouts over every byte;
+* linearity, bitwise reproducibility, and the two-vector kernels against the one-vector ones;
+* config 2 (N=100k x M=500k, CG-max-iter 50): a VAMP run is reproducible, identical with and without shared passes,
+  and recovers the simulated effects.
+"""
+import numpy as np
+import pytest
+
+from gvamp_amd import capi, hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_config3_full_matrix_sampled_columns_adjoint_linearity(oracle):
+    N, Mt, seed, miss = 400000, 1000000, 20240601, 5000
+    rng = np.random.default_rng(5)
+    sample = np.array([0, 1, 63, 64, 255, 256, 32767, 32768, 65535, 499999, 500000, 524288, 777777, 999998, 999999])
+    mini = np.concatenate([synth.synth_bed(N, 1, seed=seed, miss_ppm=miss, S=int(j)) for j in sample])
+    o_mave, o_msig = oracle.marker_stats(mini, N, len(sample))
+    with capi.Shard(N, Mt) as sh:
+        sh.set_layout(False, True)          # stripes only: 2 x 100 GB resident
+        sh.set_kernel_mode(1)
+        sh.synth_bed(seed, miss)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        assert np.allclose(mave[sample], o_mave, rtol=1e-13, atol=1e-15)
+        # the oracle (like data.cpp:392-546) accumulates 400 000 fp64 terms serially; the product derives the
+        # statistics from exact genotype counts, so the difference is the oracle's own rounding (~N eps)
+        assert np.allclose(msig[sample], o_msig, rtol=1e-10, atol=0)
+
+        # A^T p on the sampled markers
+        p = rng.standard_normal(N)
+        w = sh.ATx(p)
+        ow = oracle.atx(mini, N, len(sample), o_mave, o_msig, p)
+        assert rel(w[sample], ow) < 1e-10
+
+        # A x with x supported on the sample = the oracle's Ax over just those columns
+        xs = rng.standard_normal(len(sample))
+        x = np.zeros(Mt)
+        x[sample] = xs
+        z = sh.Ax(x)
+        oz = oracle.ax(mini, N, len(sample), o_mave, o_msig, xs)
+        assert rel(z, oz) < 1e-10
+
+        # adjoint identity and linearity with dense vectors over the whole 100 GB
+        x1, x2 = rng.standard_normal(Mt), rng.standard_normal(Mt)
+        z1, z2 = sh.Ax(x1), sh.Ax(x2)
+        lhs, rhs = float(z1 @ p), float(x1 @ w)
+        assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+        assert rel(sh.Ax(2.5 * x1 - 0.75 * x2), 2.5 * z1 - 0.75 * z2) < 1e-12
+        assert np.array_equal(sh.Ax(x1), z1) and np.array_equal(sh.ATx(p), w)      # integer accumulation
+
+        # two-vector passes equal the one-vector ones bit for bit
+        va, vb, oa, ob = sh.vecM(x1), sh.vecM(x2), sh.vecN(), sh.vecN()
+        sh.ax2_dev(va, vb, oa, ob)
+        assert np.array_equal(oa.download()[:N], z1[:N]) and np.array_equal(ob.download()[:N], z2[:N])
+        pa, pb, wa, wb = sh.vecN(p), sh.vecN(z1), sh.vecM(), sh.vecM()
+        sh.atx2_dev(pa, pb, wa, wb)
+        assert np.array_equal(wa.download(), w)
+        assert np.array_equal(wb.download(), sh.ATx(z1))
+
+
+def test_config2_vamp_run_properties():
+    N, M, CV = 100000, 500000, 5000
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(False, True)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(424242, 5000)
+        sh.compute_markers_statistics()
+        beta, y = hostapi.sim_phen(sh, 0.5, CV, 7)
+        kw = dict(iterations=4, CG_max_iter=50, rho=0.5, seed=7, true_signal=beta, history=False)
+        r1 = hostapi.infere_linear(sh, y, None, None, fuse_solves=1, **kw)
+        r0 = hostapi.infere_linear(sh, y, None, None, fuse_solves=0, **kw)
+        r2 = hostapi.infere_linear(sh, y, None, None, fuse_solves=1, **kw)
+    assert r1.niter == r0.niter == 4
+    assert np.array_equal(r1.x_est, r2.x_est)                     # reproducible run to run
+    assert np.array_equal(r1.x_est, r0.x_est)                     # shared passes change no bit
+    for a, b in zip(r1.trace, r0.trace):
+        assert a["cg_iters"] == b["cg_iters"] and a["onsager_iters"] == b["onsager_iters"]
+        assert a["n_ax"] == b["n_ax"] and a["n_atx"] == b["n_atx"]
+        assert a["n_ax_pass"] < b["n_ax_pass"] and a["n_atx_pass"] < b["n_atx_pass"]
+        assert 0 < a["cg_iters"] <= 50
+    # the estimate explains the simulated effects: correlation with the truth and a sane noise precision
+    # (h2 = 0.5 on a standardised phenotype: gamw -> 1 / (1 - h2) = 2)
+    c = np.corrcoef(r1.x_est, beta)[0, 1]
+    assert c > 0.5
+    assert 1.5 < r1.trace[-1]["gamw"] < 2.6
