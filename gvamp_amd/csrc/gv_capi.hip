@@ -415,13 +415,16 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     pl.M = M; pl.N = N;
     pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
     pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
-    // K-splits per row group.  Measured on MI355X (N=400k): ~45k waves per launch (~15 rounds of the 3 x 1024 resident
-    // waves) hide the tail, but a wave should keep >= 256 K-blocks (1 MiB of stripes) to amortise its prologue,
-    // epilogue and partial sums: Mt=1M -> ks 3 (ATx) / 7 (Ax) = 6.5 / 6.2 TB/s; M=125k -> ks 6 / 1.
+    // K-splits.  A launch is ceil(nrg / 4) * ks workgroups, each walking nkb / ks K-blocks.  Measured on MI355X (N=400k,
+    // sweeps with GV_KS_M / GV_KS_N): a workgroup should keep ~768 K-blocks (3 MiB of stripes per wave) to amortise its
+    // prologue, epilogue and partial sums, as long as the launch still has one full round (256 CUs x 3) of workgroups:
+    // Mt=1M -> ks 2 (ATx) / 5 (Ax), M=125k -> 2 / 1; more splits cost 1-4 %, fewer leave a tail.
     auto pick_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks) {
-        int64_t ks = nrg > 0 ? (45056 + nrg / 2) / nrg : 1;
-        const int64_t cap = (nkb + 128) / 256 > 1 ? (nkb + 128) / 256 : 1;
-        if (ks > cap) ks = cap;
+        const int64_t nq = (nrg + 3) / 4;
+        int64_t ks = (nkb + 384) / 768;
+        const int64_t fill = nq > 0 ? (768 + nq - 1) / nq : 1;      // splits needed for one round of workgroups ...
+        const int64_t fill_cap = nkb / 64 > 1 ? nkb / 64 : 1;       // ... but never below 64 K-blocks per workgroup
+        if (ks < (fill < fill_cap ? fill : fill_cap)) ks = fill < fill_cap ? fill : fill_cap;
         if (ks < min_ks) ks = min_ks;
         if (ks > 64) ks = 64;
         if (ks > nkb) ks = nkb;

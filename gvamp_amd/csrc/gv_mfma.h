@@ -9,7 +9,7 @@ struct Plan {
     int64_t M = 0, N = 0;
     int64_t nrg_m = 0, nkb_m = 0;   // stripes_m: row groups of 64 markers x K-blocks of 256 individuals
     int64_t nrg_n = 0, nkb_n = 0;   // stripes_n: row groups of 64 individuals x K-blocks of 256 markers
-    int ks_m = 1, ks_n = 1;         // K-splits (waves per row group)
+    int ks_m = 1, ks_n = 1;         // K-splits (workgroups per group of 4 row groups)
     void* stripes_m = nullptr;
     void* stripes_n = nullptr;
     void* dig0 = nullptr;           // digit buffers, max(nkb_m, nkb_n) * 2048 bytes each

@@ -257,66 +257,99 @@ __global__ __launch_bounds__(256) void k_quant(const double* __restrict__ v, int
 }
 
 // ---- the matvec kernel ----------------------------------------------------------------------------------------------
-// One kernel for both products.  Per K-block (256 K-entries) a wave reads its supertile (4 tiles x 1 KiB, streamed
-// once, non-temporal) and ONE digit block, and issues per (tile, dword) two MFMAs: plane r' -> accX, plane miss -> accY.
-//   MODE 0 (ATx): digit block = digits(p), 8 columns (2 KiB); lanes c >= 8 alias column c-8 (their results are
-//                 never stored).  result rows: X = accX[:, 0:8], Y = accY[:, 0:8].
-//   MODE 1 (Ax):  digit block = [digits(c) | digits(e)], 16 columns (4 KiB).  r'.c comes out in accX[:, 0:8] and
-//                 miss.e in accY[:, 8:16]; both are stored as two "planes" and added (exactly) by k_fin_ax.
-// Software pipeline in registers: NA = 3 supertile buffers (two K-blocks in flight from HBM) and NB = 2 digit
-// buffers (one in flight from L2).  No LDS, no cross-lane traffic, no barriers in the loop.
+// One kernel for all products.  A workgroup = 4 waves = 4 consecutive row groups (64 rows each) over the SAME K range.
+// Per K-block (256 K-entries) each wave reads its own supertile (4 tiles x 1 KiB, streamed once, non-temporal) and the
+// workgroup reads ONE digit block; per (tile, dword) a wave issues two MFMAs: plane r' -> accX, plane miss -> accY.
+//   MODE 0 (ATx):  digit block = digits(p), 8 columns (2 KiB); lanes c >= 8 alias column c-8 (their results are never
+//                  stored).  result rows: X = accX[:, 0:8], Y = accY[:, 0:8].
+//   MODE 1 (Ax):   digit block = [digits(c) | digits(e)], 16 columns (4 KiB).  r'.c comes out in accX[:, 0:8] and
+//                  miss.e in accY[:, 8:16]; both are stored as two "planes" and added (exactly) by k_fin_ax.
+//   MODE 2 (two N-vectors, ATx / p-value sums): [digits(p_a) | digits(p_b)]; columns 0..7 / 8..15 = vector a / b.
+//   MODE 3 (two M-vectors, Ax): the r' plane multiplies dig0 = [c_a | c_b], the miss plane dig1 = [e_a | e_b] (8 KiB):
+//                  vector a = accX[:, 0:8] + accY[:, 0:8], vector b = accX[:, 8:16] + accY[:, 8:16].
+// The LMMSE solve and the Onsager probe solve of one VAMP iteration are CG runs on the SAME operator (vamp.cpp:593-596
+// and :884); MODE 2 / 3 let their matvecs share the stream over the genotype shard at the cost of one.
+//
+// Pipeline.  Stripes: three supertile register buffers, two K-blocks in flight from HBM per wave, three waves per SIMD.
+// Digits: fetched once per WORKGROUP (16-32 B per thread), parked in a two-stage LDS ring, read back with one
+// ds_read_b128 per dword-slot -- a wave fetching its own copy from L2 (the first version of this kernel) put 1.5-3x the
+// HBM stream on the vector-memory path and cost 6 % (MODE 1) to 25 % (MODE 3).  One workgroup barrier per K-block: a
+// bare s_barrier behind an LDS-only fence, so the stripe prefetches (vmcnt) stay in flight across it.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ABuf { u32x4 t[4]; };
-struct BBuf { u32x4 d[4]; };
 
 __device__ __forceinline__ void load_a(ABuf& a, const u32x4* __restrict__ ap) {
 #pragma unroll
     for (int i = 0; i < 4; i++) a.t[i] = __builtin_nontemporal_load(ap + i * 64);
 }
+
 template <int MODE>
-__device__ __forceinline__ void load_b(BBuf& b, const u32x4* __restrict__ bp) {
-    constexpr int DS = (MODE == 0) ? 32 : 64;   // u32x4 per dword-slot d
+struct BFrag { u32x4 d[4]; u32x4 e[MODE == 3 ? 4 : 1]; };
+
+template <int MODE>
+__device__ __forceinline__ void lds_read_b(BFrag<MODE>& b, const u32x4* sb, int bofs) {
+    constexpr int DS = (MODE == 0) ? 32 : 64;
 #pragma unroll
-    for (int d = 0; d < 4; d++) b.d[d] = bp[d * DS];
+    for (int d = 0; d < 4; d++) b.d[d] = sb[d * DS + bofs];
+    if (MODE == 3) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) b.e[d] = sb[256 + d * 64 + bofs];
+    }
 }
 
-__device__ __forceinline__ void compute_step(const ABuf& a, const BBuf& b, v4i (&accX)[4], v4i (&accY)[4]) {
+template <int MODE>
+__device__ __forceinline__ void compute_step(const ABuf& a, const BFrag<MODE>& b, v4i (&accX)[4], v4i (&accY)[4]) {
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const v4i B = {(int)b.d[d].x, (int)b.d[d].y, (int)b.d[d].z, (int)b.d[d].w};
+        const v4i BX = {(int)b.d[d].x, (int)b.d[d].y, (int)b.d[d].z, (int)b.d[d].w};
+        const u32x4 be = (MODE == 3) ? b.e[d] : b.d[d];
+        const v4i BY = {(int)be.x, (int)be.y, (int)be.z, (int)be.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t w = a.t[i][d];
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
             const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
-            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B, accX[i], 0, 0, 0);
-            // byte LUT {0,0,0,1}: selector byte value 3 (missing) -> 1
+            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BX, accX[i], 0, 0, 0);
             const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
-            accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B, accY[i], 0, 0, 0);
+            accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BY, accY[i], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the X/Y operand live ranges inside one dword-slot
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// partial layout: [(ks * 2 + plane) * rows_p + row] * 8 + digit   (int32), rows_p = 64 * nrg
+__device__ __forceinline__ void wg_barrier_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// grid: ceil(nrg / 4) * ksplit workgroups.
+// partial layout (int32): [(ks * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1) or 4 (MODE 2, 3:
+// planes 2v, 2v+1 belong to vector v)
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig,
-                                                     int64_t nrg, int64_t nkb, int ksplit,
-                                                     int32_t* __restrict__ partial) {
-    constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of the digit buffer
-    const int lane = threadIdx.x & 63;
-    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wg >= nrg * ksplit) return;
-    const int64_t rg = wg % nrg;
-    const int ks = (int)(wg / nrg);
+__global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
+                                                 const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
+                                                 int32_t* __restrict__ partial) {
+    constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
+    constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
+    __shared__ u32x4 sB[2][SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t nq = (nrg + 3) >> 2;
+    const int64_t q = (int64_t)blockIdx.x % nq;
+    const int ks = (int)((int64_t)blockIdx.x / nq);
+    int64_t rg = q * 4 + (tid >> 6);
+    const bool live = rg < nrg;      // a dead wave still loads digits and meets the barriers; it re-reads the last row group
+    if (!live) rg = nrg - 1;
     const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
+    const int64_t nsteps = kb1 - kb0;   // uniform over the workgroup
+    if (nsteps <= 0) return;
     const int c = lane & 15, g = lane >> 4;
-    const int bofs = (MODE == 0) ? g * 8 + (c & 7) : g * 16 + c;
+    const int bofs = (MODE == 0) ? g * 8 + (c & 7) : lane;
 
     v4i accX[4], accY[4];
 #pragma unroll
@@ -325,30 +358,61 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         accY[i] = (v4i){0, 0, 0, 0};
     }
     const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
-    const u32x4* bp = dig + kb0 * KBS + bofs;
-    const int64_t nsteps = kb1 - kb0;
-    if (nsteps <= 0) return;   // cannot happen (ksplit <= nkb); rows of an empty range would stay unwritten
-    // Unconditional, clamped prefetch (no branches around loads): the tail re-reads the last K-block.
+    // MODE 0: the block is 128 pieces; threads 128..255 copy pieces 0..127 again into the unused half of the stage, so
+    // that the copy has no divergent branch (the loop body stays one basic block)
+    const u32x4* g0 = dig0 + kb0 * KBS + (MODE == 0 ? (tid & 127) : tid);
+    const u32x4* g1 = (MODE == 3) ? dig1 + kb0 * KBS + tid : nullptr;
     const int64_t last = nsteps - 1;
+
     ABuf a0, a1, a2;
-    BBuf b0, b1;
+    u32x4 r0, r1;
+    r0 = g0[0];
+    if (MODE == 3) r1 = g1[0];
     load_a(a0, ap);
-    load_b<MODE>(b0, bp);
     load_a(a1, ap + (last < 1 ? last : 1) * 256);
+    sB[0][tid] = r0;
+    if (MODE == 3) sB[0][256 + tid] = r1;
+    wg_barrier_lds();
+
+    // One step: prefetch the digits of K-block S+1 and the stripes of K-block S+2 (clamped: no branches around loads),
+    // multiply K-block S out of CUR and LDS stage S&1, park the digits in the other stage, meet the workgroup.
+    // vmcnt retires in order: the digit load is issued BEFORE the 4 stripe loads so that the ds_write waits for it only.
+#define GV_WG_STEP(CUR, NXT, S)                                                        \
+    {                                                                                  \
+        const int64_t sv = (S);                                                        \
+        const int64_t n2 = sv + 2 < last ? sv + 2 : last, n1 = sv + 1 < last ? sv + 1 : last; \
+        r0 = g0[n1 * KBS];                                                             \
+        if (MODE == 3) r1 = g1[n1 * KBS];                                              \
+        load_a(NXT, ap + n2 * 256);                                                    \
+        BFrag<MODE> bf;                                                                \
+        lds_read_b<MODE>(bf, sB[sv & 1], bofs);                                        \
+        compute_step<MODE>(CUR, bf, accX, accY);                                     \
+        u32x4* sw = sB[(sv + 1) & 1];                                                  \
+        sw[tid] = r0;                                                                  \
+        if (MODE == 3) sw[256 + tid] = r1;                                             \
+        wg_barrier_lds();                                                              \
+    }
+    // nsteps % 3 leading steps rotate the three supertile buffers by register moves; the main loop rotates them by NAME
+    // (three steps per trip, one basic block), so a stripe load is only waited for two steps after it was issued.
+    int64_t st = 0;
+    const int64_t rem = nsteps % 3;
 #pragma unroll 1
-    for (int64_t st = 0; st < nsteps; st++) {
-        const int64_t n2 = st + 2 < last ? st + 2 : last, n1 = st + 1 < last ? st + 1 : last;
-        load_a(a2, ap + n2 * 256);
-        load_b<MODE>(b1, bp + n1 * KBS);
-        compute_step(a0, b0, accX, accY);
+    for (; st < rem; st++) {
+        GV_WG_STEP(a0, a2, st)
         a0 = a1;
         a1 = a2;
-        b0 = b1;
     }
+#pragma unroll 1
+    for (; st < nsteps; st += 3) {
+        GV_WG_STEP(a0, a2, st)
+        GV_WG_STEP(a1, a0, st + 1)
+        GV_WG_STEP(a2, a1, st + 2)
+    }
+#undef GV_WG_STEP
+    if (!live) return;
     const int64_t rows_p = nrg * 64;
     const int cd = c & 7;
-    if (MODE == 2) {
-        // two vectors: planes 0/1 = X/Y of vector 1 (columns 0..7), planes 2/3 = X/Y of vector 2 (columns 8..15)
+    if (MODE >= 2) {
         const int pv = (c >> 3) * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -361,8 +425,8 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         }
         return;
     }
-    const bool stX = c < 8;                         // accX: digit columns 0..7
-    const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);   // accY: columns 0..7 (ATx) or 8..15 (Ax, digits of e)
+    const bool stX = c < 8;
+    const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -469,92 +533,18 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     out[n] = (T - scal[1]) * post;
 }
 
-// ---- two vectors per pass ---------------------------------------------------------------------------------------------
-// The LMMSE solve and the Onsager probe solve of one VAMP iteration are CG runs on the SAME operator
-// (vamp.cpp:593-596 and :884), so their matvecs can share the stream over the genotype shard.
-//   ATx of two N-vectors: k_mfma_matvec<2> -- digits(p_a) in columns 0..7, digits(p_b) in columns 8..15: free.
-//   Ax of two M-vectors: k_mfma_ax2 -- the r' plane multiplies the digit block [c_a | c_b], the miss plane the block
-//   [e_a | e_b]: still two MFMAs per (tile, dword), now with all 16 columns of both in use (the one-vector kernel
-//   wastes half of each).  Vector a = accX[:, 0:8] + accY[:, 0:8], vector b = accX[:, 8:16] + accY[:, 8:16].
-__device__ __forceinline__ void compute_step2(const ABuf& a, const BBuf& bc, const BBuf& be, v4i (&accX)[4], v4i (&accY)[4]) {
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const v4i BC = {(int)bc.d[d].x, (int)bc.d[d].y, (int)bc.d[d].z, (int)bc.d[d].w};
-        const v4i BE = {(int)be.d[d].x, (int)be.d[d].y, (int)be.d[d].z, (int)be.d[d].w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t w = a.t[i][d];
-            const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
-                           e3 = (w >> 6) & 0x03030303u;
-            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
-            accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BC, accX[i], 0, 0, 0);
-            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
-            accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BE, accY[i], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// partial layout: [(ks * 4 + 2 v + plane) * rows_p + row] * 8 + digit, v = vector (0, 1), plane 0 = r'.c, 1 = miss.e
-__global__ __launch_bounds__(256, 3) void k_mfma_ax2(const u32x4* __restrict__ stripes, const u32x4* __restrict__ digc,
-                                                     const u32x4* __restrict__ dige, int64_t nrg, int64_t nkb, int ksplit,
-                                                     int32_t* __restrict__ partial) {
-    constexpr int KBS = 256;
-    const int lane = threadIdx.x & 63;
-    const int64_t wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wg >= nrg * ksplit) return;
-    const int64_t rg = wg % nrg;
-    const int ks = (int)(wg / nrg);
-    const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
-    const int c = lane & 15, g = lane >> 4;
-    const int bofs = g * 16 + c;
-    v4i accX[4], accY[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        accX[i] = (v4i){0, 0, 0, 0};
-        accY[i] = (v4i){0, 0, 0, 0};
-    }
-    const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
-    const u32x4* bpc = digc + kb0 * KBS + bofs;
-    const u32x4* bpe = dige + kb0 * KBS + bofs;
-    const int64_t nsteps = kb1 - kb0;
-    if (nsteps <= 0) return;
-    const int64_t last = nsteps - 1;
-    ABuf a0, a1, a2;
-    BBuf bc0, bc1, be0, be1;
-    load_a(a0, ap);
-    load_b<1>(bc0, bpc);
-    load_b<1>(be0, bpe);
-    load_a(a1, ap + (last < 1 ? last : 1) * 256);
-#pragma unroll 1
-    for (int64_t st = 0; st < nsteps; st++) {
-        const int64_t n2 = st + 2 < last ? st + 2 : last, n1 = st + 1 < last ? st + 1 : last;
-        load_a(a2, ap + n2 * 256);
-        load_b<1>(bc1, bpc + n1 * KBS);
-        load_b<1>(be1, bpe + n1 * KBS);
-        compute_step2(a0, bc0, be0, accX, accY);
-        a0 = a1;
-        a1 = a2;
-        bc0 = bc1;
-        be0 = be1;
-    }
-    const int64_t rows_p = nrg * 64;
-    const int cd = c & 7, pv = (c >> 3) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
-            partial[(((int64_t)ks * 4 + pv + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
-            partial[(((int64_t)ks * 4 + pv + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
-        }
-    }
-}
-
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+// launch of the streaming kernel of one matvec (HIP events around it when the roofline timing is on)
+template <int MODE>
+void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, const void* dig0, const void* dig1, int64_t nrg,
+                   int64_t nkb, int ks) {
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    const int64_t nq = (nrg + 3) / 4;
+    hipLaunchKernelGGL(k_mfma_matvec<MODE>, dim3((unsigned)(nq * ks)), dim3(256), 0, s, (const u32x4*)stripes,
+                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, ks, pl.partial);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+}
 
 }  // namespace
 
@@ -591,11 +581,7 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
     hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p, npad, pl.nkb_m, pl.scal,
                        (uint32_t*)pl.dig0, 8, 0);
-    int64_t waves = pl.nrg_m * pl.ks_m;
-    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
-    hipLaunchKernelGGL(k_mfma_matvec<0>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
-                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
-    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, out, 2, 0);
 }
@@ -612,11 +598,7 @@ void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int
                        (uint32_t*)pl.dig0, 16, 0);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, pb, npad, pl.nkb_m, pl.scal + 4,
                        (uint32_t*)pl.dig0, 16, 8);
-    int64_t waves = pl.nrg_m * pl.ks_m;
-    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
-    hipLaunchKernelGGL(k_mfma_matvec<2>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
-                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
-    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, outa, 4, 0);
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
@@ -635,9 +617,11 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
                        (uint32_t*)pl.dig0, 16, 0);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p2, npad, pl.nkb_m, pl.scal + 4,
                        (uint32_t*)pl.dig0, 16, 8);
-    int64_t waves = pl.nrg_m * pl.ks_m;
-    hipLaunchKernelGGL(k_mfma_matvec<2>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_m,
-                       (const u32x4*)pl.dig0, pl.nrg_m, pl.nkb_m, pl.ks_m, pl.partial);
+    {
+        gvm::Plan q = pl;      // no roofline events around the p-value pass
+        q.ev0 = q.ev1 = nullptr;
+        launch_stream<2>(s, q, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
+    }
     hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
                        pl.scal, pl.scal + 4, out4);
 }
@@ -651,11 +635,7 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
                        (uint32_t*)pl.dig0, 16, 0);
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, pl.scal,
                        (uint32_t*)pl.dig0, 16, 8);
-    int64_t waves = pl.nrg_n * pl.ks_n;
-    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
-    hipLaunchKernelGGL(k_mfma_matvec<1>, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_n,
-                       (const u32x4*)pl.dig0, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
-    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
                        pl.scal, mask2, post, out, 2, 0);
 }
@@ -673,11 +653,7 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
         hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig0, 16, 8 * v);
         hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig1, 16, 8 * v);
     }
-    int64_t waves = pl.nrg_n * pl.ks_n;
-    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
-    hipLaunchKernelGGL(k_mfma_ax2, dim3(nblk(waves, 4)), dim3(256), 0, s, (const u32x4*)pl.stripes_n, (const u32x4*)pl.dig0,
-                       (const u32x4*)pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n, pl.partial);
-    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n);
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
                        pl.scal, mask2, post, outa, 4, 0);
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,

@@ -13,10 +13,13 @@ ap.add_argument("--N", type=int, default=100000)
 ap.add_argument("--M", type=int, default=100000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--mode", type=int, default=0)
+ap.add_argument("--stripes-only", type=int, default=0)
 a = ap.parse_args()
 
 with capi.Shard(a.N, a.M) as sh:
     t = time.time()
+    if a.stripes_only:
+        sh.set_layout(False, True)
     sh.synth_bed(1234, 5000)
     sh.compute_markers_statistics()
     print("synth+stats s", time.time() - t, flush=True)
@@ -38,3 +41,13 @@ with capi.Shard(a.N, a.M) as sh:
     print(c)
     print("Ax  ms %.3f  GB/s %.1f" % (c["ms_ax"] / c["n_ax"], nbytes / (c["ms_ax"] / c["n_ax"] * 1e-3) / 1e9))
     print("ATx ms %.3f  GB/s %.1f" % (c["ms_atx"] / c["n_atx"], nbytes / (c["ms_atx"] / c["n_atx"] * 1e-3) / 1e9))
+    # two-vector passes
+    x2, p2, w2 = sh.vecM(rng.standard_normal(a.M)), sh.vecN(), sh.vecM()
+    sh.ax2_dev(x, x2, p, p2); sh.atx2_dev(p, p2, w, w2); sh.synchronize()
+    sh.counters(reset=True)
+    for _ in range(a.reps):
+        sh.ax2_dev(x, x2, p, p2)
+        sh.atx2_dev(p, p2, w, w2)
+    c = sh.counters()
+    print("Ax2  ms %.3f  (x2 vectors) GB/s per pass %.1f" % (c["ms_ax"] / a.reps, nbytes / (c["ms_ax"] / a.reps * 1e-3) / 1e9))
+    print("ATx2 ms %.3f  (x2 vectors) GB/s per pass %.1f" % (c["ms_atx"] / a.reps, nbytes / (c["ms_atx"] / a.reps * 1e-3) / 1e9))
