@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--cpu-markers", type=int, default=0, help="markers of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--vamp-iterations", type=int, default=5, help="VAMP iterations of the iters/s leg (0 = skip)")
     ap.add_argument("--CG-max-iter", type=int, default=50)
+    ap.add_argument("--fuse-solves", type=int, default=2,
+                    help="0 = the reference's sequence of matvecs, 1 = LMMSE and Onsager CG share passes (bit-identical), "
+                         "2 = also z1 rides in a free slot and A x2_hat / A^T A invQ u come out of the CG recurrences")
     return ap.parse_args()
 
 
@@ -213,41 +216,60 @@ def main():
         p.free(); d.free()
         CV = max(1, Mt // 100)
         beta, y = hostapi.sim_phen(sh, 0.5, CV, 1, rank=rank)                 # sim.cpp recipe, h2 = 0.5, seed 1
-        barrier()
-        t1 = time.perf_counter()
-        r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5,
-                                  seed=1, gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank)
-        sh.synchronize()
-        t_total = time.perf_counter() - t1
-        its = r.trace
-        tail = its[1:] if len(its) > 1 else its                               # iteration 1 has a cold CG
-        secs = [t["seconds"] for t in tail]
-        if world > 1:
-            tt = torch.tensor([sum(secs)], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tot = float(tt.item())
-        else:
-            tot = sum(secs)
-        out["vamp"] = {
-            "iters_per_s": round(len(tail) / tot, 4) if tot > 0 else None,
-            "seconds_per_iter": [round(t["seconds"], 4) for t in its], "wall_s_all_iterations": round(t_total, 3),
-            "n_ax": [t["n_ax"] for t in its], "n_atx": [t["n_atx"] for t in its],
-            "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
-            "cg_iters": [t["cg_iters"] for t in its], "onsager_iters": [t["onsager_iters"] for t in its],
-            "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "L_after": [t["L_after"] for t in its],
-            "config": "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, "
-                      "%d iterations; iters/s over iterations 2.., file output off; n_ax / n_atx = vector products, "
-                      "n_*_pass = passes over the genotype shard (the LMMSE and the Onsager CG share passes)"
-                      % (CV, a.CG_max_iter, len(its)),
-        }
+
+        def vamp_leg(fuse):
+            barrier()
+            t1 = time.perf_counter()
+            r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5,
+                                      seed=1, gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank,
+                                      fuse_solves=fuse)
+            sh.synchronize()
+            t_total = time.perf_counter() - t1
+            its = r.trace
+            tail = its[1:] if len(its) > 1 else its                           # iteration 1 has a cold CG
+            secs = [t["seconds"] for t in tail]
+            if world > 1:
+                tt = torch.tensor([sum(secs)], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tot = float(tt.item())
+            else:
+                tot = sum(secs)
+            return r, {
+                "iters_per_s": round(len(tail) / tot, 4) if tot > 0 else None, "fuse_solves": fuse,
+                "seconds_per_iter": [round(t["seconds"], 4) for t in its], "wall_s_all_iterations": round(t_total, 3),
+                "n_ax": [t["n_ax"] for t in its], "n_atx": [t["n_atx"] for t in its],
+                "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
+                "cg_iters": [t["cg_iters"] for t in its], "onsager_iters": [t["onsager_iters"] for t in its],
+                "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "L_after": [t["L_after"] for t in its],
+            }
+
+        r, out["vamp"] = vamp_leg(a.fuse_solves)
+        out["vamp"]["config"] = (
+            "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, %d iterations; "
+            "iters/s over iterations 2.., file output off; n_ax / n_atx = explicit vector products, n_*_pass = passes over "
+            "the genotype shard.  fuse_solves %d (DESIGN.md section 5); `reference_sequence` = the same run issuing the "
+            "reference's own sequence of products (fuse_solves 0), x_hat agreement between the two in `x_hat_rel_l2`"
+            % (CV, a.CG_max_iter, len(r.trace), a.fuse_solves))
+        if a.fuse_solves != 0:
+            r0, v0 = vamp_leg(0)
+            keep = ("iters_per_s", "seconds_per_iter", "n_ax", "n_atx", "n_ax_pass", "n_atx_pass", "cg_iters", "onsager_iters")
+            out["vamp"]["reference_sequence"] = {k: v0[k] for k in keep}
+            num = float(np.linalg.norm(r.x_est - r0.x_est)) ** 2
+            den = float(np.linalg.norm(r0.x_est)) ** 2
+            if world > 1:
+                tt = torch.tensor([num, den], dtype=torch.float64)
+                dist.all_reduce(tt)
+                num, den = float(tt[0]), float(tt[1])
+            out["vamp"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
         if "vamp" in out and len(out["vamp"]["n_ax"]) > 1:
             f = Mt / cb["sample_markers"]       # CPU matvec time is linear in the number of markers at fixed N
-            v = out["vamp"]
+            v = out["vamp"].get("reference_sequence", out["vamp"])             # the reference's own matvec counts
             est = [(v["n_ax"][i] * cb["ax_s"] + v["n_atx"][i] * cb["atx_s"]) * f for i in range(1, len(v["n_ax"]))]
             cb["vamp_iter_s_extrapolated"] = round(sum(est) / len(est), 1)
-            cb["vamp_note"] = ("seconds per VAMP iteration the CPU port would need for the SAME matvec counts: "
+            cb["vamp_note"] = ("seconds per VAMP iteration the CPU port would need for the matvec counts of the reference "
+                               "sequence (vamp.reference_sequence): "
                                "(n_ax*t_ax + n_atx*t_atx) measured on the sample, scaled linearly by Mt/sample_markers")
         out["cpu_baseline"] = cb
     sh.close()

@@ -19,7 +19,8 @@ EXPORTS = [
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
-    "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_denoise", "gv_prior_estep",
+    "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
+    "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
 ]
@@ -32,6 +33,10 @@ class GvError(RuntimeError):
 class CgStats(C.Structure):
     _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("rel_res", C.c_double), ("onsager", C.c_double),
                 ("n_ax", C.c_int), ("n_atx", C.c_int), ("n_relres", C.c_int)]
+
+
+class CgExtras(C.Structure):
+    _fields_ = [("ride_x", C.c_void_p), ("ride_out", C.c_void_p), ("a_mu_a", C.c_void_p), ("ata_mu_b", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -90,6 +95,8 @@ def load():
     L.gv_atx2_dev.argtypes = [vp, vp, vp, vp, vp]
     L.gv_cg_solve2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
                                C.POINTER(CgStats), dp, dp]
+    L.gv_cg_solve2x.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
+                                C.POINTER(CgStats), dp, dp, C.POINTER(CgExtras)]
     L.gv_set_phen.argtypes = [vp, vp, dp]
     L.gv_lmmse_mult.argtypes = [vp, vp, C.c_double, C.c_double, vp]
     L.gv_cg_solve.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.POINTER(CgStats), dp]
@@ -308,6 +315,16 @@ class Shard:
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
         self._ck(self.L.gv_cg_solve2(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
                                      max_iter, mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb)))
+        return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
+
+    def cg_solve2x(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, ride_x=None, ride_out=None, a_mu_a=None,
+                   ata_mu_b=None):
+        """gv_cg_solve2 plus its pass-free by-products (include/gvamp.h: gv_cg_extras)."""
+        sa, sb = CgStats(), CgStats()
+        ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
+        ex = CgExtras(*[v.h if v is not None else None for v in (ride_x, ride_out, a_mu_a, ata_mu_b)])
+        self._ck(self.L.gv_cg_solve2x(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
+                                      max_iter, mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb), C.byref(ex)))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def denoise(self, r1, gam1, probs, vars_scaled, x1_out, d_out=None):

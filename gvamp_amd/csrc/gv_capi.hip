@@ -727,6 +727,10 @@ struct CgSys {
     int iters = 0, n_relres = 0, converged = 0;
     const double* req = nullptr;   // operand of the pending operator application
     double* res = nullptr;         // where its result goes
+    // by-products (gv_cg_solve2x)
+    double* az = nullptr;          // N-space: A mu, accumulated from the A p_k of the operator applications
+    const double* wslot = nullptr; // N-space buffer holding A req after the last application
+    bool keep_resid = false;       // keep r = v - Q mu exact on the Onsager-rule exit too
 };
 
 static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
@@ -757,6 +761,7 @@ static int cg_consume(gv_ctx* c, CgSys& s, double gam2, double diag, int max_ite
     hipStream_t st = c->stream;
     if (s.phase == 0) {                                                   // r = v - Q mu0 (:1142-1145)
         gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
+        if (s.az) HIPCHK(c, hipMemcpyAsync(s.az, s.wslot, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, st));   // A mu0
         KCHK(c);
         return cg_finish_init(c, s, diag, multi);
     }
@@ -771,6 +776,7 @@ static int cg_consume(gv_ctx* c, CgSys& s, double gam2, double diag, int max_ite
     if (multi && allreduce_scalars(c, &dp, 1)) return 1;
     const double alpha = s.rz / dp;                                       // :1167
     gvk::cg_step_a(st, s.mu, s.p, alpha, s.v, M, c->red_partial, c->red_out);   // mu += alpha p (:1169-1172)
+    if (s.az) gvk::axpby(st, s.az, 1.0, s.az, alpha, s.wslot, c->npad);  // A mu += alpha A p
     KCHK(c);
     if (s.denoiser == 0) {                                                // :1174-1193
         double vm;
@@ -779,6 +785,10 @@ static int cg_consume(gv_ctx* c, CgSys& s, double gam2, double diag, int max_ite
         s.onsager = gam2 * vm;
         const double oerr = (s.onsager != 0) ? fabs((s.onsager - s.prev_onsager) / s.onsager) : 1.0;
         if (oerr < 1e-8) {
+            if (s.keep_resid) {                                           // the reference leaves r one step behind here
+                gvk::axpby(st, s.r, 1.0, s.r, -alpha, s.d, M);
+                KCHK(c);
+            }
             s.converged = 1;
             s.active = false;
             return 0;
@@ -818,7 +828,10 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
     return 0;
 }
 
-static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter) {
+// ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
+// one system is still active (a two-vector pass costs what a one-vector pass costs), else by a pass of its own.
+static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x = nullptr,
+                  double* ride_out = nullptr) {
     const int64_t M = c->M;
     const bool multi = is_multi(c);
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
@@ -831,6 +844,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             s.res = s.r;
         } else {
             gvk::fill(c->stream, s.mu, M, 0.0);
+            if (s.az) gvk::fill(c->stream, s.az, c->npad, 0.0);
             HIPCHK(c, hipMemcpyAsync(s.r, s.v, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
             if (cg_finish_init(c, s, diag, multi)) return 1;
         }
@@ -844,14 +858,27 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
         if (na == 0) break;
         if (na == 2) {
             if (lmmse2_device(c, act[0]->req, act[1]->req, tau, gam2, act[0]->res, act[1]->res)) return 1;
-        } else if (lmmse_device(c, act[0]->req, tau, gam2, act[0]->res))
-            return 1;
+            act[0]->wslot = c->w_n->d;
+            act[1]->wslot = c->w_n2->d;
+        } else {
+            if (ride_x) {                                                 // Ax of the rider in the free slot
+                if (ensure_work(c)) return 1;
+                if (ax2_device(c, act[0]->req, ride_x, c->w_n->d, ride_out)) return 1;
+                if (atx_device(c, c->w_n->d, act[0]->res)) return 1;
+                gvk::axpby(c->stream, act[0]->res, tau, act[0]->res, gam2, act[0]->req, M);
+                KCHK(c);
+                ride_x = nullptr;
+            } else if (lmmse_device(c, act[0]->req, tau, gam2, act[0]->res))
+                return 1;
+            act[0]->wslot = c->w_n->d;
+        }
         for (int k = 0; k < na; k++) {
             const bool was_init = act[k]->phase == 0;
             if (cg_consume(c, *act[k], gam2, diag, max_iter, multi)) return 1;
             if (was_init && max_iter <= 0) act[k]->active = false;
         }
     }
+    if (ride_x && ax_device(c, ride_x, ride_out)) return 1;
     return 0;
 }
 
@@ -885,13 +912,23 @@ int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, 
 
 // The LMMSE solve (denoiser = 1, optional warm start) and the Onsager probe solve (denoiser = 0, zero start) of one VAMP
 // iteration in lock-step.  n_ax / n_atx of the stats count vector products (2 per shared pass).
-int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
-                 int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
-                 double* relres_b) {
+int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
+                  double* relres_b, const gv_cg_extras* ex) {
     NEED(c, v_a->space == GV_SPACE_M && v_b->space == GV_SPACE_M && mu_a->space == GV_SPACE_M && mu_b->space == GV_SPACE_M,
          "gv_cg_solve2: M-space vectors required");
     NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && mu_a != mu_b, "gv_cg_solve2: outputs must not alias inputs");
+    gv_cg_extras none{};
+    if (!ex) ex = &none;
+    NEED(c, (ex->ride_x == nullptr) == (ex->ride_out == nullptr), "gv_cg_solve2x: ride_x and ride_out go together");
+    NEED(c, !ex->ride_x || (ex->ride_x->space == GV_SPACE_M && ex->ride_out->space == GV_SPACE_N),
+         "gv_cg_solve2x: ride_x is M-space, ride_out N-space");
+    NEED(c, !ex->a_mu_a || ex->a_mu_a->space == GV_SPACE_N, "gv_cg_solve2x: a_mu_a is N-space");
+    NEED(c, !ex->ata_mu_b || (ex->ata_mu_b->space == GV_SPACE_M && ex->ata_mu_b != mu_b && ex->ata_mu_b != v_b),
+         "gv_cg_solve2x: ata_mu_b is M-space and must not alias v_b / mu_b");
+    NEED(c, !ex->ata_mu_b || tau != 0.0, "gv_cg_solve2x: ata_mu_b needs tau != 0");
     if (ensure_work(c)) return 1;
+    if (!c->w_n2 && vec_new(c, GV_SPACE_N, &c->w_n2)) return 1;
     for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
         if (!*w && vec_new(c, GV_SPACE_M, w)) return 1;
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
@@ -899,15 +936,30 @@ int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const g
     s[0].v = v_a->d; s[0].mu0 = mu_start_a ? mu_start_a->d : nullptr; s[0].mu = mu_a->d;
     s[0].r = c->cg_r->d; s[0].z = c->cg_z->d; s[0].p = c->cg_p->d; s[0].d = c->cg_d->d;
     s[0].denoiser = 1; s[0].relres = relres_a;
+    s[0].az = ex->a_mu_a ? ex->a_mu_a->d : nullptr;
     s[1].v = v_b->d; s[1].mu0 = nullptr; s[1].mu = mu_b->d;
     s[1].r = c->cg2_r->d; s[1].z = c->cg2_z->d; s[1].p = c->cg2_p->d; s[1].d = c->cg2_d->d;
     s[1].denoiser = 0; s[1].relres = relres_b;
-    if (cg_run(c, s, 2, tau, gam2, max_iter)) return 1;
+    s[1].keep_resid = ex->ata_mu_b != nullptr;
+    if (cg_run(c, s, 2, tau, gam2, max_iter, ex->ride_x ? ex->ride_x->d : nullptr, ex->ride_out ? ex->ride_out->d : nullptr))
+        return 1;
+    if (ex->ata_mu_b) {   // Q mu_b = v_b - r_b  =>  A^T A mu_b = (v_b - r_b - gam2 mu_b) / tau
+        double* o = ex->ata_mu_b->d;
+        gvk::axpby(c->stream, o, 1.0 / tau, s[1].v, -1.0 / tau, s[1].r, c->M);
+        gvk::axpby(c->stream, o, 1.0, o, -gam2 / tau, s[1].mu, c->M);
+        KCHK(c);
+    }
     cg_fill_stats(s[0], st_a);
     cg_fill_stats(s[1], st_b);
     if (st_a) { st_a->n_ax = (int)(c->cnt.n_ax - ax0); st_a->n_atx = (int)(c->cnt.n_atx - atx0); }
     if (st_b) { st_b->n_ax = st_a ? st_a->n_ax : 0; st_b->n_atx = st_a ? st_a->n_atx : 0; }
     return 0;
+}
+
+int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                 int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
+                 double* relres_b) {
+    return gv_cg_solve2x(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, st_a, st_b, relres_a, relres_b, nullptr);
 }
 
 // ---- denoiser side ------------------------------------------------------------------------------------------

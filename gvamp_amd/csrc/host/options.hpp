@@ -69,7 +69,9 @@ public:
     long get_synth_seed() const { return synth_seed; }         // --synth-seed S: on-device synthetic .bed (no --bed-file)
     unsigned int get_synth_miss_ppm() const { return synth_miss_ppm; }   // --synth-miss-ppm (default 5000)
     int get_diagnostics() const { return diagnostics; }        // --diagnostics 1: the 3 print-only Ax of vamp.cpp:646-681
-    int get_fuse_solves() const { return fuse_solves; }        // --fuse-solves 0: separate LMMSE / Onsager CG passes
+    // --fuse-solves 0: the reference sequence; 1: the LMMSE and Onsager CG solves share their passes (bit-identical);
+    // 2: also z1 = A x1_hat rides in a free slot and A x2_hat, A^T A invQ u come out of the CG recurrences (rounding-level)
+    int get_fuse_solves() const { return fuse_solves; }
     int get_store_iterates() const { return store_iterates; }  // --store-iterates 0: skip the per-iteration .bin/.csv dumps
     // [ext] programmatic construction (host_capi.cpp): the solver knobs that `vamp` reads through the getters above
     void set_solver(unsigned int EM_max_iter_, unsigned int CG_max_iter_, double EM_err_thr_, double stop_criteria_thr_,

@@ -65,7 +65,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -138,12 +138,25 @@ double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
 
 // The two CG solves of one iteration share the operator (tau A^T A + gam2 I): gv_cg_solve2 applies it to both pending
 // directions in one two-vector Ax + ATx pair per round.  Iterates, stopping rules and results per solve are unchanged.
-double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters) {
+double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
+                          gv_vec* ride_x, gv_vec* ride_out) {
     draw_onsager_probe(dataset);
     gv_cg_stats sa, sb;
     std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
-    ck(gv_cg_solve2(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data()),
-       "gv_cg_solve2");
+    gv_cg_extras ex{};
+    have_derived = false;
+    if (fuse_solves >= 2) {
+        // --fuse-solves 2: products the solves make available without a further pass over the shard (gvamp.h, gv_cg_extras)
+        if (!ax2_der) ck(gv_vec_alloc(ctx, GV_SPACE_N, &ax2_der), "gv_vec_alloc");
+        if (!ata_der) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_der), "gv_vec_alloc");
+        ex.ride_x = ride_x;
+        ex.ride_out = ride_out;
+        ex.a_mu_a = ax2_der;        // A x2_hat          (vamp.cpp:897, vamp_probit.cpp:555)
+        ex.ata_mu_b = ata_der;      // A^T A invQ u      (vamp.cpp:913-914)
+        have_derived = true;
+    }
+    ck(gv_cg_solve2x(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
+                     &ex), "gv_cg_solve2x");
     if (verbose && rank == 0) {
         for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
         for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
@@ -157,15 +170,21 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
 // that the duplicate Ax of the reference is not repeated.
 void vamp::updateNoisePrec(data* dataset, double* R2_out) {
     (void)dataset;
-    ck(gv_ax2_dev(ctx, x2_hat, invQ_bern_vec, tN, tN2), "gv_ax2_dev");     // A x2_hat (:897) and A invQ u (:913), one pass
-    ck(gv_vec_axpby(ctx, tN, 1.0, tN, -1.0, y), "gv_vec_axpby");          // temp = A x2_hat - y
+    gv_vec* ata = tM;
+    if (have_derived) {                                                    // both products came out of the solves
+        ck(gv_vec_axpby(ctx, tN, 1.0, ax2_der, -1.0, y), "gv_vec_axpby");   // temp = A x2_hat - y
+        ata = ata_der;
+    } else {
+        ck(gv_ax2_dev(ctx, x2_hat, invQ_bern_vec, tN, tN2), "gv_ax2_dev");  // A x2_hat (:897) and A invQ u (:913), one pass
+        ck(gv_vec_axpby(ctx, tN, 1.0, tN, -1.0, y), "gv_vec_axpby");      // temp = A x2_hat - y
+    }
     const gv_vec* xs[2] = {tN, y};
     const gv_vec* ys[2] = {tN, y};
     double d2[2];
     ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
     const double temp_norm2 = d2[0];
-    ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
-    const double trace_corr = dotM(bern_vec, tM) * Mt;
+    if (!have_derived) ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
+    const double trace_corr = dotM(bern_vec, ata) * Mt;
     if (verbose && rank == 0) {
         std::cout << "l2_norm2(temp) / N = " << temp_norm2 / N << std::endl;
         std::cout << "trace_correction / N = " << trace_corr / N << std::endl;
@@ -310,14 +329,20 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             ck(gv_vec_axpby(ctx, x1_hat, rho, x1_hat, 1 - rho, x1_hat_prev), "gv_vec_axpby");
             alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
         }
-        ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");                      // z1 = A x1_hat (:429)
+        // z1 = A x1_hat (:429).  --fuse-solves 2: it is only printed / stored, so it rides in a free slot of the CG passes
+        // below and its outputs follow the solve.
+        const bool z1_rides = fuse_solves >= 2 && reverse == 0;
+        if (!z1_rides) ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");
 
         double t0 = now_s();
-        if (store_iterates && rank == 0) {                                // :435-436 (every rank in the reference)
-            std::vector<double> zh(4 * dataset->get_mbytes());
-            ck(gv_vec_download(ctx, z1, zh.data()), "gv_vec_download");
-            store_vec_to_file(pre + "_z1_it_" + std::to_string(it) + ".csv", zh);
-        }
+        auto z1_outputs_a = [&]() {
+            if (store_iterates && rank == 0) {                            // :435-436 (every rank in the reference)
+                std::vector<double> zh(4 * dataset->get_mbytes());
+                ck(gv_vec_download(ctx, z1, zh.data()), "gv_vec_download");
+                store_vec_to_file(pre + "_z1_it_" + std::to_string(it) + ".csv", zh);
+            }
+        };
+        if (!z1_rides) z1_outputs_a();
         if (verbose && rank == 0) std::cout << "rho = " << rho << std::endl;
         {
             ck(gv_vec_download(ctx, x1_hat, x1_hat_stored.data()), "gv_vec_download");
@@ -341,7 +366,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         st.alpha1 = alpha1; st.eta1 = eta1; st.gam2 = gam2; st.rho = rho;
 
         if (auto_var_max_iter == 0 || it <= 1) updatePrior(1);            // :518-519
-        {   // err_measures(1) (:1295-1317): R2 of the cached z1
+        auto z1_outputs_b = [&]() {   // err_measures(1) (:1295-1317): R2 of the cached z1
             ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, z1), "gv_vec_axpby");
             const gv_vec* xs[2] = {tN, y};
             const gv_vec* ys[2] = {tN, y};
@@ -351,7 +376,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             st.R2_denoise = 1 - e * e;
             R2trains.push_back(st.R2_denoise);
             if (verbose && rank == 0) std::cout << "R2 = " << st.R2_denoise << std::endl;
-        }
+        };
+        if (!z1_rides) z1_outputs_b();
         if (verbose && rank == 0) {
             std::cout << "prior variances = ";
             for (double v : vars) std::cout << v << ' ';
@@ -374,7 +400,14 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             ck(gv_vec_axpby(ctx, vM, gamw, aty, gam2, r2), "gv_vec_axpby");   // v = gamw A^T y + gam2 r2 (:590-591)
             gv_vec* warm = (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last;
             if (fuse_solves) {
-                fused_alpha2 = fused_solves(vM, warm, gamw, dataset, &st.cg_iters, &st.onsager_iters);
+                fused_alpha2 = fused_solves(vM, warm, gamw, dataset, &st.cg_iters, &st.onsager_iters,
+                                            z1_rides ? x1_hat : nullptr, z1_rides ? z1 : nullptr);
+                if (z1_rides) {
+                    double tz = now_s();
+                    z1_outputs_a();
+                    t_io += now_s() - tz;
+                    z1_outputs_b();
+                }
             } else
                 cg(vM, warm, gamw, 1, x2_hat, &st.cg_iters);               // :593-596
             ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");       // :1225-1226
@@ -589,7 +622,10 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         gam1 = gam2 * (1 - alpha2) / alpha2;                              // :548-549
         st.gam1_next = gam1;
         if (verbose && rank == 0) std::cout << "gam1 = " << gam1 << std::endl;
-        ck(gv_ax_dev(ctx, x2_hat, tN), "gv_ax_dev");                       // z2_hat (:555)
+        if (fuse_solves && have_derived)                                   // z2_hat = A x2_hat (:555): a by-product of the solve
+            ck(gv_vec_copy(ctx, tN, ax2_der), "gv_vec_copy");
+        else
+            ck(gv_ax_dev(ctx, x2_hat, tN), "gv_ax_dev");
         const double beta2 = (double)Mt / N * (1 - alpha2);               // :561
         const double zeta2 = tau2 / beta2;
         if (it > 1) {                                                     // :565-574

@@ -69,7 +69,10 @@ public:
     double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
     void draw_onsager_probe(data* dataset);                                   // vamp.cpp:875-882 (host RNG)
     // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2
-    double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters);
+    double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
+                        gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);
+    gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
+    bool have_derived = false;
     void updatePrior(int verbose);                       // vamp.cpp:929-1072
     void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)
 

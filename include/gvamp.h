@@ -121,6 +121,27 @@ int gv_cg_solve2(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const
                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
                  double* relres_a, double* relres_b);
 
+/* gv_cg_solve2 plus by-products that cost no further pass over the shard.  Every member may be NULL (= not wanted):
+ *   ride_x / ride_out : ride_out = data::Ax(ride_x) (data.cpp:848) for an M-vector unrelated to the solves -- e.g.
+ *                       z1 = A x1_hat of vamp.cpp:429 -- computed in the free slot of the first round in which only one
+ *                       solve is still active (a two-vector pass costs what a one-vector pass costs), else by one pass of
+ *                       its own after the solves.  Bit-identical to gv_ax_dev.
+ *   a_mu_a   (N-space): A mu_a, accumulated from the products A p_k that CG forms anyway
+ *                       (A mu_a = A mu_start + sum_k alpha_k A p_k): the A x2_hat of vamp.cpp:897 without its Ax.
+ *   ata_mu_b (M-space): A^T A mu_b = (v_b - r_b - gam2 mu_b) / tau from the final residual of solve b: the
+ *                       A^T (A invQ u) of vamp.cpp:913-914 without its Ax and ATx.
+ * a_mu_a and ata_mu_b are algebraic identities of the CG recurrences: they agree with the explicit products to rounding
+ * (~1e-13 relative), not bit for bit. */
+typedef struct gv_cg_extras {
+    const gv_vec* ride_x;
+    gv_vec* ride_out;
+    gv_vec* a_mu_a;
+    gv_vec* ata_mu_b;
+} gv_cg_extras;
+int gv_cg_solve2x(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
+                  double* relres_a, double* relres_b, const gv_cg_extras* extras);
+
 /* ---- denoiser side (fused element-wise kernels) ------------------------------------------------------
  * vamp::g1 / g1d over a vector (vamp.cpp:805-869; loops :292-310): x1 = g1(r1), sums[0] = sum g1d(r1) (local),
  * sums[1] = sum (x1-r1)^2 (local).  vars already multiplied by N (vamp.cpp:154-155).  d_out may be NULL. */
