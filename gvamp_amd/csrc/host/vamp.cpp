@@ -123,7 +123,13 @@ std::vector<double> vamp::infere(data* dataset) {
 // vamp.cpp:871-889: u in {+-1/sqrt(Mt)}^M from mt19937{seed + S} + bernoulli(0.5) on the host (bit-comparable with the
 // reference at matched shard boundaries), CG on the device.
 void vamp::draw_onsager_probe(data* dataset) {
-    std::mt19937 rd{seed + (long unsigned int)dataset->get_S()};
+    // the generator is re-seeded with the same seed + S on every call (:875): the probe is the same vector every
+    // iteration, so it is drawn and uploaded once per (seed, S) and stays resident
+    const long unsigned int key = seed + (long unsigned int)dataset->get_S();
+    if (have_probe && probe_key == key) return;
+    have_probe = true;
+    probe_key = key;
+    std::mt19937 rd{key};
     std::bernoulli_distribution bern(0.5);
     std::vector<double> u(M > 0 ? M : 0);
     for (int i = 0; i < M; i++) u[i] = (2 * bern(rd) - 1) / sqrt(Mt);
@@ -283,6 +289,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     }
     const std::string pre = out_dir + out_name;
     std::vector<double> x1_hat_stored(M > 0 ? M : 0, 0.0);
+    bool ran_any = false;
 
     double fused_alpha2 = 0;
     for (int it = 1; it <= max_iter; it++) {
@@ -344,12 +351,13 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         };
         if (!z1_rides) z1_outputs_a();
         if (verbose && rank == 0) std::cout << "rho = " << rho << std::endl;
-        {
+        if (store_iterates || keep_history) {   // otherwise only the last iterate is wanted: fetched after the loop
             ck(gv_vec_download(ctx, x1_hat, x1_hat_stored.data()), "gv_vec_download");
             for (double& v : x1_hat_stored) v /= sqrtN;
             if (store_iterates) mpi_store_vec_to_file(pre + "_it_" + std::to_string(it) + ".bin", x1_hat_stored, S, M);
             if (keep_history) x1_hist.push_back(x1_hat_stored);
         }
+        ran_any = true;
         store_scaled(pre + "_r1_it_" + std::to_string(it) + ".bin", r1, &r1_hist);
         t_io += now_s() - t0;
 
@@ -487,6 +495,10 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         if (verbose && rank == 0)
             std::cout << "total iteration time = " << st.seconds << " (Ax " << st.n_ax << ", ATx " << st.n_atx << ")"
                       << std::endl << std::endl;
+    }
+    if (ran_any && !(store_iterates || keep_history)) {   // x1_hat still holds the last iteration's (damped) estimate
+        ck(gv_vec_download(ctx, x1_hat, x1_hat_stored.data()), "gv_vec_download");
+        for (double& v : x1_hat_stored) v /= sqrtN;
     }
     if (store_pvals == 1) {                                                 // vamp.cpp:761-776
         // z1 / x1_hat of the last completed iteration, y = filtered phenotype (all still resident on the device)

@@ -73,6 +73,8 @@ public:
                         gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);
     gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
     bool have_derived = false;
+    bool have_probe = false;          // draw_onsager_probe: bern_vec is resident for (seed + S) == probe_key
+    long unsigned int probe_key = 0;
     void updatePrior(int verbose);                       // vamp.cpp:929-1072
     void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)
 
