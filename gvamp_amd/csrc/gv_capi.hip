@@ -89,6 +89,13 @@ int read_scalars(gv_ctx* c, int K, double* out) {
 bool is_multi(const gv_ctx* c);
 int comm_allreduce(gv_ctx* c, double* dev, size_t n);
 
+// K scalars a reduction launcher left in red_out, summed over the ranks (utilities.cpp:203) and read back: the all-reduce
+// runs on the device buffer itself, so a CG scalar costs one stream synchronisation whether or not the job is sharded
+int read_scalars_global(gv_ctx* c, int K, double* out, bool multi) {
+    if (multi && comm_allreduce(c, c->red_out, K)) return 1;
+    return read_scalars(c, K, out);
+}
+
 // MPI_Allreduce(SUM, MPI_DOUBLE) of K host scalars (utilities.cpp:203): device round trip through RCCL
 int allreduce_scalars(gv_ctx* c, double* buf, int K) {
     if (!is_multi(c)) return 0;
@@ -756,62 +763,97 @@ static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
     return 0;
 }
 
-static int cg_consume(gv_ctx* c, CgSys& s, double gam2, double diag, int max_iter, bool multi) {
+// One CG step (:1160-1223) of every system whose operator application has just come back.  The systems move through
+// the three reductions of a step TOGETHER: their scalars sit in disjoint slots of red_out (8 doubles per system), so a
+// step costs three all-reduce + read-back round trips however many systems are active (sharded jobs: the latency of
+// these small messages is what remains of a CG step besides the two passes over the shard).
+static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double diag, int max_iter, bool multi) {
     const int64_t M = c->M;
     hipStream_t st = c->stream;
-    if (s.phase == 0) {                                                   // r = v - Q mu0 (:1142-1145)
-        gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
-        if (s.az) HIPCHK(c, hipMemcpyAsync(s.az, s.wslot, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, st));   // A mu0
-        KCHK(c);
-        return cg_finish_init(c, s, diag, multi);
+    CgSys* stp[2];
+    int slot[2];
+    int ns = 0;
+    for (int k = 0; k < na; k++) {
+        CgSys& s = *act[k];
+        if (s.phase == 0) {                                               // r = v - Q mu0 (:1142-1145)
+            gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
+            if (s.az) HIPCHK(c, hipMemcpyAsync(s.az, s.wslot, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, st));   // A mu0
+            KCHK(c);
+            if (cg_finish_init(c, s, diag, multi)) return 1;
+            if (max_iter <= 0) s.active = false;
+        } else {
+            slot[ns] = k;
+            stp[ns++] = &s;
+        }
     }
-    const int i = s.iters;
-    s.iters = i + 1;
-    const double* xs[1] = {s.d};
-    const double* ys[1] = {s.p};
-    gvk::dots(st, 1, xs, ys, M, c->red_partial, c->red_out);
+    if (ns == 0) return 0;
+    const int K = 8 * (slot[ns - 1] + 1);
+    double sc[16], alpha[2] = {0, 0};
+    auto part = [&](int j) { return c->red_partial + (size_t)slot[j] * RED_BLOCKS * 8; };
+    auto outp = [&](int j) { return c->red_out + 8 * slot[j]; };
+    // <d, p>
+    for (int j = 0; j < ns; j++) {
+        const double* xs[1] = {stp[j]->d};
+        const double* ys[1] = {stp[j]->p};
+        gvk::dots(st, 1, xs, ys, M, part(j), outp(j));
+    }
     KCHK(c);
-    double dp;
-    if (read_scalars(c, 1, &dp)) return 1;
-    if (multi && allreduce_scalars(c, &dp, 1)) return 1;
-    const double alpha = s.rz / dp;                                       // :1167
-    gvk::cg_step_a(st, s.mu, s.p, alpha, s.v, M, c->red_partial, c->red_out);   // mu += alpha p (:1169-1172)
-    if (s.az) gvk::axpby(st, s.az, 1.0, s.az, alpha, s.wslot, c->npad);  // A mu += alpha A p
+    if (read_scalars_global(c, K, sc, multi)) return 1;
+    bool any_onsager = false;
+    for (int j = 0; j < ns; j++) {
+        CgSys& s = *stp[j];
+        alpha[j] = s.rz / sc[8 * slot[j]];                                // :1167
+        gvk::cg_step_a(st, s.mu, s.p, alpha[j], s.v, M, part(j), outp(j));   // mu += alpha p (:1169-1172)
+        if (s.az) gvk::axpby(st, s.az, 1.0, s.az, alpha[j], s.wslot, c->npad);   // A mu += alpha A p
+        any_onsager |= s.denoiser == 0;
+    }
     KCHK(c);
-    if (s.denoiser == 0) {                                                // :1174-1193
-        double vm;
-        if (read_scalars(c, 1, &vm)) return 1;
-        if (multi && allreduce_scalars(c, &vm, 1)) return 1;
-        s.onsager = gam2 * vm;
-        const double oerr = (s.onsager != 0) ? fabs((s.onsager - s.prev_onsager) / s.onsager) : 1.0;
-        if (oerr < 1e-8) {
-            if (s.keep_resid) {                                           // the reference leaves r one step behind here
-                gvk::axpby(st, s.r, 1.0, s.r, -alpha, s.d, M);
-                KCHK(c);
+    bool stepping[2] = {true, true};
+    if (any_onsager) {                                                    // :1174-1193
+        if (read_scalars_global(c, K, sc, multi)) return 1;
+        for (int j = 0; j < ns; j++) {
+            CgSys& s = *stp[j];
+            s.iters++;
+            if (s.denoiser != 0) continue;
+            s.onsager = gam2 * sc[8 * slot[j]];
+            const double oerr = (s.onsager != 0) ? fabs((s.onsager - s.prev_onsager) / s.onsager) : 1.0;
+            if (oerr < 1e-8) {
+                if (s.keep_resid) gvk::axpby(st, s.r, 1.0, s.r, -alpha[j], s.d, M);   // the reference leaves r one step behind
+                s.converged = 1;
+                s.active = false;
+                stepping[j] = false;
             }
+            s.prev_onsager = s.onsager;
+        }
+    } else
+        for (int j = 0; j < ns; j++) stp[j]->iters++;
+    bool any = false;
+    for (int j = 0; j < ns; j++) {
+        if (!stepping[j]) continue;
+        CgSys& s = *stp[j];
+        gvk::cg_step_b(st, s.r, s.d, alpha[j], diag, s.z, s.mu, M, part(j), outp(j));   // :1195-1216
+        any = true;
+    }
+    KCHK(c);
+    if (!any) return 0;
+    if (read_scalars_global(c, K, sc, multi)) return 1;
+    for (int j = 0; j < ns; j++) {
+        if (!stepping[j]) continue;
+        CgSys& s = *stp[j];
+        const double* q = sc + 8 * slot[j];
+        const double beta = q[0] / s.rz;                                  // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
+        s.rz = q[0];
+        gvk::axpby(st, s.p, 1.0, s.z, beta, s.p, M);                      // p = z + beta p (:1209-1210)
+        s.rel_err = sqrt(q[2]) / s.norm_v;                                // :1215
+        if (s.relres) s.relres[s.iters - 1] = s.rel_err;
+        s.n_relres = s.iters;
+        if (s.rel_err < 1e-5) {                                           // :1217,:1222
             s.converged = 1;
             s.active = false;
-            return 0;
-        }
-        s.prev_onsager = s.onsager;
+        } else if (s.iters >= max_iter)
+            s.active = false;
     }
-    double sc[4];
-    gvk::cg_step_b(st, s.r, s.d, alpha, diag, s.z, s.mu, M, c->red_partial, c->red_out);   // :1195-1216
     KCHK(c);
-    if (read_scalars(c, 4, sc)) return 1;
-    if (multi && allreduce_scalars(c, sc, 4)) return 1;
-    const double beta = sc[0] / s.rz;                                     // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
-    s.rz = sc[0];
-    gvk::axpby(st, s.p, 1.0, s.z, beta, s.p, M);                          // p = z + beta p (:1209-1210)
-    KCHK(c);
-    s.rel_err = sqrt(sc[2]) / s.norm_v;                                   // :1215
-    if (s.relres) s.relres[i] = s.rel_err;
-    s.n_relres = i + 1;
-    if (s.rel_err < 1e-5) {                                               // :1217,:1222
-        s.converged = 1;
-        s.active = false;
-    } else if (s.iters >= max_iter)
-        s.active = false;
     return 0;
 }
 
@@ -872,11 +914,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
                 return 1;
             act[0]->wslot = c->w_n->d;
         }
-        for (int k = 0; k < na; k++) {
-            const bool was_init = act[k]->phase == 0;
-            if (cg_consume(c, *act[k], gam2, diag, max_iter, multi)) return 1;
-            if (was_init && max_iter <= 0) act[k]->active = false;
-        }
+        if (cg_consume_all(c, act, na, gam2, diag, max_iter, multi)) return 1;
     }
     if (ride_x && ax_device(c, ride_x, ride_out)) return 1;
     return 0;
