@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
 ]
 
@@ -104,6 +104,7 @@ def load():
     L.gv_prior_estep.argtypes = [vp, vp, C.c_double, C.c_double, dp, dp, C.c_int, dp]
     L.gv_allreduce_host.argtypes = [vp, dp, C.c_int]
     L.gv_probit_denoise.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, dp]
+    L.gv_probit_denoise_cov.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, dp]
     L.gv_people_stats.argtypes = [vp, dp, dp, dp]
     L.gv_cg_solve_aat.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.POINTER(CgStats), dp]
     L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
@@ -342,9 +343,12 @@ class Shard:
         self._ck(self.L.gv_prior_estep(self.h, r1.h, gam1, lam, _dp(om), _dp(vs), om.size, _dp(sums)))
         return sums
 
-    def probit_denoise(self, p1, y, tau1, probit_var, z1_out):
+    def probit_denoise(self, p1, y, tau1, probit_var, z1_out, m_cov=None):
         sums = np.empty(2)
-        self._ck(self.L.gv_probit_denoise(self.h, p1.h, y.h, tau1, probit_var, z1_out.h, _dp(sums)))
+        if m_cov is None:
+            self._ck(self.L.gv_probit_denoise(self.h, p1.h, y.h, tau1, probit_var, z1_out.h, _dp(sums)))
+        else:
+            self._ck(self.L.gv_probit_denoise_cov(self.h, p1.h, y.h, m_cov.h, tau1, probit_var, z1_out.h, _dp(sums)))
         return sums
 
     def compute_people_statistics(self):

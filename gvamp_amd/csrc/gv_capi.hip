@@ -1033,13 +1033,19 @@ int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, cons
 }
 
 // ---- probit: z-side denoiser of vamp::infere_bin_class (vamp_probit.cpp:335-352) -------------------------------------
-int gv_probit_denoise(gv_ctx* c, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
-                      double* sums2) {
-    NEED(c, p1->space == GV_SPACE_N && y->space == GV_SPACE_N && z1_out->space == GV_SPACE_N,
+int gv_probit_denoise_cov(gv_ctx* c, const gv_vec* p1, const gv_vec* y, const gv_vec* m_cov, double tau1, double probit_var,
+                          gv_vec* z1_out, double* sums2) {
+    NEED(c, p1->space == GV_SPACE_N && y->space == GV_SPACE_N && z1_out->space == GV_SPACE_N &&
+                (!m_cov || m_cov->space == GV_SPACE_N),
          "gv_probit_denoise: N-space vectors required");
-    gvk::probit_denoise(c->stream, p1->d, y->d, c->N, c->npad, tau1, probit_var, z1_out->d, c->red_partial, c->red_out);
+    gvk::probit_denoise(c->stream, p1->d, y->d, m_cov ? m_cov->d : nullptr, c->N, c->npad, tau1, probit_var, z1_out->d,
+                        c->red_partial, c->red_out);
     KCHK(c);
     return read_scalars(c, 2, sums2);
+}
+int gv_probit_denoise(gv_ctx* c, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
+                      double* sums2) {
+    return gv_probit_denoise_cov(c, p1, y, nullptr, tau1, probit_var, z1_out, sums2);
 }
 
 // ---- --use-XXT-denoiser 1: LMMSE through CG in N-space (denoiserXXT.cpp), matrix-free ------------------------------

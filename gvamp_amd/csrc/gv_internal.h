@@ -95,8 +95,8 @@ void aat_diag(hipStream_t s, const double* mave_p, const double* msig_p, const d
               double Nd, int64_t npad, double* diag);
 void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, const double* diag, double* z, int64_t n,
                     double* partial, double* out);   // out = <r,z>, <r,r>
-void probit_denoise(hipStream_t s, const double* p1, const double* y, int64_t N, int64_t npad, double tau1,
-                    double probit_var, double* z1, double* partial, double* out);   // out = sum g1d, sum (z1-p1)^2
+void probit_denoise(hipStream_t s, const double* p1, const double* y, const double* m_cov, int64_t N, int64_t npad,
+                    double tau1, double probit_var, double* z1, double* partial, double* out);   // out = sum g1d, sum (z1-p1)^2
 void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n);
 void select_eq(hipStream_t s, double* out, const double* x, const int* key, int value, int64_t n);
 void ax_table(hipStream_t s, const double* x, const double* mave, const double* msig, int64_t M, double* t3);

@@ -314,11 +314,12 @@ __global__ __launch_bounds__(256) void k_cg_b_diag(double* __restrict__ r, const
 }
 
 // ---- probit (--model bin_class): vamp::g1_bin_class / g1d_bin_class over the N individuals (vamp_probit.cpp:335-352,
-// :661-705), m_cov = 0.  z1 = posterior mean of z given y in {0,1} and the cavity N(p1, 1/tau1); partials of
+// :661-705); m_cov (may be NULL) is the per-individual covariate offset.  z1 = posterior mean of z given y in {0,1} and the cavity N(p1, 1/tau1); partials of
 // sum g1d and sum (z1 - p1)^2.  Entries n >= N of z1 are zeroed.
 __global__ __launch_bounds__(256) void k_probit_denoise(const double* __restrict__ p1, const double* __restrict__ y,
-                                                        int64_t N, int64_t npad, double tau1, double probit_var,
-                                                        double* __restrict__ z1, double* __restrict__ partial) {
+                                                        const double* __restrict__ m_cov, int64_t N, int64_t npad,
+                                                        double tau1, double probit_var, double* __restrict__ z1,
+                                                        double* __restrict__ partial) {
     __shared__ double sh[4];
     const double inv_s = 1.0 / sqrt(probit_var + 1.0 / tau1);
     int64_t stride = (int64_t)gridDim.x * 256;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_probit_denoise(const double* __restrict
         double out = 0.0;
         if (i < N) {
             const double p = p1[i], sgn = 2 * y[i] - 1;
-            const double c = p * inv_s;
+            const double c = (m_cov ? p + m_cov[i] : p) * inv_s;   // m_cov = <Z[i], cov_eff> (vamp_probit.cpp:347,:364)
             const double ratio = 2.0 / sqrt(2 * M_PI) / erfcx(-sgn * c / sqrt(2.0));   // pdf / cdf at sgn * c
             out = p + sgn * ratio / tau1 * inv_s;
             const double gd = 1 - ratio / (1 + tau1 * probit_var) * (sgn * c + ratio);
@@ -604,10 +605,10 @@ void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, con
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 2, out);
 }
 
-void probit_denoise(hipStream_t s, const double* p1, const double* y, int64_t N, int64_t npad, double tau1,
-                    double probit_var, double* z1, double* partial, double* out) {
+void probit_denoise(hipStream_t s, const double* p1, const double* y, const double* m_cov, int64_t N, int64_t npad,
+                    double tau1, double probit_var, double* z1, double* partial, double* out) {
     int nb = red_blocks(npad, 256);
-    hipLaunchKernelGGL(k_probit_denoise, dim3(nb), dim3(256), 0, s, p1, y, N, npad, tau1, probit_var, z1, partial);
+    hipLaunchKernelGGL(k_probit_denoise, dim3(nb), dim3(256), 0, s, p1, y, m_cov, N, npad, tau1, probit_var, z1, partial);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 2, out);
 }
 

@@ -285,3 +285,39 @@ std::vector<double> data::filter_pheno(int* nonnan) {
     *nonnan = cnt;
     return y;
 }
+
+// data.cpp:286-331 -- covariates file of the probit model: one line per individual, C whitespace-separated numbers.
+// (The reference splits on the regex \s+ and dies in std::stod on a leading blank; a stream extraction reads the same
+// well-formed files.)  A line with another number of values is fatal, as in the reference.
+void data::read_covariates(std::string covfp, int C) {
+    if (C == 0) return;
+    std::ifstream covf(covfp);
+    if (!covf.is_open()) {
+        std::cout << "FATAL: cannot open covariates file " << covfp << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    std::string line;
+    while (std::getline(covf, line)) {
+        std::istringstream is(line);
+        std::vector<double> entries;
+        std::string tok;
+        while (is >> tok) entries.push_back(std::stod(tok));
+        if ((int)entries.size() != C) {
+            std::cout << "FATAL: number of covariates = " << entries.size()
+                      << " does not match to the specified number of covariates = " << C << std::endl;
+            exit(EXIT_FAILURE);
+        }
+        covs.push_back(entries);
+    }
+    if ((int)covs.size() < N) {
+        std::cout << "FATAL: covariates file " << covfp << " holds " << covs.size() << " lines for N = " << N << std::endl;
+        exit(EXIT_FAILURE);
+    }
+}
+
+// data.cpp:1050-1058
+std::vector<double> data::Zx(std::vector<double> phen) {
+    std::vector<double> out(4 * mbytes, 0.0);
+    for (int i = 0; i < N; i++) out[i] = inner_prod(covs[i], phen, 0);
+    return out;
+}

@@ -16,6 +16,7 @@ private:
     std::vector<double> phen_data;
     std::vector<unsigned char> mask4;
     std::vector<double> mave, msig;    // host copies of the device statistics (get_mave / get_msig)
+    std::vector<std::vector<double>> covs;
     double intercept = 0, scale = 1, alpha_scale = 1;
     gv_ctx* ctx = nullptr;
     bool owns_ctx = true;
@@ -65,6 +66,11 @@ public:
     void compute_markers_statistics();      // data.cpp:392-546
     std::vector<double> Ax(double* __restrict__ phen);    // data.cpp:848 : M doubles -> 4*mbytes, reduced + scaled
     std::vector<double> ATx(double* __restrict__ phen);   // data.cpp:810 : 4*mbytes doubles -> M
+    // covariates of the probit model (data.cpp:286-331, :1050-1058): one row of C values per individual
+    void read_covariates(std::string covfp, int C = 0);
+    std::vector<std::vector<double>> get_covs() { return covs; }
+    void set_covs(std::vector<std::vector<double>> z) { covs = std::move(z); }   // [ext] covariates given in memory
+    std::vector<double> Zx(std::vector<double> phen);     // 4*mbytes: <covs[i], phen> for i < N, 0 beyond
     std::vector<double> filter_pheno();                   // data.cpp:1065-1079
     std::vector<double> filter_pheno(int* nonnan);        // data.cpp:1081-1097
     // data.cpp:1108-1226 / :1235-1353 -- leave-one-out / leave-one-chromosome-out t-test p-values, one vector per

@@ -55,6 +55,13 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
     opt.set_probit_var(o->probit_var);
     opt.set_fuse_solves(o->fuse_solves);
+    if (o->C > 0 && o->covs) {
+        opt.set_C((unsigned int)o->C);
+        std::vector<std::vector<double>> z(N, std::vector<double>(o->C));
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < o->C; j++) z[i][j] = o->covs[(size_t)i * o->C + j];
+        ds.set_covs(std::move(z));
+    }
     gv_host_set_quiet(!o->verbose);
     vamp vm(N, M, Mt, o->gam1, o->gamw, o->iterations, o->rho, vars, probs, ts, rank, "",
             o->out_prefix ? o->out_prefix : "", o->bin_class ? "bin_class" : "linear", opt);
@@ -62,6 +69,10 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     vm.set_keep_history((x1_hist || x2_hist || r1_hist) ? 1 : 0);
     std::vector<double> x = vm.infere(&ds);
     if (x_est && M > 0) memcpy(x_est, x.data(), sizeof(double) * M);
+    if (o->cov_eff_out) {
+        const std::vector<double> ce = vm.get_cov_eff();
+        for (size_t j = 0; j < ce.size() && (int)j < o->C; j++) o->cov_eff_out[j] = ce[j];
+    }
     const std::vector<vamp_iter_stats>& st = vm.get_stats();
     int n = (int)st.size();
     if (n_iters) *n_iters = n;

@@ -139,3 +139,54 @@ double calc_stdev(std::vector<double> vec, int sync) {
     const double mean = sum / n;
     return std::sqrt((sq - n * mean * mean) / (n - 1));
 }
+
+double normal_cdf(double value) { return 0.5 * erfc(-value * M_SQRT1_2); }
+
+// exp(x^2) erfc(x) without overflow / cancellation: the product of the two libm functions while exp(x^2) is finite and
+// erfc(x) is a normal number, the asymptotic expansion 1/(x sqrt(pi)) (1 - 1/(2x^2) + 3/(4x^4) - ...) beyond, and
+// erfcx(-x) = 2 exp(x^2) - erfcx(x) on the negative axis.
+double erfcx(double x) {
+    if (std::isnan(x)) return x;
+    const double ax = fabs(x);
+    double pos;
+    if (ax < 25.0)
+        pos = exp(ax * ax) * erfc(ax);
+    else {
+        const double h = 0.5 / (ax * ax);
+        double t = 1.0, acc = 1.0;
+        for (int k = 1; k <= 12; k++) {
+            t *= -(2 * k - 1) * h;
+            acc += t;
+        }
+        pos = acc / (ax * sqrt(M_PI));
+    }
+    if (x >= 0) return pos;
+    const double big = exp(ax * ax);
+    return std::isinf(big) ? big : 2.0 * big - pos;
+}
+
+bool lu_solve(std::vector<double> A, std::vector<double>& b, int n) {
+    auto at = [&](int i, int j) -> double& { return A[(size_t)i * n + j]; };
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int i = col + 1; i < n; i++)
+            if (fabs(at(i, col)) > fabs(at(piv, col))) piv = i;
+        if (at(piv, col) == 0.0) return false;
+        if (piv != col) {
+            for (int j = 0; j < n; j++) std::swap(at(col, j), at(piv, j));
+            std::swap(b[col], b[piv]);
+        }
+        for (int i = col + 1; i < n; i++) {
+            const double m = at(i, col) / at(col, col);
+            if (m == 0.0) continue;
+            for (int j = col + 1; j < n; j++) at(i, j) -= m * at(col, j);
+            b[i] -= m * b[col];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double acc = b[i];
+        for (int j = i + 1; j < n; j++) acc -= at(i, j) * b[j];
+        b[i] = acc / at(i, i);
+    }
+    return true;
+}

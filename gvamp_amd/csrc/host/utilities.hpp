@@ -25,3 +25,8 @@ std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S); 
 double inner_prod(std::vector<double> const& u, std::vector<double> const& v, int sync);   // host vectors, sync ignored
 double l2_norm2(std::vector<double> const& u, int sync);
 double calc_stdev(std::vector<double> vec, int sync = 0);
+double normal_cdf(double value);                                                        // utilities.cpp:336-339
+double erfcx(double x);                                                                // utilities.cpp:345-409: exp(x^2) erfc(x)
+// A x = b for a dense n x n system (row-major) by LU with partial pivoting -- what the reference takes from Boost uBLAS
+// in Newton_method_cov (vamp_probit.cpp:983-996).  false: a pivot is exactly zero, b is left unspecified.
+bool lu_solve(std::vector<double> A, std::vector<double>& b, int n);

@@ -111,10 +111,6 @@ std::vector<double> vamp::infere(data* dataset) {
     }
     if (!strcmp(model.c_str(), "linear")) return infere_linear(dataset);
     if (!strcmp(model.c_str(), "bin_class")) {
-        if (C > 0) {
-            std::cout << "FATAL: --model bin_class with covariates (--C > 0) is not built yet" << std::endl;
-            exit(EXIT_FAILURE);
-        }
         return infere_bin_class(dataset);
     }
     throw "invalid model specification!";   // vamp.cpp:180 (bin_class / robust: SURVEY 8f)
@@ -521,7 +517,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     return x1_hat_stored;   // x1_hat / sqrt(N) of the last iteration (:802)
 }
 
-// vamp::infere_bin_class (vamp_probit.cpp:20-658) without covariates (C == 0): generalised VAMP for y in {0, 1}.
+// vamp::infere_bin_class (vamp_probit.cpp:20-658): generalised VAMP for y in {0, 1}, with or without covariates.
 // Signal side shared with the linear model (gv_denoise, updatePrior, gv_cg_solve, g2d_onsager); the z side is
 // gv_probit_denoise over the N individuals.  probit_err_measures and the "true ..." prints of the reference are
 // diagnostics against a known signal and are not reproduced.
@@ -547,6 +543,18 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
     const double sqrtN = sqrt((double)N);
     const std::string pre = out_dir + out_name;
     std::vector<double> x1_host(M > 0 ? M : 0, 0.0);
+    // covariates (:84-87): effects start at 0, Z = dataset->get_covs(); m_cov[i] = <Z[i], cov_eff> lives in HBM
+    gv_vec* m_cov = nullptr;
+    std::vector<std::vector<double>> Z;
+    if (C > 0) {
+        cov_eff = std::vector<double>(C, 0.0);
+        Z = dataset->get_covs();
+        if ((int)Z.size() < N) {
+            std::cout << "FATAL: --C " << C << " but only " << Z.size() << " covariate rows for N = " << N
+                      << " (--cov-file)" << std::endl;
+            exit(EXIT_FAILURE);
+        }
+    }
 
     for (int it = 1; it <= max_iter; it++) {
         const double t_start = now_s();
@@ -557,7 +565,24 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         memset(&st, 0, sizeof(st));
         if (verbose && rank == 0)
             std::cout << std::endl << "********************" << std::endl << "iteration = " << it << std::endl
-                      << "********************" << std::endl << "->DENOISING" << std::endl;
+                      << "********************" << std::endl;
+        if (it == 1 && C > 0) {                                           // :110-131: once, with gg = z1_hat = 0
+            const double tc = now_s();
+            std::vector<double> yh = dataset->filter_pheno();
+            yh.resize(N, 0.0);
+            cov_eff = Newton_method_cov(yh, std::vector<double>(N, 0.0), Z, cov_eff);
+            if (rank == 0 && verbose) {
+                for (int i0 = 0; i0 < C; i0++) {
+                    std::cout << "cov_eff[" << i0 << "] = " << cov_eff[i0] << ", ";
+                    if (i0 % 4 == 3) std::cout << std::endl;
+                }
+                std::cout << std::endl << "time for covariates effects update = " << now_s() - tc << " seconds." << std::endl;
+            }
+            std::vector<double> mh = dataset->Zx(cov_eff);
+            newN(&m_cov);
+            ck(gv_vec_upload(ctx, m_cov, mh.data()), "gv_vec_upload");
+        }
+        if (verbose && rank == 0) std::cout << "->DENOISING" << std::endl;
         const double rho_it = 1;                                          // :71
         ck(gv_vec_copy(ctx, x1_hat_prev, x1_hat), "gv_vec_copy");
         const double alpha1_prev = alpha1;
@@ -600,7 +625,7 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         st.alpha1 = alpha1; st.eta1 = eta1; st.gam2 = gam2; st.rho = rho;
 
         double zs[2];                                                     // :335-379 (one round)
-        ck(gv_probit_denoise(ctx, p1, y, tau1, probit_var, z1_hat, zs), "gv_probit_denoise");
+        ck(gv_probit_denoise_cov(ctx, p1, y, m_cov, tau1, probit_var, z1_hat, zs), "gv_probit_denoise_cov");
         const double beta1 = zs[0] / N;
         if (verbose && rank == 0) std::cout << "beta1 = " << beta1 << std::endl;
         const double zeta1 = tau1 / beta1;
@@ -671,6 +696,94 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
             break;
         }
     }
-    for (gv_vec* v : {p1, p2, z1_hat}) gv_vec_free(ctx, v);
+    for (gv_vec* v : {p1, p2, z1_hat, m_cov})
+        if (v) gv_vec_free(ctx, v);
     return x1_host;   // unscaled x1_hat (:657)
+}
+
+// ---- covariates of the probit model ----------------------------------------------------------------------------------
+// Every rank holds all N individuals and all C covariates, so these run redundantly on the host of every rank, as in the
+// reference (no collective); N x C is tiny next to the genotype passes.
+
+// vamp_probit.cpp:813-838 -- gradient of the mean negative log-likelihood of y ~ probit(gg + Z eta)
+std::vector<double> vamp::grad_cov(const std::vector<double>& y, const std::vector<double>& gg, double probit_var,
+                                   const std::vector<std::vector<double>>& Z, const std::vector<double>& eta) {
+    std::vector<double> grad(C, 0.0);
+    const double isd = 1.0 / sqrt(probit_var);
+    for (int i = 0; i < N; i++) {
+        const double s = 2 * y[i] - 1;
+        const double arg = s * isd * (gg[i] + inner_prod(Z[i], eta, 0));
+        const double ratio = 2.0 / sqrt(2 * M_PI) / erfcx(-arg / sqrt(2.0));          // pdf / cdf at arg
+        for (int j = 0; j < C; j++) grad[j] -= ratio * s * isd * Z[i][j];
+    }
+    for (int j = 0; j < C; j++) grad[j] /= N;
+    return grad;
+}
+
+// vamp_probit.cpp:840-857
+double vamp::mlogL_probit(const std::vector<double>& y, const std::vector<double>& gg, double probit_var,
+                          const std::vector<std::vector<double>>& Z, const std::vector<double>& eta) {
+    double acc = 0;
+    const double isd = 1.0 / sqrt(probit_var);
+    for (int i = 0; i < N; i++) acc -= log(normal_cdf((2 * y[i] - 1) * isd * (gg[i] + inner_prod(Z[i], eta, 0))));
+    return acc / N;
+}
+
+// vamp_probit.cpp:936-1062 -- Newton-Raphson with backtracking (step scaled by 0.9 until the Armijo-type test of
+// :1023 holds).  Reference behaviour kept on purpose: the Newton weights use (2y-1) g without 1/sqrt(probit_var)
+// (:951-957) while the line search uses mlogL_probit with it; the relative-step exit returns the point BEFORE the
+// last step (:1044-1049); a singular Hessian yields a zero step (:991-994); at most 501 outer iterations.
+std::vector<double> vamp::Newton_method_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                            const std::vector<std::vector<double>>& Z, std::vector<double> eta) {
+    std::vector<double> eta_new = eta;
+    for (int it = 0; it <= 500; it++) {
+        std::vector<double> hess((size_t)C * C, 0.0), step(C, 0.0);
+        for (int i = 0; i < N; i++) {
+            const double g_i = gg[i] + inner_prod(Z[i], eta, 0);
+            const double s = 2 * y[i] - 1;
+            const double lam = s * (2.0 / sqrt(2 * M_PI) / erfcx(-s * g_i / sqrt(2.0)));
+            const double w = lam * (lam + g_i);
+            for (int j = 0; j < C; j++) {
+                step[j] += Z[i][j] * lam;                                              // Xtm * lambda (:976)
+                for (int k = 0; k < C; k++) hess[(size_t)j * C + k] += Z[i][j] * (Z[i][k] * w);   // Xtm * WXm (:975)
+            }
+        }
+        if (!lu_solve(hess, step, C)) step.assign(C, 0.0);
+        const std::vector<double> grad = grad_cov(y, gg, probit_var, Z, eta);
+        double fac = 1;
+        const double f0 = mlogL_probit(y, gg, probit_var, Z, eta);
+        std::vector<double> displ(C, 0.0);
+        for (int i = 1; i < 300; i++) {                                                // 0.9^300 = 1.8e-14
+            for (int j = 0; j < C; j++) {
+                displ[j] = fac * step[j];
+                eta_new[j] = eta[j] + displ[j];
+            }
+            if (mlogL_probit(y, gg, probit_var, Z, eta_new) <= f0 + inner_prod(displ, grad, 0) / 2) {
+                if (rank == 0 && verbose) std::cout << "scale = " << fac << std::endl;
+                break;
+            }
+            fac *= 0.9;
+        }
+        std::vector<double> diff = eta;
+        for (int j = 0; j < C; j++) diff[j] -= eta_new[j];
+        const double norm_eta = sqrt(l2_norm2(eta, 0));
+        const double rel_err = norm_eta == 0 ? 1 : sqrt(l2_norm2(diff, 0)) / norm_eta;
+        if (rank == 0 && verbose) std::cout << "[Newton_cov] it = " << it << ", relative err = " << rel_err << std::endl;
+        if (rel_err < 1e-4) {
+            if (rank == 0 && verbose)
+                std::cout << "[Newton_cov] relative error <= 1e-4 - stoping criteria satisfied" << std::endl;
+            break;
+        }
+        const double before = mlogL_probit(y, gg, probit_var, Z, eta);
+        eta = eta_new;
+        const double after = mlogL_probit(y, gg, probit_var, Z, eta);
+        if (after > before) {
+            if (rank == 0 && verbose) {
+                std::cout << "previous mlogL = " << before << ", current mlogL = " << after << std::endl;
+                std::cout << "likelihood value is not increasing -> terminating Newton-Raphson mehod" << std::endl;
+            }
+            break;
+        }
+    }
+    return eta;
 }

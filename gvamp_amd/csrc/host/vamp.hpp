@@ -37,6 +37,14 @@ private:
     std::string r1_init_file, estimate_file;
     int diagnostics = 0, store_iterates = 1, verbose = 1, fuse_solves = 1;
     double probit_var = 1;   // options.hpp:124
+    // covariates of the probit model (--C > 0, --cov-file): effects fitted once in iteration 1 (vamp_probit.cpp:110-126)
+    std::vector<double> cov_eff;                                                          // vamp.hpp:24
+    std::vector<double> grad_cov(const std::vector<double>& y, const std::vector<double>& gg, double probit_var,
+                                 const std::vector<std::vector<double>>& Z, const std::vector<double>& eta);    // :813-838
+    double mlogL_probit(const std::vector<double>& y, const std::vector<double>& gg, double probit_var,
+                        const std::vector<std::vector<double>>& Z, const std::vector<double>& eta);             // :840-857
+    std::vector<double> Newton_method_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                          const std::vector<std::vector<double>>& Z, std::vector<double> eta);  // :936-1062
 
     // device state (allocated in infere_linear)
     gv_ctx* ctx = nullptr;
@@ -57,6 +65,7 @@ private:
     void common_init(const Options& opt);
 
 public:
+    std::vector<double> get_cov_eff() const { return cov_eff; }                 // vamp.hpp:149
     vamp(int N, int M, int Mt, double gam1, double gamw, int max_iter, double rho, std::vector<double> vars,
          std::vector<double> probs, std::vector<double> true_signal, int rank, std::string out_dir,
          std::string out_name, std::string model, Options opt = Options());                    // vamp.cpp:32-82

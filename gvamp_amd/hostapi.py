@@ -22,7 +22,8 @@ class Opts(C.Structure):
                 ("gam1", C.c_double), ("gamw", C.c_double), ("L", C.c_int),
                 ("probs", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
                 ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double), ("use_XXT_denoiser", C.c_int),
-                ("bin_class", C.c_int), ("probit_var", C.c_double), ("fuse_solves", C.c_int)]
+                ("bin_class", C.c_int), ("probit_var", C.c_double), ("fuse_solves", C.c_int),
+                ("C", C.c_int), ("covs", C.POINTER(C.c_double)), ("cov_eff_out", C.POINTER(C.c_double))]
 
 
 class Iter(C.Structure):
@@ -68,7 +69,8 @@ class Result:
 def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_max_iter=2, EM_err_thr=1e-2,
                   stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1, use_lmmse_damp=0, gam1=1e-8, gamw=2.0,
                   true_signal=None, out_prefix=None, verbose=0, diagnostics=0, alpha_scale=1.0, mask4=None,
-                  nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0, fuse_solves=1):
+                  nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0, fuse_solves=1,
+                  covs=None):
     L = load()
     y = np.ascontiguousarray(y, dtype=np.float64)
     o = Opts()
@@ -87,6 +89,12 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     o.use_XXT_denoiser = use_XXT_denoiser
     o.bin_class, o.probit_var = int(model == "bin_class"), probit_var
     o.fuse_solves = fuse_solves
+    cov_eff = None
+    if covs is not None:
+        cz = np.ascontiguousarray(covs, dtype=np.float64)
+        cov_eff = np.zeros(cz.shape[1])
+        keep += [cz, cov_eff]
+        o.C, o.covs, o.cov_eff_out = cz.shape[1], _dp(cz), _dp(cov_eff)
     M = shard.M
     ts = np.ascontiguousarray(true_signal, dtype=np.float64) if true_signal is not None else None
     m4 = np.ascontiguousarray(mask4, dtype=np.uint8) if mask4 is not None else None
@@ -117,4 +125,5 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
         r.x2 = [hist[1][i, :M].copy() for i in range(n.value)]
         r.r1 = [hist[2][i, :M].copy() for i in range(n.value)]
     r.probs, r.vars = pout[:Lout.value].copy(), vout[:Lout.value].copy()
+    r.cov_eff = cov_eff
     return r

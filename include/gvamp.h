@@ -156,6 +156,10 @@ int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, co
  * N(p1, 1/tau1)], sums2[0] = sum_n g1d_bin_class, sums2[1] = sum_n (z1 - p1)^2.  y holds 0 / 1 (N-space handle). */
 int gv_probit_denoise(gv_ctx* ctx, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
                       double* sums2);
+/* the same with covariates (--C > 0): m_cov[i] = <Z[i], cov_eff> (vamp_probit.cpp:347,:364) shifts the argument of the
+ * probit likelihood, c = (p1 + m_cov) / sqrt(probit_var + 1/tau1).  m_cov: N-space handle or NULL. */
+int gv_probit_denoise_cov(gv_ctx* ctx, const gv_vec* p1, const gv_vec* y, const gv_vec* m_cov, double tau1,
+                          double probit_var, gv_vec* z1_out, double* sums2);
 
 /* ---- --use-XXT-denoiser 1 (vamp.cpp:169-170, :599-606; denoiserXXT.cpp): LMMSE through CG in N-space, matrix-free --
  * data::compute_people_statistics (data.cpp:558-716): per-individual mean, inverse std and count of the standardised

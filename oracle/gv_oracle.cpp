@@ -669,7 +669,124 @@ double Vamp::g1d_bin_class(double p, double tau1, double y, double m_cov) const 
     return 1 - Nc_phiyc / (1 + tau1 * o.probit_var) * ((2 * y - 1) * c + Nc_phiyc);
 }
 
-// vamp_probit.cpp:20-658 with C == 0 (no covariates): generalised VAMP for y in {0,1}.  The signal side (g1/g1d,
+double normal_cdf(double value) { return 0.5 * erfc(-value * M_SQRT1_2); }
+
+bool lu_solve(std::vector<double> A, std::vector<double>& b, int n) {
+    std::vector<int> piv(n);
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        double best = fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[(size_t)i * n + k]) > best) { best = fabs(A[(size_t)i * n + k]); p = i; }
+        if (best == 0.0) return false;
+        if (p != k) {
+            for (int j = 0; j < n; j++) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]);
+            std::swap(b[k], b[p]);
+        }
+        for (int i = k + 1; i < n; i++) {
+            const double f = A[(size_t)i * n + k] / A[(size_t)k * n + k];
+            A[(size_t)i * n + k] = f;
+            for (int j = k + 1; j < n; j++) A[(size_t)i * n + j] -= f * A[(size_t)k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int j = i + 1; j < n; j++) s -= A[(size_t)i * n + j] * b[j];
+        b[i] = s / A[(size_t)i * n + i];
+    }
+    return true;
+}
+
+double Vamp::cov_dot(int i, const std::vector<double>& eta) const {
+    double s = 0;
+    for (int j = 0; j < o.C; j++) s += o.covs[(size_t)i * o.C + j] * eta[j];
+    return s;
+}
+
+// vamp_probit.cpp:813-838 -- gradient of -logL / N of the probit regression of y on the covariates with offset gg
+std::vector<double> Vamp::grad_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                   const std::vector<double>& eta) const {
+    const int C = o.C;
+    std::vector<double> grad(C, 0.0);
+    for (int j = 0; j < C; j++)
+        for (int i = 0; i < N; i++) {
+            double g_i = gg[i] + cov_dot(i, eta);
+            double arg = (2 * y[i] - 1) / sqrt(o.probit_var) * g_i;
+            double ratio = 2.0 / sqrt(2 * M_PI) / erfcx(-arg / sqrt(2));
+            grad[j] += (-1) * ratio * (2 * y[i] - 1) / sqrt(o.probit_var) * o.covs[(size_t)i * C + j];
+        }
+    for (int j = 0; j < C; j++) grad[j] /= N;
+    return grad;
+}
+
+// vamp_probit.cpp:840-857
+double Vamp::mlogL_probit(const std::vector<double>& y, const std::vector<double>& gg, const std::vector<double>& eta) const {
+    double mlogL = 0;
+    for (int i = 0; i < N; i++) {
+        double g_i = gg[i] + cov_dot(i, eta);
+        double arg = (2 * y[i] - 1) / sqrt(o.probit_var) * g_i;
+        mlogL -= log(normal_cdf(arg));
+    }
+    return mlogL / N;
+}
+
+// vamp_probit.cpp:936-1062 -- Newton-Raphson with a backtracking line search on the covariate effects.  Kept as the
+// reference has them: lambda is formed WITHOUT the 1/sqrt(probit_var) that grad_cov / mlogL_probit apply (:951-957); the
+// stopping test on the relative step returns the PREVIOUS eta, not eta_new (:1044-1049, `return eta`); a singular
+// Hessian gives a zero step (:991-994).
+std::vector<double> Vamp::Newton_method_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                            std::vector<double> eta) const {
+    const int C = o.C;
+    const int rank0 = (!comm || comm->rank == 0);
+    std::vector<double> eta_new;
+    for (int it = 0; it <= 500; it++) {
+        std::vector<double> H((size_t)C * C, 0.0), RHS(C, 0.0), lambda(N);
+        for (int i = 0; i < N; i++) {
+            double g_i = gg[i] + cov_dot(i, eta);
+            double arg = (2 * y[i] - 1) * g_i;
+            double ratio = 2.0 / sqrt(2 * M_PI) / erfcx(-arg / sqrt(2));
+            lambda[i] = ratio * (2 * y[i] - 1);
+            const double w = lambda[i] * (lambda[i] + g_i);
+            for (int j = 0; j < C; j++) {
+                const double zij = o.covs[(size_t)i * C + j];
+                RHS[j] += zij * lambda[i];
+                for (int k = 0; k < C; k++) H[(size_t)j * C + k] += zij * (o.covs[(size_t)i * C + k] * w);
+            }
+        }
+        if (!lu_solve(H, RHS, C)) RHS.assign(C, 0.0);
+        eta_new = eta;
+        std::vector<double> displ(C, 0.0);
+        std::vector<double> grad = grad_cov(y, gg, eta);
+        double scale = 1;
+        double init_val = mlogL_probit(y, gg, eta);
+        for (int i = 1; i < 300; i++) {
+            for (int j = 0; j < C; j++) displ[j] = scale * RHS[j];
+            for (int j = 0; j < C; j++) eta_new[j] = eta[j] + displ[j];
+            double curr_val = mlogL_probit(y, gg, eta_new);
+            double dg = 0;
+            for (int j = 0; j < C; j++) dg += displ[j] * grad[j];
+            if (curr_val <= init_val + dg / 2) break;
+            scale *= 0.9;
+        }
+        double d2 = 0, n2 = 0;
+        for (int j = 0; j < C; j++) {
+            d2 += (eta[j] - eta_new[j]) * (eta[j] - eta_new[j]);
+            n2 += eta[j] * eta[j];
+        }
+        double norm_eta = sqrt(n2);
+        double rel_err = (norm_eta == 0) ? 1 : sqrt(d2) / norm_eta;
+        if (o.verbose && rank0) printf("[Newton_cov] it = %d, relative err = %.10g\n", it, rel_err);
+        if (rel_err < 1e-4) break;
+        init_val = mlogL_probit(y, gg, eta);
+        eta = eta_new;
+        double curr_val = mlogL_probit(y, gg, eta);
+        if (curr_val > init_val) break;
+    }
+    return eta;
+}
+
+// vamp_probit.cpp:20-658 : generalised VAMP for y in {0,1}.  The signal side (g1/g1d,
 // updatePrior, CG, Onsager probe) is shared with the linear model; the z side adds the probit denoiser over N.
 // Diagnostics against the true signal (probit_err_measures, "true gam" prints) are not restated: they only print.
 std::vector<double> Vamp::infere_bin_class() {
@@ -682,11 +799,18 @@ std::vector<double> Vamp::infere_bin_class() {
     alpha1 = 0;
     std::vector<double> z1_hat(N, 0.0), p2(4 * d->mbytes, 0.0), z2_hat;
     const int rank0 = (!comm || comm->rank == 0);
+    const int C = o.C;
+    if (C > 0) cov_eff = std::vector<double>(C, 0.0);                    // :84-85
+    std::vector<double> m_cov(N, 0.0);                                   // inner_prod(Z[i], cov_eff) of :347,:364
     for (int it = 1; it <= o.iterations; it++) {
         double t_start = now_s();
         long ax0 = d->n_ax, atx0 = d->n_atx;
         IterTrace tr;
         memset(&tr, 0, sizeof(tr));
+        if (it == 1 && C > 0) {                                          // :110-126: once, with gg = z1_hat = 0
+            cov_eff = Newton_method_cov(d->filter_pheno(), z1_hat, cov_eff);
+            for (int i = 0; i < N; i++) m_cov[i] = cov_dot(i, cov_eff);
+        }
         double rho_it = 1;                                               // :71 (overrides :66-70)
         x1_hat_prev = x1_hat;
         double rho_it2 = o.rho, alpha1_prev = alpha1, gam1_reEst_prev;
@@ -731,10 +855,10 @@ std::vector<double> Vamp::infere_bin_class() {
         std::vector<double> y = d->filter_pheno();
         double beta1 = 0;
         {   // :335-379, auto_var_max_iter = 1: one round
-            for (int i = 0; i < N; i++) z1_hat[i] = g1_bin_class(p1[i], tau1, y[i], 0);
+            for (int i = 0; i < N; i++) z1_hat[i] = g1_bin_class(p1[i], tau1, y[i], m_cov[i]);
             std::vector<double> z1_hat_m_p1 = z1_hat;
             for (int i0 = 0; i0 < N; i0++) z1_hat_m_p1[i0] -= p1[i0];
-            for (int i = 0; i < N; i++) beta1 += g1d_bin_class(p1[i], tau1, y[i], 0);
+            for (int i = 0; i < N; i++) beta1 += g1d_bin_class(p1[i], tau1, y[i], m_cov[i]);
             beta1 /= N;
             double zeta1 = tau1 / beta1;
             if (it > 1) tau1 = std::min(std::max(1 / (1 / zeta1 + l2_norm2(z1_hat_m_p1, 0, comm) / N), gamma_min), gamma_max);

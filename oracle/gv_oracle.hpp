@@ -58,6 +58,10 @@ double student_t_two_sided(double t, double nu);
 // (libm erfc / exp where they are accurate, the asymptotic series beyond, the reflection 2 exp(x^2) - erfcx(-x) for x < 0)
 // instead of the reference's polynomial.
 double erfcx(double x);
+double normal_cdf(double value);                                                             // utilities.cpp:336-339
+// dense solve A x = b (n x n, row-major) by LU with partial pivoting: what Newton_method_cov takes from Boost uBLAS
+// (lu_factorize / lu_substitute, vamp_probit.cpp:983-996).  Returns false when a pivot is exactly zero ("singular").
+bool lu_solve(std::vector<double> A, std::vector<double>& b, int n);
 double linear_reg1d_pvals(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, int n);
 
 // ---- class data (data.hpp:93-140) --------------------------------------------------------------
@@ -107,8 +111,10 @@ struct VampOpts {
     std::string out_prefix;               // "" = no files; else out_dir+out_name as in vamp.cpp:435
     int verbose = 0;
     int use_XXT_denoiser = 0;             // vamp.cpp:68,169-170,599-606: LMMSE via CG in N-space (denoiserXXT.cpp)
-    int bin_class = 0;                    // --model bin_class: vamp::infere_bin_class (vamp_probit.cpp:20-658), C = 0
+    int bin_class = 0;                    // --model bin_class: vamp::infere_bin_class (vamp_probit.cpp:20-658)
     double probit_var = 1.0;              // options.hpp:124
+    int C = 0;                            // --C: number of covariates of the probit model (options.cpp:376)
+    std::vector<double> covs;             // N x C row-major: data::covs of read_covariates (data.cpp:286-331)
     std::vector<double> r1_init;          // restart (vamp.cpp:226-233): local shard of the r1 file, non-empty = restart
     std::vector<double> x_init;           // --init-est 1 (vamp.cpp:244-258): local shard of the estimate file
 };
@@ -145,7 +151,16 @@ struct Vamp {
     double g2d_onsager(double gam2, double tau);                   // :871-889
     double g1_bin_class(double p, double tau1, double y, double m_cov) const;              // vamp_probit.cpp:661-687
     double g1d_bin_class(double p, double tau1, double y, double m_cov) const;             // vamp_probit.cpp:689-705
-    std::vector<double> infere_bin_class();                                                // vamp_probit.cpp:20-658 (C = 0)
+    std::vector<double> infere_bin_class();                                                // vamp_probit.cpp:20-658
+    // covariates of the probit model (--C > 0): effects fitted once, in iteration 1 (vamp_probit.cpp:110-126)
+    std::vector<double> cov_eff;                                                           // vamp.hpp:24
+    double cov_dot(int i, const std::vector<double>& eta) const;                           // inner_prod(Z[i], eta, 0)
+    std::vector<double> grad_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                 const std::vector<double>& eta) const;                    // vamp_probit.cpp:813-838
+    double mlogL_probit(const std::vector<double>& y, const std::vector<double>& gg,
+                        const std::vector<double>& eta) const;                             // vamp_probit.cpp:840-857
+    std::vector<double> Newton_method_cov(const std::vector<double>& y, const std::vector<double>& gg,
+                                          std::vector<double> eta) const;                  // vamp_probit.cpp:936-1062
     std::vector<double> lmmse_multAAT(const std::vector<double>& u, double tau);            // denoiserXXT.cpp:15-35
     std::vector<double> CG_solverAAT(const std::vector<double>& v, const std::vector<double>& mu_start, double tau,
                                      int save);                                            // denoiserXXT.cpp:52-130

@@ -83,8 +83,10 @@ struct gvo_params {
     int use_XXT_denoiser;       // vamp.cpp:169-170, :599-606
     const double* r1_init;      // Mt or NULL: restart (vamp.cpp:226-233)
     const double* x_init;       // Mt or NULL: --init-est 1 (vamp.cpp:244-258)
-    int bin_class;              // --model bin_class (vamp_probit.cpp), C = 0
+    int bin_class;              // --model bin_class (vamp_probit.cpp)
     double probit_var;
+    int C;                      // covariates of the probit model (--C)
+    const double* covs;         // N x C row-major, or NULL
 };
 
 struct gvo_run {
@@ -93,6 +95,7 @@ struct gvo_run {
     std::vector<IterTrace> trace;              // of shard 0 (scalars agree across shards)
     std::vector<std::vector<double>> x1_hist, x2_hist, r1_hist;  // [it][Mt]
     std::vector<double> gam1s, gam2s, R2trains, probs, vars;
+    std::vector<double> cov_eff;               // probit covariate effects (vamp.hpp:24)
     std::vector<std::vector<double>> cg_relres;
     std::vector<double> mave, msig;            // Mt
 };
@@ -289,9 +292,14 @@ static void run_shard(const gvo_params* p, const unsigned char* bed_full, const 
     if (p->x_init) o.x_init.assign(p->x_init + S, p->x_init + S + M);
     o.bin_class = p->bin_class;
     o.probit_var = p->probit_var;
+    if (p->C > 0 && p->covs) {
+        o.C = p->C;
+        o.covs.assign(p->covs, p->covs + (size_t)p->N * p->C);
+    }
     Vamp v(&d, o);
     std::vector<double> x = v.infere();
     std::lock_guard<std::mutex> lk(*mu);
+    if (rank == 0 || p->shard_rank >= 0) out->cov_eff = v.cov_eff;
     size_t nit = v.x1_hist.size();
     if (out->x1_hist.size() < nit) {
         out->x1_hist.resize(nit, std::vector<double>(p->Mt, 0.0));
@@ -372,6 +380,38 @@ void gvo_run_trace_probit(const gvo_run* r, int it, double* out3) {
     out3[2] = r->trace[it].tau1_next;
 }
 // vamp::g1_bin_class / g1d_bin_class on a grid (y in {0,1}), and erfcx
+int gvo_run_cov_eff(const gvo_run* r, double* out, int cap) {
+    for (int i = 0; i < (int)r->cov_eff.size() && i < cap; i++) out[i] = r->cov_eff[i];
+    return (int)r->cov_eff.size();
+}
+// vamp::Newton_method_cov (vamp_probit.cpp:936-1062) on its own: y, gg of length N, covs N x C row-major, eta0 / out of
+// length C; also the value of mlogL_probit and grad_cov at the returned point (stats[0], grad[C])
+void gvo_newton_cov(int N, int C, const double* covs, const double* y, const double* gg, double probit_var,
+                    const double* eta0, double* eta_out, double* mlogL_out, double* grad_out) {
+    Data d;
+    d.N = N; d.M = 1; d.Mt = 1;
+    VampOpts o;
+    o.probs = {1.0};
+    o.vars = {0.0};
+    o.probit_var = probit_var;
+    o.C = C;
+    o.covs.assign(covs, covs + (size_t)N * C);
+    Vamp v(&d, o);
+    std::vector<double> yy(y, y + N), g(gg, gg + N), e0(eta0, eta0 + C);
+    std::vector<double> e = v.Newton_method_cov(yy, g, e0);
+    for (int j = 0; j < C; j++) eta_out[j] = e[j];
+    if (mlogL_out) *mlogL_out = v.mlogL_probit(yy, g, e);
+    if (grad_out) {
+        std::vector<double> gr = v.grad_cov(yy, g, e);
+        for (int j = 0; j < C; j++) grad_out[j] = gr[j];
+    }
+}
+int gvo_lu_solve(const double* A, double* b, int n) {
+    std::vector<double> a(A, A + (size_t)n * n), bb(b, b + n);
+    const bool ok = lu_solve(a, bb, n);
+    for (int i = 0; i < n; i++) b[i] = bb[i];
+    return ok ? 0 : 1;
+}
 void gvo_probit_g(const double* p, const double* y, long n, double tau1, double probit_var, double* g, double* gd) {
     Data d;
     d.N = 4; d.M = 1; d.Mt = 1;
@@ -383,6 +423,20 @@ void gvo_probit_g(const double* p, const double* y, long n, double tau1, double 
     for (long i = 0; i < n; i++) {
         g[i] = v.g1_bin_class(p[i], tau1, y[i], 0);
         gd[i] = v.g1d_bin_class(p[i], tau1, y[i], 0);
+    }
+}
+void gvo_probit_g_cov(const double* p, const double* y, const double* m_cov, long n, double tau1, double probit_var,
+                      double* g, double* gd) {
+    Data d;
+    d.N = 4; d.M = 1; d.Mt = 1;
+    VampOpts o;
+    o.probs = {1.0};
+    o.vars = {0.0};
+    o.probit_var = probit_var;
+    Vamp v(&d, o);
+    for (long i = 0; i < n; i++) {
+        g[i] = v.g1_bin_class(p[i], tau1, y[i], m_cov[i]);
+        gd[i] = v.g1d_bin_class(p[i], tau1, y[i], m_cov[i]);
     }
 }
 double gvo_erfcx(double x) { return erfcx(x); }

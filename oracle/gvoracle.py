@@ -30,7 +30,7 @@ class Params(C.Structure):
                 ("phen_mode", C.c_int), ("is_na", C.POINTER(C.c_ubyte)),
                 ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int),
                 ("r1_init", C.POINTER(C.c_double)), ("x_init", C.POINTER(C.c_double)),
-                ("bin_class", C.c_int), ("probit_var", C.c_double)]
+                ("bin_class", C.c_int), ("probit_var", C.c_double), ("C", C.c_int), ("covs", C.POINTER(C.c_double))]
 
 
 def build(force=False):
@@ -77,6 +77,12 @@ def lib():
         L.gvo_people_stats.argtypes = [up, C.c_int, C.c_int, up, C.c_int, dp, dp, dp]
         L.gvo_run_trace_probit.argtypes = [C.c_void_p, C.c_int, dp]
         L.gvo_probit_g.argtypes = [dp, dp, C.c_long, C.c_double, C.c_double, dp, dp]
+        L.gvo_probit_g_cov.argtypes = [dp, dp, dp, C.c_long, C.c_double, C.c_double, dp, dp]
+        L.gvo_newton_cov.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, dp, C.POINTER(C.c_double), dp]
+        L.gvo_lu_solve.restype = C.c_int
+        L.gvo_lu_solve.argtypes = [dp, dp, C.c_int]
+        L.gvo_run_cov_eff.restype = C.c_int
+        L.gvo_run_cov_eff.argtypes = [C.c_void_p, dp, C.c_int]
         L.gvo_erfcx.restype = C.c_double
         L.gvo_erfcx.argtypes = [C.c_double]
         L.gvo_student_t_two_sided.restype = C.c_double
@@ -183,6 +189,33 @@ def probit_g(p, y, tau1, probit_var=1.0):
     return g, gd
 
 
+def probit_g_cov(p, y, m_cov, tau1, probit_var=1.0):
+    """g1_bin_class / g1d_bin_class with the covariate offset m_cov[i] = <Z[i], cov_eff> (vamp_probit.cpp:347,:364)."""
+    p, y, m = _f64(p), _f64(y), _f64(m_cov)
+    g, gd = np.empty(p.size), np.empty(p.size)
+    lib().gvo_probit_g_cov(_dp(p), _dp(y), _dp(m), p.size, tau1, probit_var, _dp(g), _dp(gd))
+    return g, gd
+
+
+def newton_cov(covs, y, gg=None, probit_var=1.0, eta0=None):
+    """vamp::Newton_method_cov (vamp_probit.cpp:936-1062): (eta, mlogL_probit(eta), grad_cov(eta))."""
+    covs = np.ascontiguousarray(covs, dtype=np.float64)
+    N, Cn = covs.shape
+    y = _f64(y)
+    gg = _f64(gg) if gg is not None else np.zeros(N)
+    e0 = _f64(eta0) if eta0 is not None else np.zeros(Cn)
+    out, grad, ml = np.empty(Cn), np.empty(Cn), C.c_double()
+    lib().gvo_newton_cov(N, Cn, _dp(covs), _dp(y), _dp(gg), probit_var, _dp(e0), _dp(out), C.byref(ml), _dp(grad))
+    return out, ml.value, grad
+
+
+def lu_solve(A, b):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    x = np.array(b, dtype=np.float64)
+    rc = lib().gvo_lu_solve(_dp(A), _dp(x), A.shape[0])
+    return x if rc == 0 else None
+
+
 def erfcx(x):
     return lib().gvo_erfcx(float(x))
 
@@ -248,6 +281,8 @@ class Run:
             self.relres.append(rb[:k].copy())
         k = L.gvo_run_R2trains(h, _dp(rb), rb.size)
         self.R2trains = rb[:k].copy()
+        k = L.gvo_run_cov_eff(h, _dp(rb), rb.size)
+        self.cov_eff = rb[:k].copy()
         L.gvo_run_free(h)
 
 
@@ -255,7 +290,7 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
            EM_max_iter=2, EM_err_thr=1e-2, stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1,
            use_lmmse_damp=0, gam1=1e-8, gamw=2.0, true_signal=None, out_prefix=None, verbose=0, nthreads=1,
            alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0, r1_init=None, x_init=None,
-           model="linear", probit_var=1.0):
+           model="linear", probit_var=1.0, covs=None):
     """vamp::infere (linear) on `nshards` marker shards.  `allreduce(np_array)` is an in-place SUM callback
     used when shard_rank >= 0 (one shard per process, e.g. torch.distributed gloo)."""
     bed_full, y = _u8(bed_full), _f64(y)
@@ -280,6 +315,10 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
     p.verbose, p.nthreads, p.alpha_scale = verbose, nthreads, alpha_scale
     p.use_XXT_denoiser = use_XXT_denoiser
     p.bin_class, p.probit_var = int(model == "bin_class"), probit_var
+    if covs is not None:
+        cz = np.ascontiguousarray(covs, dtype=np.float64)
+        keep.append(cz)
+        p.C, p.covs = cz.shape[1], _dp(cz)
     if r1_init is not None:
         ri = _f64(r1_init)
         keep.append(ri)

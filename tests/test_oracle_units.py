@@ -152,3 +152,38 @@ def test_erfcx_and_probit_denoiser(oracle):
         gp, _ = oracle.probit_g(p + h, np.full(4, yv), tau, pv)
         gm, _ = oracle.probit_g(p - h, np.full(4, yv), tau, pv)
         assert np.allclose(gd, (gp - gm) / (2 * h), rtol=1e-6)
+
+
+def test_newton_method_cov_is_the_probit_regression_fit(oracle):
+    """vamp_probit.cpp:936-1062 with gg = 0 and probit_var = 1 is the MLE of a probit regression; checked against an
+    independent optimiser.  The relative-step exit (1e-4) returns the point before the last step, hence ~1e-6."""
+    from scipy.optimize import minimize
+    from scipy.stats import norm
+    rng = np.random.default_rng(0)
+    N, C = 4000, 4
+    Z = np.c_[np.ones(N), rng.standard_normal((N, C - 1))]
+    eta_true = np.array([0.3, -0.5, 0.8, 0.1])
+    y = (Z @ eta_true + rng.standard_normal(N) > 0).astype(float)
+    eta, ml, grad = oracle.newton_cov(Z, y)
+    r = minimize(lambda b: -np.mean(norm.logcdf((2 * y - 1) * (Z @ b))), np.zeros(C), method="BFGS", tol=1e-12)
+    assert np.allclose(eta, r.x, atol=5e-6)
+    assert np.isclose(ml, r.fun, rtol=1e-10) and np.abs(grad).max() < 1e-6
+    # with an offset the fit moves the intercept accordingly
+    eta2, _, _ = oracle.newton_cov(Z, y, gg=np.full(N, 0.25))
+    assert np.isclose(eta2[0], eta[0] - 0.25, atol=1e-4) and np.allclose(eta2[1:], eta[1:], atol=1e-4)
+
+
+def test_lu_solve_and_covariate_offset(oracle):
+    rng = np.random.default_rng(1)
+    A, b = rng.standard_normal((6, 6)), rng.standard_normal(6)
+    assert np.allclose(oracle.lu_solve(A, b), np.linalg.solve(A, b), rtol=1e-12)
+    A[[0, 3]] = A[[3, 0]]
+    A[0, 0] = 0.0                                         # forces a row exchange
+    assert np.allclose(oracle.lu_solve(A, b), np.linalg.solve(A, b), rtol=1e-10)
+    assert oracle.lu_solve(np.zeros((3, 3)), np.ones(3)) is None
+    # m_cov shifts the likelihood argument only: g1(p, m) - p == g1(p + m, 0) - (p + m)   (vamp_probit.cpp:661-687)
+    p, m = rng.standard_normal(50), rng.standard_normal(50)
+    y = (rng.random(50) < 0.5).astype(float)
+    g, gd = oracle.probit_g_cov(p, y, m, 0.7)
+    g0, gd0 = oracle.probit_g(p + m, y, 0.7)
+    assert np.allclose(g - p, g0 - (p + m), rtol=1e-12) and np.allclose(gd, gd0, rtol=1e-12)
