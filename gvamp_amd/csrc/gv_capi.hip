@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "gv_internal.h"
 
@@ -154,6 +155,25 @@ int comm_allreduce(gv_ctx* c, double* dev, size_t n) {
     HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// the Student-t tails of the p-values are independent per marker and run on the host: spread over the host cores
+template <class F>
+void host_parallel_for(int64_t n, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 32) nt = 32;
+    if (nt < 2 || n < 4096) {
+        for (int64_t k = 0; k < n; k++) f(k);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const int64_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo >= hi) break;
+        pool.emplace_back([=, &f]() { for (int64_t k = lo; k < hi; k++) f(k); });
+    }
+    for (std::thread& th : pool) th.join();
 }
 
 struct Timer {
@@ -1274,7 +1294,7 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
         PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
         PV_HIP(hipStreamSynchronize(c->stream));
         // y_mark = y_mod + gen_part * x1_hat[k] (data.cpp:1145-1148): the marker's own column, c = x1_hat[k] / sqrt(N)
-        for (int64_t k = 0; k < M; k++) pvals[k] = marker_test(k, xh[k] / sqrtN);
+        host_parallel_for(M, [&](int64_t k) { pvals[k] = marker_test(k, xh[k] / sqrtN); });
     } else {
         PV_TRY(vec_new(c, GV_SPACE_N, &ych));
         PV_TRY(vec_new(c, GV_SPACE_M, &xch));
@@ -1293,8 +1313,9 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
             PV_TRY(marker_sums_p_p2(c, ych->d, sq->d, sums_dev));
             PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
             PV_HIP(hipStreamSynchronize(c->stream));
-            for (int64_t k = 0; k < M; k++)
+            host_parallel_for(M, [&](int64_t k) {
                 if (chrom[k] == ch) pvals[k] = marker_test(k, 0.0);
+            });
         }
     }
 #undef PV_TRY
