@@ -568,6 +568,8 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
                       << "********************" << std::endl;
         if (it == 1 && C > 0) {                                           // :110-131: once, with gg = z1_hat = 0
             const double tc = now_s();
+            // y: the filtered phenotype (NA -> 0), i.e. what the z-side denoiser sees (:320).  The reference hands over
+            // get_phen() (vamp.cpp:151), in which an NA is DBL_MAX and the fit degenerates; equal when nothing is missing.
             std::vector<double> yh = dataset->filter_pheno();
             yh.resize(N, 0.0);
             cov_eff = Newton_method_cov(yh, std::vector<double>(N, 0.0), Z, cov_eff);

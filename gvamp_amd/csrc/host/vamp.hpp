@@ -74,7 +74,7 @@ public:
 
     std::vector<double> infere(data* dataset);           // vamp.cpp:149-183
     std::vector<double> infere_linear(data* dataset);    // vamp.cpp:190-803
-    std::vector<double> infere_bin_class(data* dataset); // vamp_probit.cpp:20-658 (no covariates)
+    std::vector<double> infere_bin_class(data* dataset); // vamp_probit.cpp:20-658
     double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
     void draw_onsager_probe(data* dataset);                                   // vamp.cpp:875-882 (host RNG)
     // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2

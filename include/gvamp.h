@@ -152,7 +152,7 @@ int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, 
 int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
                    const double* vars, int L, double* sums);
 /* ---- --model bin_class (vamp_probit.cpp): the z-side probit denoiser over the N individuals ------------------------
- * vamp::g1_bin_class / g1d_bin_class (vamp_probit.cpp:661-705; loops :335-352), no covariates: z1 = E[z | y, cavity
+ * vamp::g1_bin_class / g1d_bin_class (vamp_probit.cpp:661-705; loops :335-352) with m_cov = 0: z1 = E[z | y, cavity
  * N(p1, 1/tau1)], sums2[0] = sum_n g1d_bin_class, sums2[1] = sum_n (z1 - p1)^2.  y holds 0 / 1 (N-space handle). */
 int gv_probit_denoise(gv_ctx* ctx, const gv_vec* p1, const gv_vec* y, double tau1, double probit_var, gv_vec* z1_out,
                       double* sums2);

@@ -808,6 +808,9 @@ std::vector<double> Vamp::infere_bin_class() {
         IterTrace tr;
         memset(&tr, 0, sizeof(tr));
         if (it == 1 && C > 0) {                                          // :110-126: once, with gg = z1_hat = 0
+            // the reference passes its member y = get_phen() (vamp.cpp:151), where an NA phenotype is DBL_MAX and the fit
+            // degenerates to inf/NaN; the filtered phenotype (NA -> 0, what the z-side denoiser sees, :320) is used here.
+            // The two agree whenever no phenotype is missing.
             cov_eff = Newton_method_cov(d->filter_pheno(), z1_hat, cov_eff);
             for (int i = 0; i < N; i++) m_cov[i] = cov_dot(i, cov_eff);
         }

@@ -1,4 +1,4 @@
-"""--model bin_class (vamp_probit.cpp, BASELINE config 4 without covariates): the probit z-denoiser kernel and full
+"""--model bin_class (vamp_probit.cpp, BASELINE config 4, with and without covariates): the probit z-denoiser kernel and full
 generalised-VAMP runs of the product against the CPU oracle."""
 import os
 import subprocess
