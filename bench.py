@@ -206,7 +206,11 @@ def main():
                    "ingest_s": round(t_ingest, 2)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic,
-                     "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4)},
+                     "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4),
+                     # context ("also report vs measured copy bandwidth"): what plain streaming kernels reach
+                     # on this box, measured now -- a read-only stream over the same resident stripes, and a copy
+                     "read_stream_GBps": round(sh.read_bandwidth(1 << 30, 3), 1),
+                     "copy_GBps_read_plus_write": round(sh.copy_bandwidth(1 << 30, 10), 1)},
         "kernels": {"ax": {"avg_ms": round(ms_ax, 4), "GBps": round(ax_gbps, 1), "launches": cnt["n_ax_kernel"]},
                     "atx": {"avg_ms": round(ms_atx, 4), "GBps": round(atx_gbps, 1), "launches": cnt["n_atx_kernel"]}},
     }

@@ -22,7 +22,7 @@ EXPORTS = [
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
-    "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth",
+    "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
 
@@ -118,6 +118,7 @@ def load():
     L.gv_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.gv_reset_counters.argtypes = [vp]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
+    L.gv_read_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     _LIB = L
     return L
 
@@ -407,4 +408,10 @@ class Shard:
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         out = C.c_double()
         self._ck(self.L.gv_copy_bandwidth(self.h, nbytes, reps, C.byref(out)))
+        return out.value
+
+    def read_bandwidth(self, nbytes=1 << 30, reps=5):
+        """read-only stream probe over the resident stripes (or a scratch buffer): GB/s"""
+        out = C.c_double()
+        self._ck(self.L.gv_read_bandwidth(self.h, nbytes, reps, C.byref(out)))
         return out.value

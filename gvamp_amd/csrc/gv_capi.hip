@@ -1431,4 +1431,38 @@ int gv_copy_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {
     return 0;
 }
 
+// read-only stream probe: the resident stripes when there are any (the very bytes the matvecs stream), else a scratch
+// buffer of nbytes.  ~45k waves of equal contiguous runs, like a matvec launch.
+int gv_read_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {
+    void* buf = nullptr;
+    bool own = false;
+    size_t have = 0;
+    if (c->have_stripes && c->plan.stripes_m) {
+        buf = c->plan.stripes_m;
+        have = (size_t)c->plan.nrg_m * c->plan.nkb_m * 4096;
+    }
+    if (have < (size_t)64 << 20) {
+        have = nbytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : nbytes;
+        HIPCHK(c, hipMalloc(&buf, have));
+        HIPCHK(c, hipMemsetAsync(buf, 1, have, c->stream));
+        own = true;
+    }
+    const int64_t blocks = (int64_t)(have / 4096);
+    int64_t nwaves = 45056;
+    if (blocks / nwaves < 16) nwaves = blocks / 16 > 0 ? blocks / 16 : 1;
+    const int64_t bpw = blocks / nwaves;
+    unsigned int* sink = reinterpret_cast<unsigned int*>(c->red_out);
+    gvk::read_bw(c->stream, buf, bpw, nwaves, sink);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; i++) gvk::read_bw(c->stream, buf, bpw, nwaves, sink);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    KCHK(c);
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *gbps = (double)bpw * nwaves * 4096.0 * reps / (ms * 1e-3) / 1e9;
+    if (own) (void)hipFree(buf);
+    return 0;
+}
+
 }  // extern "C"

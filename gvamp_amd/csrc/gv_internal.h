@@ -122,4 +122,5 @@ void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_p
 void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& om_vars,
                  double* partial, double* out);               // out[0..1+2(L-1))
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n);
+void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink);
 }  // namespace gvk

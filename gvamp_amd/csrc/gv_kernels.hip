@@ -375,6 +375,33 @@ __global__ void k_copy(const double2* __restrict__ src, double2* __restrict__ ds
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n2; i += stride) dst[i] = src[i];
 }
+// read-only stream probe with the access shape of the matvec kernels: every wave walks its own contiguous run of
+// 4 KiB blocks (one coalesced, non-temporal KiB per instruction), two blocks in flight, nothing but an XOR per load.
+// What it reaches is the ceiling a streaming kernel can be held against on this part.
+typedef unsigned int rd_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 3) void k_read_stream(const rd_u32x4* __restrict__ src, int64_t blocks_per_wave,
+                                                        int64_t nwaves, unsigned int* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nwaves) return;
+    const rd_u32x4* p = src + w * blocks_per_wave * 256 + lane;
+    rd_u32x4 acc = {0, 0, 0, 0};
+    rd_u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = __builtin_nontemporal_load(p + i * 64);
+    for (int64_t k = 1; k < blocks_per_wave; k++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[i] = __builtin_nontemporal_load(p + k * 256 + i * 64);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc ^= a[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = b[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc ^= a[i];
+    const unsigned int v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (v == 0x9E3779B9u) sink[0] = v;   // practically never: keeps the loads alive without a store stream
+}
 
 // ---- reductions: block partials -> one ordered final pass (deterministic; SURVEY 7 parity trap d) ------------
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, int nblocks, int K,
@@ -711,6 +738,10 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
 
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n) {
     hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, s, (const double2*)src, (double2*)dst, n / 2);
+}
+void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink) {
+    hipLaunchKernelGGL(k_read_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, (const rd_u32x4*)src,
+                       blocks_per_wave, nwaves, sink);
 }
 
 }  // namespace gvk

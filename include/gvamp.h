@@ -217,6 +217,10 @@ int gv_get_counters(gv_ctx* ctx, gv_counters* out);
 int gv_reset_counters(gv_ctx* ctx);
 /* device copy bandwidth probe: copies nbytes device->device `reps` times, returns GB/s (read+write bytes) */
 int gv_copy_bandwidth(gv_ctx* ctx, size_t nbytes, int reps, double* gbps);
+/* read-only stream probe with the access shape of the matvec kernels (every wave walks a contiguous run of 4 KiB blocks,
+ * non-temporal 16-byte loads, nothing else): GB/s over the resident marker-major stripes when there are any, else over a
+ * scratch buffer of nbytes.  The ceiling a streaming kernel can be held against on this part. */
+int gv_read_bandwidth(gv_ctx* ctx, size_t nbytes, int reps, double* gbps);
 
 #ifdef __cplusplus
 }
