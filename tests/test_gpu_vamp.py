@@ -152,11 +152,12 @@ def test_unknown_flag_and_missing_bed_are_fatal():
     assert r.returncode != 0 and "no bed file" in r.stdout
 
 
-@pytest.mark.parametrize("nshards,mode", [(2, 1), (8, 1), (2, 0)])
-def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode):
+@pytest.mark.parametrize("nshards,mode,fuse", [(2, 1, 1), (8, 1, 1), (2, 0, 1), (2, 1, 2), (8, 1, 2), (4, 1, 0)])
+def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode, fuse):
     """Marker-sharded VAMP exactly as the reference shards over MPI ranks (divide_work, one N-vector all-reduce per
     Ax, Hutchinson probe seeded seed + S): `nshards` contexts on this GPU joined by the in-process communicator,
-    compared with what the REAL reference wrote at np = 2 and np = 8 (survey probe)."""
+    compared with what the REAL reference wrote at np = 2 and np = 8 (survey probe).  fuse = --fuse-solves level (2 is
+    what bench.py runs on N GPUs); np = 4 has no reference files and is compared with the oracle's 4-shard run."""
     import threading
     raw = np.frombuffer(lzma.open(os.path.join(G, "toy.bed.xz")).read(), dtype=np.uint8)[3:]
     N, Mt = 2000, 10000
@@ -169,7 +170,7 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode):
         b, y = hostapi.sim_phen(sh, 0.5, 500, 7)
         assert np.allclose(b, beta, rtol=1e-13, atol=0)
     results, errors = [None] * nshards, []
-    group = 1000 + 10 * nshards + mode
+    group = 1000 + 100 * fuse + 10 * nshards + mode
 
     def work(rank):
         try:
@@ -181,7 +182,7 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode):
                 sh.set_kernel_mode(mode)
                 sh.comm_init_local(group, nshards, rank)
                 r = hostapi.infere_linear(sh, y, PROBS, VARS, iterations=3, CG_max_iter=20, rho=0.5, seed=7, gam1=1e-8,
-                                          gamw=2.0, true_signal=beta[S:S + M], rank=rank)
+                                          gamw=2.0, true_signal=beta[S:S + M], rank=rank, fuse_solves=fuse)
                 results[rank] = (S, M, r)
         except Exception as e:   # noqa: BLE001
             errors.append((rank, repr(e)))
@@ -192,15 +193,21 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode):
     for t in th:
         t.join(timeout=600)
     assert not errors, errors
-    pre = os.path.join(G, "sim_np%d_" % nshards)
     x1_3 = np.concatenate([res[2].x1[2] for res in results])
     x2_1 = np.concatenate([res[2].x2[0] for res in results])
     x2_3 = np.concatenate([res[2].x2[2] for res in results])
     r1_3 = np.concatenate([res[2].r1[2] for res in results])
-    assert rel(x2_1, np.fromfile(pre + "it_1_x2_hat.bin")) < TIGHT
-    assert rel(x1_3, np.fromfile(pre + "it_3.bin")) < TIGHT
-    assert rel(x2_3, np.fromfile(pre + "it_3_x2_hat.bin")) < TIGHT
-    assert rel(r1_3, np.fromfile(pre + "r1_it_3.bin")) < TIGHT
+    pre = os.path.join(G, "sim_np%d_" % nshards)
+    if os.path.exists(pre + "it_3.bin"):
+        assert rel(x2_1, np.fromfile(pre + "it_1_x2_hat.bin")) < TIGHT
+        assert rel(x1_3, np.fromfile(pre + "it_3.bin")) < TIGHT
+        assert rel(x2_3, np.fromfile(pre + "it_3_x2_hat.bin")) < TIGHT
+        assert rel(r1_3, np.fromfile(pre + "r1_it_3.bin")) < TIGHT
+    else:
+        from oracle import gvoracle
+        ref = gvoracle.infere(raw, N, Mt, y, PROBS, VARS, nshards=nshards, iterations=3, CG_max_iter=20, rho=0.5, seed=7,
+                              gam1=1e-8, gamw=2.0, true_signal=beta)
+        assert rel(x1_3, ref.x1[2]) < TIGHT and rel(x2_3, ref.x2[2]) < TIGHT and rel(r1_3, ref.r1[2]) < TIGHT
     # every rank saw the same scalars
     g = [[t["gamw"] for t in res[2].trace] for res in results]
     assert all(gg == g[0] for gg in g)
