@@ -18,7 +18,7 @@ EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
-    "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_dot", "gv_vec_dots",
+    "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
@@ -87,6 +87,7 @@ def load():
     L.gv_vec_fill.argtypes = [vp, vp, C.c_double]
     L.gv_vec_copy.argtypes = [vp, vp, vp]
     L.gv_vec_axpby.argtypes = [vp, vp, C.c_double, vp, C.c_double, vp]
+    L.gv_vec_mul.argtypes = [vp, vp, vp, vp]
     L.gv_vec_dot.argtypes = [vp, vp, vp, C.c_int, dp]
     L.gv_vec_dots.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, dp]
     L.gv_ax_dev.argtypes = [vp, vp, vp]

@@ -659,6 +659,12 @@ int gv_vec_axpby(gv_ctx* c, gv_vec* out, double a, const gv_vec* x, double b, co
     KCHK(c);
     return 0;
 }
+int gv_vec_mul(gv_ctx* c, gv_vec* out, const gv_vec* x, const gv_vec* y) {
+    NEED(c, out->space == x->space && y->space == x->space, "gv_vec_mul: space mismatch");
+    gvk::mul(c->stream, out->d, x->d, y->d, x->len);
+    KCHK(c);
+    return 0;
+}
 int gv_vec_dots(gv_ctx* c, int n, const gv_vec* const* x, const gv_vec* const* y, int sync, double* out) {
     NEED(c, n >= 1 && n <= 8, "gv_vec_dots: 1 <= n <= 8");
     const double *xs[8], *ys[8];

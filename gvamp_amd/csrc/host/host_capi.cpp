@@ -55,6 +55,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
     opt.set_probit_var(o->probit_var);
     opt.set_fuse_solves(o->fuse_solves);
+    if (o->freeze_index_file && o->freeze_index_file[0]) opt.set_freeze(o->freeze_index_file);
     if (o->C > 0 && o->covs) {
         opt.set_C((unsigned int)o->C);
         std::vector<std::vector<double>> z(N, std::vector<double>(o->C));

@@ -84,6 +84,7 @@ public:
     void set_use_XXT_denoiser(unsigned int v) { use_XXT_denoiser = v; }
     void set_fuse_solves(int v) { fuse_solves = v; }
     void set_C(unsigned int v) { C = v; }
+    void set_freeze(const std::string& file) { use_freeze = 1; freeze_index_file = file; }
 
 private:
     std::string bed_file = "", bed_file_test = "", estimate_file = "", freeze_index_file = "", cov_estimate_file = "",

@@ -42,6 +42,8 @@ void vamp::common_init(const Options& opt) {
     diagnostics = opt.get_diagnostics();
     store_iterates = opt.get_store_iterates();
     fuse_solves = opt.get_fuse_solves();
+    use_freeze = (int)opt.get_use_freeze();
+    freeze_index_file = opt.get_freeze_index_file();
     probit_var = opt.get_probit_var();
     nranks = gv_env_nranks();
     initialize_prior(this->probs, this->vars, N, Mt, rank);
@@ -65,7 +67,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, unfrozen, frozen, dvec})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -286,6 +288,19 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     const std::string pre = out_dir + out_name;
     std::vector<double> x1_hat_stored(M > 0 ? M : 0, 0.0);
     bool ran_any = false;
+    if (use_freeze == 1) {                                                  // vamp.cpp:205-209
+        std::vector<double> freeze_ind = read_vec_from_file(freeze_index_file, M, S);
+        freeze_ind.resize(M > 0 ? M : 0, 0.0);
+        std::vector<double> u(freeze_ind.size()), f(freeze_ind.size());
+        for (size_t i = 0; i < freeze_ind.size(); i++) {
+            u[i] = freeze_ind[i] == 0 ? 1.0 : 0.0;
+            f[i] = 1.0 - u[i];
+        }
+        for (gv_vec** v : {&unfrozen, &frozen, &dvec})
+            if (!*v) newM(v);
+        ck(gv_vec_upload(ctx, unfrozen, u.data()), "gv_vec_upload");
+        ck(gv_vec_upload(ctx, frozen, f.data()), "gv_vec_upload");
+    }
 
     double fused_alpha2 = 0;
     for (int it = 1; it <= max_iter; it++) {
@@ -306,12 +321,14 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         int it_revar = 1;
         for (; it_revar <= auto_var_max_iter; it_revar++) {               // vamp.cpp:289-338
             double sums[2];
+            gv_vec* dout = use_freeze == 1 ? dvec : nullptr;
             if (it == 1 && init_est == 1) {                               // :295-296: x1_hat = r1, g1d still evaluated
-                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), tM, nullptr, sums), "gv_denoise");
+                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), tM, dout, sums), "gv_denoise");
                 ck(gv_vec_copy(ctx, x1_hat, r1), "gv_vec_copy");
                 sums[1] = 0.0;
             } else
-                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, nullptr, sums), "gv_denoise");
+                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, dout, sums), "gv_denoise");
+            if (use_freeze == 1) ck(gv_vec_dot(ctx, dvec, unfrozen, 0, &sums[0]), "gv_vec_dot");   // :308: unfrozen markers only
             ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");     // :313 (+ the l2_norm2 of :326, same message)
             alpha1 = sums[0] / Mt;
             eta1 = gam1 / alpha1;
@@ -328,7 +345,13 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         if (verbose && rank == 0)
             std::cout << "A total of " << st.revar_rounds << " variance and prior tuning iterations were performed" << std::endl;
 
-        if (it > 1) {                                                     // damping (:348-414)
+        if (it > 1 && use_freeze == 1) {                                  // damping of the unfrozen markers only (:353)
+            ck(gv_vec_axpby(ctx, tM, rho, x1_hat, 1 - rho, x1_hat_prev), "gv_vec_axpby");
+            ck(gv_vec_mul(ctx, tM, tM, unfrozen), "gv_vec_mul");          // exact: the masks are 0 / 1
+            ck(gv_vec_mul(ctx, x1_hat, x1_hat, frozen), "gv_vec_mul");
+            ck(gv_vec_axpby(ctx, x1_hat, 1.0, x1_hat, 1.0, tM), "gv_vec_axpby");
+            alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
+        } else if (it > 1) {                                              // damping (:348-414)
             ck(gv_vec_axpby(ctx, x1_hat, rho, x1_hat, 1 - rho, x1_hat_prev), "gv_vec_axpby");
             alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
         }

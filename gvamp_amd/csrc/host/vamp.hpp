@@ -82,6 +82,10 @@ public:
                         gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);
     gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
     bool have_derived = false;
+    // --use-freeze 1 (vamp.cpp:205-209,:308,:353): markers whose g1d does not enter alpha1 and that are not damped
+    int use_freeze = 0;
+    std::string freeze_index_file;
+    gv_vec *unfrozen = nullptr, *frozen = nullptr, *dvec = nullptr;   // 0/1 masks and the g1d values (M-space)
     bool have_probe = false;          // draw_onsager_probe: bern_vec is resident for (seed + S) == probe_key
     long unsigned int probe_key = 0;
     void updatePrior(int verbose);                       // vamp.cpp:929-1072

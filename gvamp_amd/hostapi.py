@@ -23,7 +23,8 @@ class Opts(C.Structure):
                 ("probs", C.POINTER(C.c_double)), ("vars", C.POINTER(C.c_double)), ("out_prefix", C.c_char_p),
                 ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double), ("use_XXT_denoiser", C.c_int),
                 ("bin_class", C.c_int), ("probit_var", C.c_double), ("fuse_solves", C.c_int),
-                ("C", C.c_int), ("covs", C.POINTER(C.c_double)), ("cov_eff_out", C.POINTER(C.c_double))]
+                ("C", C.c_int), ("covs", C.POINTER(C.c_double)), ("cov_eff_out", C.POINTER(C.c_double)),
+                ("freeze_index_file", C.c_char_p)]
 
 
 class Iter(C.Structure):
@@ -70,7 +71,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
                   stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1, use_lmmse_damp=0, gam1=1e-8, gamw=2.0,
                   true_signal=None, out_prefix=None, verbose=0, diagnostics=0, alpha_scale=1.0, mask4=None,
                   nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0, fuse_solves=1,
-                  covs=None):
+                  covs=None, freeze_index_file=None):
     L = load()
     y = np.ascontiguousarray(y, dtype=np.float64)
     o = Opts()
@@ -89,6 +90,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     o.use_XXT_denoiser = use_XXT_denoiser
     o.bin_class, o.probit_var = int(model == "bin_class"), probit_var
     o.fuse_solves = fuse_solves
+    o.freeze_index_file = freeze_index_file.encode() if freeze_index_file else None
     cov_eff = None
     if covs is not None:
         cz = np.ascontiguousarray(covs, dtype=np.float64)

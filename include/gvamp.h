@@ -85,6 +85,8 @@ int gv_vec_fill(gv_ctx* ctx, gv_vec* v, double value);
 int gv_vec_copy(gv_ctx* ctx, gv_vec* dst, const gv_vec* src);
 /* out = a*x + b*y (y may be NULL when b == 0; out may alias x or y) */
 int gv_vec_axpby(gv_ctx* ctx, gv_vec* out, double a, const gv_vec* x, double b, const gv_vec* y);
+/* out = x .* y element-wise (out may alias x or y): the freeze mask of vamp.cpp:308,:353 applied on the device */
+int gv_vec_mul(gv_ctx* ctx, gv_vec* out, const gv_vec* x, const gv_vec* y);
 /* inner_prod (utilities.cpp:190-210): sync != 0 adds the cross-rank all-reduce of the scalar. */
 int gv_vec_dot(gv_ctx* ctx, const gv_vec* x, const gv_vec* y, int sync, double* out);
 /* several dots in one pass and ONE all-reduce: out[k] = <x[k], y[k]> */

@@ -31,6 +31,7 @@ typedef struct {                 /* the knobs vamp reads from Options (options.h
     int C;                        /* probit covariates (--C); 0 = none */
     const double* covs;           /* N x C row-major (the rows of --cov-file), or NULL */
     double* cov_eff_out;          /* C fitted covariate effects (vamp::get_cov_eff), or NULL */
+    const char* freeze_index_file; /* --use-freeze 1 --freeze-index-file <text file, one value per global marker>, or NULL */
 } gvh_opts;
 
 typedef struct {

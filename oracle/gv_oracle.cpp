@@ -1047,7 +1047,7 @@ static void store_bin(const std::string& path, const std::vector<double>& v, int
 }
 
 // vamp.cpp:149-183 (infere: vars *= N, model dispatch) + :190-803 (infere_linear; no restart, no
-// init_est, no freeze, no cross-val, reverse == 0).  Statement order follows the reference line by line.
+// init_est, optional freeze mask, no cross-val, reverse == 0).  Statement order follows the reference line by line.
 std::vector<double> Vamp::infere() {
     y = d->phen;
     for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;
@@ -1087,9 +1087,10 @@ std::vector<double> Vamp::infere() {
             std::vector<double> x1_hat_m_r1 = x1_hat;
             for (size_t i0 = 0; i0 < x1_hat_m_r1.size(); i0++) x1_hat_m_r1[i0] = x1_hat_m_r1[i0] - r1[i0];
             double sum_d = 0;
+            const bool use_freeze = !o.freeze_ind.empty();                 // :205-209 (--use-freeze 1)
             for (int i = 0; i < M; i++) {
                 x1_hat_d[i] = g1d(r1[i], gam1);
-                sum_d += x1_hat_d[i];
+                if (!use_freeze || (use_freeze && o.freeze_ind[i] == 0)) sum_d += x1_hat_d[i];   // :308
             }
             alpha1 = sum_d;
             if (comm) comm->allreduce_sum(&alpha1, 1);
@@ -1107,7 +1108,10 @@ std::vector<double> Vamp::infere() {
         tr.revar_rounds = std::max(it_revar - 1, 1);
 
         if (it > 1) {                                                   // :348-423
-            for (int i = 0; i < M; i++) x1_hat[i] = rho * x1_hat[i] + (1 - rho) * x1_hat_prev[i];
+            const bool use_freeze = !o.freeze_ind.empty();
+            for (int i = 0; i < M; i++)
+                if (!use_freeze || (use_freeze && o.freeze_ind[i] == 0))   // :353: frozen markers are not damped
+                    x1_hat[i] = rho * x1_hat[i] + (1 - rho) * x1_hat_prev[i];
             alpha1 = rho * alpha1 + (1 - rho) * alpha1_prev;
         }
         z1 = d->Ax(x1_hat.data());                                      // :429

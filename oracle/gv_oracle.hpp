@@ -117,6 +117,7 @@ struct VampOpts {
     std::vector<double> covs;             // N x C row-major: data::covs of read_covariates (data.cpp:286-331)
     std::vector<double> r1_init;          // restart (vamp.cpp:226-233): local shard of the r1 file, non-empty = restart
     std::vector<double> x_init;           // --init-est 1 (vamp.cpp:244-258): local shard of the estimate file
+    std::vector<double> freeze_ind;       // --use-freeze 1 (vamp.cpp:205-209,:308,:353): local shard, non-zero = frozen
 };
 
 struct IterTrace {

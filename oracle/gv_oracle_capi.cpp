@@ -87,6 +87,7 @@ struct gvo_params {
     double probit_var;
     int C;                      // covariates of the probit model (--C)
     const double* covs;         // N x C row-major, or NULL
+    const double* freeze_ind;   // Mt or NULL: --use-freeze 1 (vamp.cpp:205-209)
 };
 
 struct gvo_run {
@@ -292,6 +293,7 @@ static void run_shard(const gvo_params* p, const unsigned char* bed_full, const 
     if (p->x_init) o.x_init.assign(p->x_init + S, p->x_init + S + M);
     o.bin_class = p->bin_class;
     o.probit_var = p->probit_var;
+    if (p->freeze_ind) o.freeze_ind.assign(p->freeze_ind + S, p->freeze_ind + S + M);
     if (p->C > 0 && p->covs) {
         o.C = p->C;
         o.covs.assign(p->covs, p->covs + (size_t)p->N * p->C);

@@ -30,7 +30,8 @@ class Params(C.Structure):
                 ("phen_mode", C.c_int), ("is_na", C.POINTER(C.c_ubyte)),
                 ("cb", ALLREDUCE_CB), ("cb_user", C.c_void_p), ("use_XXT_denoiser", C.c_int),
                 ("r1_init", C.POINTER(C.c_double)), ("x_init", C.POINTER(C.c_double)),
-                ("bin_class", C.c_int), ("probit_var", C.c_double), ("C", C.c_int), ("covs", C.POINTER(C.c_double))]
+                ("bin_class", C.c_int), ("probit_var", C.c_double), ("C", C.c_int), ("covs", C.POINTER(C.c_double)),
+                ("freeze_ind", C.POINTER(C.c_double))]
 
 
 def build(force=False):
@@ -290,7 +291,7 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
            EM_max_iter=2, EM_err_thr=1e-2, stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1,
            use_lmmse_damp=0, gam1=1e-8, gamw=2.0, true_signal=None, out_prefix=None, verbose=0, nthreads=1,
            alpha_scale=1.0, is_na=None, allreduce=None, use_XXT_denoiser=0, r1_init=None, x_init=None,
-           model="linear", probit_var=1.0, covs=None):
+           model="linear", probit_var=1.0, covs=None, freeze_ind=None):
     """vamp::infere (linear) on `nshards` marker shards.  `allreduce(np_array)` is an in-place SUM callback
     used when shard_rank >= 0 (one shard per process, e.g. torch.distributed gloo)."""
     bed_full, y = _u8(bed_full), _f64(y)
@@ -319,6 +320,10 @@ def infere(bed_full, N, Mt, y, probs, vars_, *, nshards=1, shard_rank=-1, iterat
         cz = np.ascontiguousarray(covs, dtype=np.float64)
         keep.append(cz)
         p.C, p.covs = cz.shape[1], _dp(cz)
+    if freeze_ind is not None:
+        fz = _f64(freeze_ind)
+        keep.append(fz)
+        p.freeze_ind = _dp(fz)
     if r1_init is not None:
         ri = _f64(r1_init)
         keep.append(ri)
