@@ -42,6 +42,10 @@ void vamp::common_init(const Options& opt) {
     diagnostics = opt.get_diagnostics();
     store_iterates = opt.get_store_iterates();
     fuse_solves = opt.get_fuse_solves();
+    if (opt.get_redglob() != 0) {   // vamp.cpp:57,:594: CG on a sub-range of individuals (cross-validation variants)
+        std::cout << "FATAL: --red " << opt.get_redglob() << " (sub-range CG / cross-validation) is not built" << std::endl;
+        exit(EXIT_FAILURE);
+    }
     use_freeze = (int)opt.get_use_freeze();
     freeze_index_file = opt.get_freeze_index_file();
     probit_var = opt.get_probit_var();
