@@ -1,5 +1,6 @@
 // gv_capi.hip -- the C ABI of include/gvamp.h over the gfx950 kernels.  No CPU fallback anywhere: every
 // compute entry point launches HIP kernels on the context's stream or fails.
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -79,8 +80,31 @@ int ensure_work(gv_ctx* c) {
     return 0;
 }
 
-// read K scalars produced by a reduction launcher back to the host (one sync)
+// read K scalars produced by a reduction launcher back to the host.  Mailbox form (default): a one-block kernel writes
+// them into mapped coherent host memory and then a sequence number; the host spins on that number -- no copy engine,
+// no interrupt-driven stream synchronisation (measured: ~55 us of GPU idle per read-back with hipMemcpyAsync +
+// hipStreamSynchronize, a CG step has three).  When the flag arrives every earlier kernel of the stream has finished.
 int read_scalars(gv_ctx* c, int K, double* out) {
+    if (c->use_mbox && K <= RED_MAXK) {
+        unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->mbox + RED_MAXK);
+        unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
+        const unsigned long long seq = ++c->mbox_seq;
+        gvk::publish(c->stream, c->red_out, K, c->mbox_dev, flag_dev, seq);
+        KCHK(c);
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned long spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFF) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+                // the kernel before it may have faulted: let the runtime say so instead of spinning for ever
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                return fail(c, "read_scalars: the device never published the scalars");
+            }
+        }
+        memcpy(out, c->mbox, sizeof(double) * K);
+        return 0;
+    }
     HIPCHK(c, hipMemcpyAsync(c->host_pin, c->red_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(out, c->host_pin, sizeof(double) * K);
@@ -388,6 +412,22 @@ int gv_create(int device, gv_ctx** out) {
     if ((e = hipMalloc(&c->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->red_out, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc(&c->host_pin, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipHostMalloc", e);
+    // scalar mailbox (read_scalars); GV_MAILBOX=0 keeps the copy + synchronise read-back
+    const char* mb = getenv("GV_MAILBOX");
+    if (!(mb && atoi(mb) == 0)) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(double) * RED_MAXK + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            memset(hp, 0, sizeof(double) * RED_MAXK + 64);
+            c->mbox = static_cast<double*>(hp);
+            c->mbox_dev = static_cast<double*>(dp);
+            c->use_mbox = true;
+        } else {
+            (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
+        }
+    }
     *out = c;
     return 0;
 }
@@ -401,6 +441,7 @@ void gv_destroy(gv_ctx* c) {
     if (c->red_partial) (void)hipFree(c->red_partial);
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
+    if (c->mbox) (void)hipHostFree(c->mbox);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -49,6 +49,11 @@ struct gv_ctx {
     double* red_partial = nullptr; // RED_BLOCKS * RED_MAXK block partials
     double* red_out = nullptr;     // RED_MAXK device scalars
     double* host_pin = nullptr;    // pinned, RED_MAXK doubles
+    // scalar mailbox: mapped coherent host memory the device writes into (k_publish), RED_MAXK doubles + a sequence flag
+    double* mbox = nullptr;        // host address
+    double* mbox_dev = nullptr;    // the same memory as the device sees it
+    unsigned long long mbox_seq = 0;
+    bool use_mbox = false;
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
     gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
     gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
@@ -108,6 +113,7 @@ void scale_vec(hipStream_t s, double* v, int64_t n, double a);
 void atx_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p, const double* mave,
              const double* msig, double scale, double* out);
 void fill(hipStream_t s, double* v, int64_t n, double a);
+void publish(hipStream_t s, const double* src, int K, double* mailbox, unsigned long long* flag, unsigned long long seq);
 void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n);
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad);
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
