@@ -272,3 +272,18 @@ def test_kernel_families_agree_at_scale():
         assert rel(z1, z0) < 1e-12 and rel(w1, w0) < 1e-12
         lhs, rhs = float(z1 @ p), float(x @ w1)
         assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+
+
+def test_bandwidth_probes_report_plausible_rates():
+    """gv_read_bandwidth / gv_copy_bandwidth: context numbers for the roofline (bench.py), not pass/fail performance
+    gates -- only that they run on resident stripes and on a scratch buffer and return a rate in the HBM range."""
+    with capi.Shard(20000, 40000) as sh:                       # 200 MB of stripes
+        sh.set_layout(False, True)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(3, 5000)
+        r1 = sh.read_bandwidth(1 << 28, 3)
+        c1 = sh.copy_bandwidth(1 << 28, 3)
+    with capi.Shard(64, 8) as sh:                              # no stripes worth reading: scratch buffer
+        r2 = sh.read_bandwidth(1 << 28, 3)
+    for v in (r1, r2, c1):
+        assert 200.0 < v < 20000.0, v

@@ -237,3 +237,15 @@ def test_freeze_mask_vs_oracle(tmp_path, oracle):
             assert np.isclose(r.trace[it][f], ref.trace[it][f], rtol=1e-6), (it, f)
     assert rel(r.x_est, ref.x_est) < TIGHT
     assert rel(r_plain.x_est, ref.x_est) > 1e-3                  # the mask does change the run
+
+
+def test_unbuilt_variants_are_refused_loudly(tmp_path):
+    """--red 1 (CG on a sub-range of individuals, vamp.cpp:594) is not built: the driver says so instead of ignoring it."""
+    N, M = 400, 300
+    bedp = str(tmp_path / "t.bed")
+    synth.write_bed(bedp, synth.synth_bed(N, M, seed=2))
+    exe = os.path.join(ROOT, "gvamp_amd", "gvamp_sim")
+    r = subprocess.run([exe, "--bed-file", bedp, "--N", str(N), "--Mt", str(M), "--out-dir", str(tmp_path) + "/", "--out-name",
+                        "t", "--iterations", "1", "--probs", "0.9,0.1", "--vars", "0,0.01", "--CV", "10", "--h2", "0.5",
+                        "--model", "linear", "--red", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--red" in r.stdout and "not built" in r.stdout
