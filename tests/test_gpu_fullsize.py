@@ -95,3 +95,45 @@ def test_config2_vamp_run_properties():
     c = np.corrcoef(r1.x_est, beta)[0, 1]
     assert c > 0.5
     assert 1.5 < r1.trace[-1]["gamw"] < 2.6
+
+
+def test_ragged_multi_chunk_shard_with_na_phenotypes(oracle):
+    """N % 4 = 3, M not a multiple of anything (7 ingest chunks of 32 768 markers, the last one partial), 1 % NA phenotypes,
+    global marker offset S > 0: sampled columns against the oracle, the adjoint identity across the two stripe layouts,
+    zeros at NA / pad slots."""
+    N, M, S, Mt, seed = 100003, 200001, 12345, 400000, 77
+    rng = np.random.default_rng(9)
+    present = rng.random(N) >= 0.01
+    mb = (N + 3) // 4
+    m4 = np.zeros(mb, dtype=np.uint8)
+    idx = np.nonzero(present)[0]
+    np.bitwise_or.at(m4, idx >> 2, (1 << (idx & 3)).astype(np.uint8))
+    nonas = int(present.sum())
+    sample = np.array([0, 1, 63, 64, 32767, 32768, 65535, 65536, 131071, 196607, 196608, 199999, 200000])
+    mini = np.concatenate([synth.synth_bed(N, 1, seed=seed, miss_ppm=8000, S=S + int(j)) for j in sample])
+    o_mave, o_msig = oracle.marker_stats(mini, N, len(sample), mask4=m4, nonas=nonas)
+    with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+        sh.set_layout(False, True)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(seed, 8000)
+        sh.set_mask(m4, nonas)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        assert np.allclose(mave[sample], o_mave, rtol=1e-13, atol=1e-15)
+        assert np.allclose(msig[sample], o_msig, rtol=1e-10, atol=0)
+        p = np.zeros(4 * mb)
+        p[:N] = rng.standard_normal(N) * present
+        w = sh.ATx(p)
+        assert rel(w[sample], oracle.atx(mini, N, len(sample), o_mave, o_msig, p)) < 1e-10
+        xs = rng.standard_normal(len(sample))
+        x = np.zeros(M)
+        x[sample] = xs
+        z = sh.Ax(x)
+        oz = oracle.ax(mini, N, len(sample), o_mave, o_msig, xs, mask4=m4)
+        # the oracle scales by its own 1/sqrt(N); A depends on Mt only through nothing else
+        assert rel(z, oz) < 1e-10
+        assert np.all(z[N:] == 0) and np.all(z[:N][~present] == 0)
+        x1 = rng.standard_normal(M)
+        z1 = sh.Ax(x1)
+        lhs, rhs = float(z1 @ p), float(x1 @ w)
+        assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))

@@ -249,3 +249,25 @@ def test_unbuilt_variants_are_refused_loudly(tmp_path):
                         "t", "--iterations", "1", "--probs", "0.9,0.1", "--vars", "0,0.01", "--CV", "10", "--h2", "0.5",
                         "--model", "linear", "--red", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "--red" in r.stdout and "not built" in r.stdout
+
+
+@pytest.mark.parametrize("fuse", [1, 2])
+def test_long_run_stays_on_the_oracle(oracle, fuse):
+    """20 iterations (the tests above stop at 3-6): the product must not drift away from the oracle over a long run --
+    in particular the CG by-products of --fuse-solves 2, which replace explicit products by recurrences."""
+    N, M = 1500, 2500
+    bed = synth.synth_bed(N, M, seed=31)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        beta, y = hostapi.sim_phen(sh, 0.5, 120, 9)
+        kw = dict(iterations=20, CG_max_iter=40, rho=0.5, seed=9, gam1=1e-8, gamw=2.0, true_signal=beta, stop_criteria_thr=1e-12)
+        r = hostapi.infere_linear(sh, y, PROBS, VARS, fuse_solves=fuse, **kw)
+    ref = oracle.infere(bed, N, M, y, PROBS, VARS, **kw)
+    assert r.niter == ref.niter == 20
+    for it in range(r.niter):
+        t, o = r.trace[it], ref.trace[it]
+        assert (t["cg_iters"], t["onsager_iters"], t["L_after"]) == (o["cg_iters"], o["onsager_iters"], o["L_after"]), it
+        assert np.isclose(t["gamw"], o["gamw"], rtol=1e-6) and np.isclose(t["gam1_next"], o["gam1_next"], rtol=1e-6), it
+    worst = max(rel(r.x1[it], ref.x1[it]) for it in range(1, r.niter))
+    assert worst < TIGHT and rel(r.x_est, ref.x_est) < TIGHT
