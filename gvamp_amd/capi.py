@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -108,6 +108,8 @@ def load():
     L.gv_probit_denoise_cov.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, dp]
     L.gv_people_stats.argtypes = [vp, dp, dp, dp]
     L.gv_cg_solve_aat.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.POINTER(CgStats), dp]
+    L.gv_cg_solve_aat2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, C.POINTER(CgStats),
+                                   C.POINTER(CgStats), dp, dp, vp, vp]
     L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
     L.gv_pvals_loco.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp]
     L.gv_comm_unique_id.argtypes = [C.c_void_p]
@@ -366,6 +368,16 @@ class Shard:
         self._ck(self.L.gv_cg_solve_aat(self.h, v.h, mu_start.h if mu_start is not None else None, tau, gam2, max_iter,
                                         mu_out.h, C.byref(st), _dp(rr)))
         return st, rr[:st.n_relres].copy()
+
+    def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None):
+        """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes."""
+        sa, sb = CgStats(), CgStats()
+        ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
+        self._ck(self.L.gv_cg_solve_aat2(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
+                                         max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
+                                         aat_mu_a.h if aat_mu_a is not None else None,
+                                         ata_mu_b.h if ata_mu_b is not None else None))
+        return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def pvals_calc(self, z1, y, x1_hat, chrom=None):
         """data::pvals_calc (chrom None) / data::pvals_calc_LOCO on device handles; returns pvals[M]."""

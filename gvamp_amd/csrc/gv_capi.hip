@@ -1230,6 +1230,195 @@ done:
     return rc;
 }
 
+// ---- --use-XXT-denoiser 1: the N-space LMMSE solve and the M-space Onsager solve of one iteration on shared passes ------
+// System A (vamp::CG_solverAAT): Q_A u = tau A (A^T u) + gam2 u -- an ATx followed by an Ax.
+// System B (precondCG_solver, denoiser = 0, zero start): Q_B x = tau A^T (A x) + gam2 x -- an Ax followed by an ATx.
+// The two operators are made of the same two passes in opposite order, so run in step -- A half an application out of
+// phase with B -- every pass over the shard after the first carries one half-application of each (two-vector
+// kernels).  Per system the iterates, scalars, stopping rules and results are those of gv_cg_solve_aat / gv_cg_solve.
+// When A has finished its A^T mu_a (wanted for x2_hat = r2 + gamw A^T mu_a, denoiserXXT.cpp:47-49) is taken the same way.
+namespace {
+struct HalfOp {
+    bool pending = false;
+    int first = 0;          // kind of the first half: 0 = Ax, 1 = ATx
+    int stage = 0;          // 0: first half to do, 1: second half to do
+    bool one_half = false;  // only the first half is wanted (A^T mu_a)
+    const double* src = nullptr;
+    double* mid = nullptr;
+    double* dst = nullptr;
+    int kind() const { return stage == 0 ? first : 1 - first; }
+    const double* in() const { return stage == 0 ? src : mid; }
+    double* out() const { return (stage == 0 && !one_half) ? mid : dst; }
+};
+}  // namespace
+
+int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                     int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
+                     double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b) {
+    NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
+         "gv_cg_solve_aat2: system a lives in N-space");
+    NEED(c, v_b->space == GV_SPACE_M && mu_b->space == GV_SPACE_M && at_mu_a->space == GV_SPACE_M,
+         "gv_cg_solve_aat2: system b and A^T mu_a live in M-space");
+    NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && at_mu_a != mu_b && at_mu_a != v_b,
+         "gv_cg_solve_aat2: outputs must not alias inputs");
+    NEED(c, !aat_mu_a || (aat_mu_a->space == GV_SPACE_N && aat_mu_a != mu_a && aat_mu_a != v_a), "gv_cg_solve_aat2: aat_mu_a");
+    NEED(c, !ata_mu_b || (ata_mu_b->space == GV_SPACE_M && ata_mu_b != mu_b && ata_mu_b != v_b && ata_mu_b != at_mu_a),
+         "gv_cg_solve_aat2: ata_mu_b");
+    NEED(c, !(aat_mu_a || ata_mu_b) || tau != 0.0, "gv_cg_solve_aat2: the by-products need tau != 0");
+    NEED(c, c->mave_p, "gv_cg_solve_aat2: gv_people_stats must run first");
+    if (ensure_work(c)) return 1;
+    hipStream_t s = c->stream;
+    const int64_t n = c->npad, M = c->M;
+    const bool multi = is_multi(c);
+    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr, *MA = nullptr;
+    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) if (x) { (void)hipFree(x->d); delete x; } };
+    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
+        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
+    if (vec_new(c, GV_SPACE_M, &MA)) { cleanup(); return 1; }
+    double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_a->d;
+    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
+    int rc = 0;
+#define MIX_TRY(expr) do { if ((expr) != 0) { rc = 1; goto done; } } while (0)
+#define MIX_HIP(expr) do { if ((expr) != hipSuccess) { rc = fail(c, "%s failed", #expr); goto done; } } while (0)
+    // ---- system A state (denoiserXXT.cpp:52-130)
+    int a_iters = 0, a_conv = 0, a_nrel = 0, a_phase = 0;   // phase 0: waiting for Q mu0, 1: waiting for Q p, 2: A^T mu, 3: done
+    double a_rz = 0, a_vn2 = 0, a_rel = 0;
+    HalfOp ha, hb;
+    ha.first = 1;
+    hb.first = 0;
+    // ---- system B state: the M-space machinery of gv_cg_solve
+    CgSys sb;
+    const double diag_b = tau * (double)(c->N - 1) / (double)c->N + gam2;
+    {
+        sb.v = v_b->d; sb.mu0 = nullptr; sb.mu = mu_b->d;
+        sb.r = c->cg_r->d; sb.z = c->cg_z->d; sb.p = c->cg_p->d; sb.d = c->cg_d->d;
+        sb.denoiser = 0; sb.relres = relres_b;
+        sb.keep_resid = ata_mu_b != nullptr;
+        gvk::fill(s, sb.mu, M, 0.0);
+        MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+        MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
+        if (max_iter <= 0) sb.active = false;
+    }
+    {
+        auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
+            double sc[2];
+            gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);
+            if (read_scalars(c, 2, sc)) return 1;
+            a_rz = sc[0];
+            const double* vv[1] = {v_a->d};
+            gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
+            if (read_scalars(c, 1, &a_vn2)) return 1;
+            if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+            return 0;
+        };
+        auto a_post = [&](const double* src, double* dst) {   // request Q_A src -> dst
+            ha.pending = true; ha.stage = 0; ha.one_half = false; ha.src = src; ha.mid = MA->d; ha.dst = dst;
+        };
+        auto a_finish = [&]() {                                // the solve is over: A^T mu_a is the last request
+            a_phase = 2;
+            ha.pending = true; ha.stage = 0; ha.one_half = true; ha.src = mu; ha.mid = nullptr; ha.dst = at_mu_a->d;
+        };
+        gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
+        if (mu_start_a) {
+            MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            a_phase = 0;
+            a_post(mu, r);
+        } else {
+            gvk::fill(s, mu, n, 0.0);
+            MIX_HIP(hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            MIX_TRY(a_init_scalars());
+            a_phase = 1;
+            if (max_iter > 0) a_post(p, d); else a_finish();
+        }
+        auto b_post = [&]() {
+            hb.pending = sb.active;
+            hb.stage = 0; hb.one_half = false; hb.src = sb.req; hb.mid = c->w_n->d; hb.dst = sb.res;
+        };
+        b_post();
+
+        for (;;) {
+            HalfOp* todo[2];
+            int nt = 0;
+            if (ha.pending && hb.pending) {
+                if (ha.kind() == hb.kind()) { todo[nt++] = &ha; todo[nt++] = &hb; }
+                else todo[nt++] = &ha;             // out of phase: one single pass puts them in phase
+            } else if (ha.pending) todo[nt++] = &ha;
+            else if (hb.pending) todo[nt++] = &hb;
+            else break;
+            if (nt == 2) {
+                if (todo[0]->kind() == 0) MIX_TRY(ax2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
+                else MIX_TRY(atx2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
+            } else {
+                if (todo[0]->kind() == 0) MIX_TRY(ax_device(c, todo[0]->in(), todo[0]->out()));
+                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out()));
+            }
+            for (int k = 0; k < nt; k++) {
+                HalfOp* h = todo[k];
+                if (h->stage == 0 && !h->one_half) { h->stage = 1; continue; }     // second half still to come
+                h->pending = false;
+                if (h == &hb) {                                                    // Q_B req complete
+                    gvk::axpby(s, sb.res, tau, sb.res, gam2, sb.req, M);
+                    sb.wslot = c->w_n->d;
+                    CgSys* one[1] = {&sb};
+                    MIX_TRY(cg_consume_all(c, one, 1, gam2, diag_b, max_iter, multi));
+                    b_post();
+                    continue;
+                }
+                if (a_phase == 2) { a_phase = 3; continue; }                        // A^T mu_a done
+                gvk::axpby(s, ha.dst, tau, ha.dst, gam2, ha.src, n);                // Q_A src complete
+                if (a_phase == 0) {                                                // r = v - Q mu0 (:71-73)
+                    gvk::axpby(s, r, 1.0, v_a->d, -1.0, r, n);
+                    MIX_TRY(a_init_scalars());
+                    a_phase = 1;
+                    if (max_iter > 0) a_post(p, d); else a_finish();
+                    continue;
+                }
+                const int i = a_iters++;                                           // one CG step (:86-120)
+                const double* xs[1] = {d};
+                const double* ys[1] = {p};
+                gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
+                double dp, sc[2];
+                MIX_TRY(read_scalars(c, 1, &dp));
+                const double alpha = a_rz / dp;
+                gvk::axpby(s, mu, 1.0, mu, alpha, p, n);
+                gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);
+                MIX_TRY(read_scalars(c, 2, sc));
+                const double beta = sc[0] / a_rz;
+                a_rz = sc[0];
+                gvk::axpby(s, p, 1.0, z, beta, p, n);
+                a_rel = sqrt(sc[1] / a_vn2);
+                if (relres_a) relres_a[i] = a_rel;
+                a_nrel = i + 1;
+                if (a_rel < 1e-4) { a_conv = 1; a_finish(); }
+                else if (a_iters >= max_iter) a_finish();
+                else a_post(p, d);
+            }
+        }
+        if (aat_mu_a) {   // Q_A mu_a = v_a - r  =>  A A^T mu_a = (v_a - r - gam2 mu_a) / tau
+            gvk::axpby(s, aat_mu_a->d, 1.0 / tau, v_a->d, -1.0 / tau, r, n);
+            gvk::axpby(s, aat_mu_a->d, 1.0, aat_mu_a->d, -gam2 / tau, mu, n);
+        }
+        if (ata_mu_b) {
+            gvk::axpby(s, ata_mu_b->d, 1.0 / tau, sb.v, -1.0 / tau, sb.r, M);
+            gvk::axpby(s, ata_mu_b->d, 1.0, ata_mu_b->d, -gam2 / tau, sb.mu, M);
+        }
+        MIX_HIP(hipGetLastError());
+    }
+done:
+#undef MIX_TRY
+#undef MIX_HIP
+    if (st_a) {
+        st_a->iters = a_iters; st_a->converged = a_conv; st_a->rel_res = a_rel; st_a->onsager = 0; st_a->n_relres = a_nrel;
+        st_a->n_ax = (int)(c->cnt.n_ax - ax0);
+        st_a->n_atx = (int)(c->cnt.n_atx - atx0);
+    }
+    cg_fill_stats(sb, st_b);
+    if (st_b) { st_b->n_ax = (int)(c->cnt.n_ax - ax0); st_b->n_atx = (int)(c->cnt.n_atx - atx0); }
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    return rc;
+}
+
 // ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------
 // Student-t two-sided tail P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2): Lentz continued fraction of the incomplete beta
 // function (DLMF 8.17.22); the reference calls Boost's students_t (utilities.cpp:330-331).

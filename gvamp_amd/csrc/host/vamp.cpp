@@ -71,7 +71,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, unfrozen, frozen, dvec})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, unfrozen, frozen, dvec})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -361,7 +361,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         }
         // z1 = A x1_hat (:429).  --fuse-solves 2: it is only printed / stored, so it rides in a free slot of the CG passes
         // below and its outputs follow the solve.
-        const bool z1_rides = fuse_solves >= 2 && reverse == 0;
+        // --use-XXT-denoiser 1 with --fuse-solves >= 1: it shares the pass of A r2 (denoiserXXT.cpp:41) instead.
+        const bool z1_rides = (fuse_solves >= 2 && reverse == 0) || (fuse_solves >= 1 && reverse == 1);
         if (!z1_rides) ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");
 
         double t0 = now_s();
@@ -443,6 +444,41 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 cg(vM, warm, gamw, 1, x2_hat, &st.cg_iters);               // :593-596
             ck(gv_vec_copy(ctx, mu_CG_last, x2_hat), "gv_vec_copy");       // :1225-1226
             have_mu_CG_last = true;
+        } else if (fuse_solves) {
+            // lmmse_denoiserAAT (denoiserXXT.cpp:37-50) and g2d_onsager (:631) on shared passes (gv_cg_solve_aat2):
+            // (gamw A A^T + gam2 I) u = y - A r2 ; x2 = r2 + gamw A^T u ; alpha2 from (gamw A^T A + gam2 I) w = probe
+            if (!mu_CG_last_N) ck(gv_vec_alloc(ctx, GV_SPACE_N, &mu_CG_last_N), "gv_vec_alloc");
+            if (!ax2_der) ck(gv_vec_alloc(ctx, GV_SPACE_N, &ax2_der), "gv_vec_alloc");
+            ck(gv_ax2_dev(ctx, x1_hat, r2, z1, ax2_der), "gv_ax2_dev");   // z1 = A x1_hat (:429) and A r2, one pass
+            {
+                double tz = now_s();
+                z1_outputs_a();
+                t_io += now_s() - tz;
+                z1_outputs_b();
+            }
+            ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, ax2_der), "gv_vec_axpby");
+            draw_onsager_probe(dataset);
+            have_derived = fuse_solves >= 2;
+            if (have_derived) {
+                if (!aat_der) ck(gv_vec_alloc(ctx, GV_SPACE_N, &aat_der), "gv_vec_alloc");
+                if (!ata_der) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_der), "gv_vec_alloc");
+            }
+            gv_cg_stats sa, sb;
+            std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
+            ck(gv_cg_solve_aat2(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, tM,
+                                invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
+                                have_derived ? ata_der : nullptr), "gv_cg_solve_aat2");
+            st.cg_iters = sa.iters;
+            st.onsager_iters = sb.iters;
+            if (verbose && rank == 0) {
+                for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
+                for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
+            }
+            ck(gv_vec_copy(ctx, mu_CG_last_N, tN2), "gv_vec_copy");
+            ck(gv_vec_axpby(ctx, x2_hat, gamw, tM, 1.0, r2), "gv_vec_axpby");
+            fused_alpha2 = gam2 * dotM(bern_vec, invQ_bern_vec);
+            // A x2_hat = A r2 + gamw A A^T u, the latter from the residual of the N-space solve (no pass)
+            if (have_derived) ck(gv_vec_axpby(ctx, ax2_der, 1.0, ax2_der, gamw, aat_der), "gv_vec_axpby");
         } else {
             // lmmse_denoiserAAT (denoiserXXT.cpp:37-50): (gamw A A^T + gam2 I) u = y - A r2 ; x2 = r2 + gamw A^T u
             if (!mu_CG_last_N) ck(gv_vec_alloc(ctx, GV_SPACE_N, &mu_CG_last_N), "gv_vec_alloc");
@@ -463,7 +499,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         store_scaled(pre + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat, &x2_hist);
         t_io += now_s() - t0;
 
-        if (fuse_solves && reverse == 0) alpha2 = fused_alpha2;           // :631, solved together with x2_hat above
+        if (fuse_solves) alpha2 = fused_alpha2;                           // :631, solved together with x2_hat above
         else alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);
         st.alpha2 = alpha2;
         if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;

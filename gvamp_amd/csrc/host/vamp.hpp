@@ -80,6 +80,7 @@ public:
     // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2
     double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
                         gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);
+    gv_vec *aat_der = nullptr;        // --use-XXT-denoiser 1: A A^T u from the residual of the N-space solve
     gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
     bool have_derived = false;
     // --use-freeze 1 (vamp.cpp:205-209,:308,:353): markers whose g1d does not enter alpha1 and that are not damped

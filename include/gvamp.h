@@ -172,6 +172,17 @@ int gv_people_stats(gv_ctx* ctx, double* mave_people, double* msig_people, doubl
  * diagonal preconditioner, stopping at ||r||/||v|| < 1e-4.  mu_start may be NULL (zeros). */
 int gv_cg_solve_aat(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int max_iter,
                     gv_vec* mu_out, gv_cg_stats* stats, double* relres);
+/* The N-space solve above (system a: v_a, mu_start_a, N-space) and the Onsager probe solve of the same iteration (system
+ * b: gv_cg_solve with denoiser = 0 from a zero start, M-space; vamp.cpp:631 in the --use-XXT-denoiser branch) on shared
+ * passes: Q_a = tau A A^T + gam2 I is an ATx followed by an Ax, Q_b = tau A^T A + gam2 I an Ax followed by an ATx, so run
+ * half an application out of phase every pass over the shard (after the first) serves both through the two-vector kernels.
+ * Per solve the iterates, stopping rules and results are those of the stand-alone calls (bit-identical).
+ *   at_mu_a (M-space)           : A^T mu_a, the ATx of denoiserXXT.cpp:47-49 (x2_hat = r2 + gamw A^T mu_a), taken along too;
+ *   aat_mu_a (N-space, or NULL) : A A^T mu_a = (v_a - r_a - gam2 mu_a) / tau from the final residual of solve a;
+ *   ata_mu_b (M-space, or NULL) : A^T A mu_b likewise (gv_cg_extras) -- identities of the recurrences, equal to rounding. */
+int gv_cg_solve_aat2(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                     int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
+                     double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b);
 
 /* ---- association tests after the loop (vamp.cpp:761-776) ------------------------------------------------------
  * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,

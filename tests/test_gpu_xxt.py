@@ -33,8 +33,8 @@ def test_people_statistics_vs_oracle(oracle):
     assert np.all(g[0][:N][~present] == 0) and np.all(g[1][:N][~present] == 0)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_xxt_run_vs_oracle(oracle, mode):
+@pytest.mark.parametrize("mode,fuse", [(0, 1), (1, 0), (1, 1), (1, 2)])
+def test_xxt_run_vs_oracle(oracle, mode, fuse):
     N, M = 600, 2000
     bed = synth.synth_bed(N, M, seed=72, miss_ppm=5000)
     beta, y = oracle.sim_phen(bed, N, M, 0.5, 60, 3)
@@ -45,9 +45,57 @@ def test_xxt_run_vs_oracle(oracle, mode):
         sh.upload_bed(bed)
         sh.set_kernel_mode(mode)
         r = hostapi.infere_linear(sh, y, PROBS, VARS, iterations=3, CG_max_iter=40, rho=0.5, seed=3, true_signal=beta,
-                                  use_XXT_denoiser=1)
+                                  use_XXT_denoiser=1, fuse_solves=fuse)
     assert [t["cg_iters"] for t in r.trace] == [int(t["cg_iters"]) for t in ref.trace]
+    assert [t["onsager_iters"] for t in r.trace] == [int(t["onsager_iters"]) for t in ref.trace]
+    for a, b in zip(r.trace, ref.trace):
+        for f in ("alpha2", "gamw", "gam1_next"):
+            assert np.isclose(a[f], b[f], rtol=1e-6), f
     assert rel(r.x_est, ref.x_est) < 1e-7
     assert rel(r.x2[2], ref.x2[2]) < 1e-7
     # Woodbury: the N-space solve gives the M-space LMMSE estimate up to the two CG tolerances (1e-4 / 1e-5)
     assert rel(ref.x_est, std.x_est) < 5e-3
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_joint_nspace_and_onsager_solves_equal_the_separate_ones(warm):
+    """gv_cg_solve_aat2: the N-space solve and the M-space Onsager solve run half an application out of phase on shared
+    passes.  Bit-identical to gv_cg_solve_aat + gv_cg_solve + an ATx; about half the passes; by-products to rounding."""
+    N, M = 1200, 2600
+    rng = np.random.default_rng(6)
+    bed = synth.synth_bed(N, M, seed=73, miss_ppm=5000)
+    npad = 4 * ((N + 3) // 4)
+    v = np.zeros(npad)
+    v[:N] = rng.standard_normal(N)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    mu0 = np.zeros(npad)
+    mu0[:N] = 0.05 * rng.standard_normal(N)
+    tau, gam2 = 2.0, 0.8
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        sh.compute_people_statistics()              # on the raw rows (kernel mode 0) ...
+        sh.set_kernel_mode(1)                       # ... the solves on the MFMA kernels
+        sh.compute_markers_statistics()
+        dv, du = sh.vecN(v), sh.vecM(u)
+        dm0 = sh.vecN(mu0) if warm else None
+        a1, b1, a2, b2, at1, at2 = sh.vecN(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM()
+        aat, ata = sh.vecN(), sh.vecM()
+        sh.counters(reset=True)
+        sa, ra = sh.cg_solve_aat(dv, dm0, tau, gam2, 30, a1)
+        sb, rb = sh.cg_solve(du, None, tau, gam2, 0, 30, b1)
+        sh.atx_dev(a1, at1)
+        c1 = sh.counters(reset=True)
+        (s2a, r2a), (s2b, r2b) = sh.cg_solve_aat2(dv, dm0, du, tau, gam2, 30, a2, at2, b2, aat_mu_a=aat, ata_mu_b=ata)
+        c2 = sh.counters()
+        assert (s2a.iters, s2b.iters) == (sa.iters, sb.iters) and sa.iters > 1 and sb.iters > 1
+        assert np.array_equal(r2a, ra) and np.array_equal(r2b, rb)
+        assert np.array_equal(a2.download(), a1.download()) and np.array_equal(b2.download(), b1.download())
+        assert np.array_equal(at2.download(), at1.download())
+        assert c2["n_ax"] == c1["n_ax"] and c2["n_atx"] == c1["n_atx"]            # the same products ...
+        p1, p2 = c1["n_ax_pass"] + c1["n_atx_pass"], c2["n_ax_pass"] + c2["n_atx_pass"]
+        napp = max(2 * (sa.iters + (1 if warm else 0)) + 1, 2 * sb.iters) + 1
+        assert p2 <= napp and p2 < 0.7 * p1, (p1, p2)                              # ... in about half the passes
+        mu_a, mu_b = a2.download(), b2.download()
+        assert rel(aat.download(), sh.Ax(sh.ATx(mu_a))) < 1e-10
+        assert rel(ata.download(), sh.ATx(sh.Ax(mu_b))) < 1e-10
