@@ -99,3 +99,42 @@ def test_joint_nspace_and_onsager_solves_equal_the_separate_ones(warm):
         mu_a, mu_b = a2.download(), b2.download()
         assert rel(aat.download(), sh.Ax(sh.ATx(mu_a))) < 1e-10
         assert rel(ata.download(), sh.ATx(sh.Ax(mu_b))) < 1e-10
+
+
+@pytest.mark.parametrize("fuse", [0, 2])
+def test_xxt_sharded_run_vs_oracle(oracle, fuse):
+    """--use-XXT-denoiser 1 on two marker shards (in-process communicator): people statistics all-reduced over the
+    shards (data.cpp:604-606), N-space vectors replicated, M-space Onsager solve sharded."""
+    import threading
+    N, Mt, nshards = 500, 1800, 2
+    bed = synth.synth_bed(N, Mt, seed=74, miss_ppm=5000)
+    mb = (N + 3) // 4
+    beta, y = oracle.sim_phen(bed, N, Mt, 0.5, 50, 4)
+    kw = dict(iterations=3, CG_max_iter=40, rho=0.5, seed=4, use_XXT_denoiser=1)
+    ref = oracle.infere(bed, N, Mt, y, PROBS, VARS, nshards=nshards, true_signal=beta, **kw)
+    results, errors = [None] * nshards, []
+
+    def work(rank):
+        try:
+            size, modu = divmod(Mt, nshards)
+            M = size + 1 if rank < modu else size
+            S = sum(size + 1 if r < modu else size for r in range(rank))
+            with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+                sh.upload_bed(bed[S * mb:(S + M) * mb])
+                sh.set_kernel_mode(1)
+                sh.comm_init_local(4200 + fuse, nshards, rank)
+                results[rank] = hostapi.infere_linear(sh, y, PROBS, VARS, true_signal=beta[S:S + M], rank=rank,
+                                                      fuse_solves=fuse, **kw)
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nshards)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    x = np.concatenate([r.x_est for r in results])
+    assert rel(x, ref.x_est) < 1e-7
+    assert [t["cg_iters"] for t in results[0].trace] == [int(t["cg_iters"]) for t in ref.trace]
+    assert all([t["gamw"] for t in r.trace] == [t["gamw"] for t in results[0].trace] for r in results)
