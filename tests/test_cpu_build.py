@@ -91,3 +91,27 @@ def test_synth_bed_is_stable_and_plausible():
     c = codes[:, :403, 0] + 2 * codes[:, :403, 1]
     assert 0.001 < np.mean(c == 1) < 0.012                                   # missing ~0.5 %
     assert np.all(codes[:, 403:, :] == 0)                                    # pad bits
+
+
+def test_committed_bench_line_honours_the_contract():
+    """profiles/r1_bench_n1.json is the line `python bench.py` printed on an MI355X: every key the driver and the judge
+    read must be there, with consistent arithmetic (frac = achieved / peak, value = bytes / time)."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "genotype_matvec_GBps" and d["unit"] == "GB/s" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] >= r["alg_bytes_per_launch"]                       # HBM traffic cannot undercut the algorithm
+    step_bytes = 2 * r["alg_bytes_per_launch"]                               # one Ax + one ATx per step
+    assert abs(d["value"] - step_bytes / (d["ms_per_step"] * 1e-3) / 1e9) < 1.0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
