@@ -136,3 +136,46 @@ def test_vamp_run_with_by_products_equals_reference_sequence():
     for xa, xb in zip(r0.x1, r2.x1):
         assert rel(xb, xa) < 1e-9
     assert rel(r2.x_est, r0.x_est) < 1e-9
+
+
+@pytest.mark.parametrize("max_iter", [0, 1])
+def test_joint_solvers_with_no_or_one_step(max_iter):
+    """CG-max-iter 0 / 1: the joint solvers must stop where the separate ones stop (no step taken, or exactly one)."""
+    N, M = 900, 1300
+    rng = np.random.default_rng(8)
+    bed = synth.synth_bed(N, M, seed=12)
+    npad = 4 * ((N + 3) // 4)
+    v, xr = rng.standard_normal(M), rng.standard_normal(M)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    mu0 = 0.1 * rng.standard_normal(M)
+    vn = np.zeros(npad)
+    vn[:N] = rng.standard_normal(N)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        sh.compute_people_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        dv, du, dx, dm0, dvn = sh.vecM(v), sh.vecM(u), sh.vecM(xr), sh.vecM(mu0), sh.vecN(vn)
+        a1, b1, a2, b2 = sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
+        zr, za, wb = sh.vecN(), sh.vecN(), sh.vecM()
+        sa, _ = sh.cg_solve(dv, dm0, 2.0, 1.1, 1, max_iter, a1)
+        sb, _ = sh.cg_solve(du, None, 2.0, 1.1, 0, max_iter, b1)
+        (s2a, _), (s2b, _) = sh.cg_solve2x(dv, dm0, du, 2.0, 1.1, max_iter, a2, b2, ride_x=dx, ride_out=zr, a_mu_a=za,
+                                             ata_mu_b=wb)
+        assert (s2a.iters, s2b.iters) == (sa.iters, sb.iters) == (max_iter, max_iter)
+        assert np.array_equal(a2.download(), a1.download()) and np.array_equal(b2.download(), b1.download())
+        assert np.array_equal(zr.download(), sh.Ax(xr))
+        assert rel(za.download(), sh.Ax(a2.download())) < 1e-12
+        if max_iter:
+            assert rel(wb.download(), sh.ATx(sh.Ax(b2.download()))) < 1e-10
+        else:
+            assert np.all(wb.download() == 0) and np.all(b2.download() == 0)
+        # N-space / M-space pair
+        n1, n2, m1, m2, at1, at2 = sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
+        sna, _ = sh.cg_solve_aat(dvn, None, 2.0, 1.1, max_iter, n1)
+        sh.atx_dev(n1, at1)
+        (t2a, _), (t2b, _) = sh.cg_solve_aat2(dvn, None, du, 2.0, 1.1, max_iter, n2, at2, m2)
+        assert (t2a.iters, t2b.iters) == (sna.iters, sb.iters)
+        assert np.array_equal(n2.download(), n1.download()) and np.array_equal(at2.download(), at1.download())
+        assert np.array_equal(m2.download(), b1.download())
