@@ -243,6 +243,61 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
     return r;
 }
 
+// The K-split of each streaming kernel is picked by measurement among the cost model's three candidates: one warm-up and
+// two timed launches each, on the resident stripes, with throw-away vectors (no counters, no collectives).  Once per
+// shard, before its first matvec in kernel mode 1.
+int autotune_ks(gv_ctx* c) {
+    c->ks_tuned = true;
+    if ((c->ks_fixed_m && c->ks_fixed_n) || !c->have_stripes || c->M <= 0 || !c->have_stats) return 0;
+    gvm::Plan& pl = c->plan;
+    double *xm = nullptr, *wm = nullptr, *pn = nullptr, *zn = nullptr;
+    auto done = [&](int rc) {
+        for (double* q : {xm, wm, pn, zn}) if (q) (void)hipFree(q);
+        pl.ev0 = pl.ev1 = nullptr;
+        return rc;
+    };
+    if (hipMalloc(&xm, sizeof(double) * c->M) != hipSuccess || hipMalloc(&wm, sizeof(double) * c->M) != hipSuccess ||
+        hipMalloc(&pn, sizeof(double) * c->npad) != hipSuccess || hipMalloc(&zn, sizeof(double) * c->npad) != hipSuccess) {
+        (void)hipGetLastError();
+        return done(0);                      // no room for the scratch vectors: keep the model's pick
+    }
+    gvk::fill(c->stream, xm, c->M, 1.0);
+    gvk::fill(c->stream, pn, c->npad, 1.0);
+    pl.ev0 = pl.ev1 = nullptr;
+    auto time_one = [&](bool is_ax) -> double {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {   // rep 0 warms up
+            (void)hipEventRecord(c->ev0, c->stream);
+            if (is_ax) gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
+            else gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
+            (void)hipEventRecord(c->ev1, c->stream);
+            if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        return best;
+    };
+    for (int side = 0; side < 2; side++) {
+        const bool is_ax = side == 1;
+        if (is_ax ? c->ks_fixed_n : c->ks_fixed_m) continue;
+        const int* cand = is_ax ? c->ks_cand_n : c->ks_cand_m;
+        int& ks = is_ax ? pl.ks_n : pl.ks_m;
+        int best_ks = cand[0];
+        double best_t = -1;
+        for (int j = 0; j < 3; j++) {
+            if (j > 0 && (cand[j] == cand[0] || (j == 2 && cand[2] == cand[1]))) continue;
+            ks = cand[j];
+            const double t = time_one(is_ax);
+            if (t < 0) { ks = cand[0]; KCHK(c); return done(1); }
+            if (best_t < 0 || t < best_t * 0.995) { best_t = t; best_ks = cand[j]; }   // the model's order breaks near-ties
+        }
+        ks = best_ks;
+    }
+    KCHK(c);
+    return done(0);
+}
+
 // data::Ax on device pointers.  x: M doubles, out: npad doubles.
 int ax_device(gv_ctx* c, const double* x, double* out) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
@@ -250,6 +305,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
     const bool multi = is_multi(c);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+        if (!c->ks_tuned && autotune_ks(c)) return 1;
         Timer t(c, &c->cnt.ms_ax);
         gv_ctx::EvRec* er = ev_next(c, 0);
         c->plan.ev0 = er ? er->a : nullptr;
@@ -284,6 +340,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
 int atx_device(gv_ctx* c, const double* p, double* out) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
+    if (c->kernel_mode == 1 && c->M > 0 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "ATx: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
@@ -312,6 +369,7 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
         return ax_device(c, xb, outb);
     }
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
+    if (!c->ks_tuned && autotune_ks(c)) return 1;
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
     {
@@ -342,6 +400,7 @@ int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, dou
         return atx_device(c, pb, outb);
     }
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
+    if (!c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
     gv_ctx::EvRec* er = ev_next(c, 1);
     c->plan.ev0 = er ? er->a : nullptr;
@@ -483,29 +542,55 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     pl.M = M; pl.N = N;
     pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
     pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
-    // K-splits.  A launch is ceil(nrg / 4) * ks workgroups, each walking nkb / ks K-blocks.  Measured on MI355X (N=400k,
-    // sweeps with GV_KS_M / GV_KS_N): a workgroup should keep ~768 K-blocks (3 MiB of stripes per wave) to amortise its
-    // prologue, epilogue and partial sums, as long as the launch still has one full round (256 CUs x 3) of workgroups:
-    // Mt=1M -> ks 2 (ATx) / 5 (Ax), M=125k -> 2 / 1; more splits cost 1-4 %, fewer leave a tail.
-    auto pick_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks) {
+    // K-splits.  A launch is W = ceil(nrg / 4) * ks workgroups, each walking nkb / ks K-blocks; 768 are resident at a time
+    // (256 CUs x 3).  Sweeps on MI355X (GV_KS_M / GV_KS_N overrides; N = 50k ... 400k, M = 125k ... 1M) show 2-7 % between
+    // neighbouring splits, from three effects no closed form ranks reliably: a short last round of workgroups running at
+    // their own ceiling (a workgroup keeps 32 KiB in flight, ~450 of them saturate HBM), stragglers of the last round
+    // against an emptying chip, and per-workgroup prologue / epilogue / partial sums (~40 K-blocks' worth).  So a small
+    // cost model only SHORT-LISTS three candidates here
+    //   per = nkb/ks + 40 ;  W <= 768: T = per * max(W, 448) / 768 ;  W > 768: T = per * W / 768 + straggle * per
+    // and the pick among them is MEASURED once per shard on the resident data (autotune_ks, before the first matvec).
+    // Results do not depend on the split (exact integer accumulation), so tuning never changes a bit of output.
+    auto rank_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks, double straggle, int* out3) {
         const int64_t nq = (nrg + 3) / 4;
-        int64_t ks = (nkb + 384) / 768;
-        const int64_t fill = nq > 0 ? (768 + nq - 1) / nq : 1;      // splits needed for one round of workgroups ...
-        const int64_t fill_cap = nkb / 64 > 1 ? nkb / 64 : 1;       // ... but never below 64 K-blocks per workgroup
-        if (ks < (fill < fill_cap ? fill : fill_cap)) ks = fill < fill_cap ? fill : fill_cap;
-        if (ks < min_ks) ks = min_ks;
-        if (ks > 64) ks = 64;
-        if (ks > nkb) ks = nkb;
-        return (int)(ks < 1 ? 1 : ks);
+        out3[0] = out3[1] = out3[2] = (int)(min_ks > 1 ? min_ks : 1);
+        if (nq <= 0 || nkb <= 0) return;
+        int64_t hi = nkb / 32 > 1 ? nkb / 32 : 1;                  // never fewer than 32 K-blocks per workgroup
+        if (hi > 64) hi = 64;
+        if (min_ks > hi) hi = min_ks;
+        double cost[3] = {0, 0, 0};
+        int n = 0;
+        for (int64_t ks = min_ks > 1 ? min_ks : 1; ks <= hi && ks <= nkb; ks++) {
+            const double per = (double)nkb / (double)ks + 40.0;
+            const int64_t W = nq * ks;
+            const double t = W <= 768 ? per * (double)(W > 448 ? W : 448) / 768.0 : per * (double)W / 768.0 + straggle * per;
+            int pos = n < 3 ? n : 3;                                // insertion into the three cheapest
+            while (pos > 0 && t < cost[pos - 1]) pos--;
+            if (pos >= 3) continue;
+            for (int j = (n < 3 ? n : 2); j > pos; j--) { cost[j] = cost[j - 1]; out3[j] = out3[j - 1]; }
+            cost[pos] = t;
+            out3[pos] = (int)ks;
+            if (n < 3) n++;
+        }
+        for (int j = n; j < 3; j++) out3[j] = out3[n > 0 ? n - 1 : 0];
     };
-    pl.ks_m = pick_ks(pl.nrg_m, pl.nkb_m, 1);
-    pl.ks_n = pick_ks(pl.nrg_n, pl.nkb_n, (M * 512 + 2147483646LL) / 2147483647LL);
-    // tuning overrides (development): GV_KS_M / GV_KS_N = K-splits of the ATx / Ax kernels
-    if (const char* e = getenv("GV_KS_M")) { int v = atoi(e); if (v >= 1 && v <= pl.nkb_m) pl.ks_m = v; }
+    const int64_t min_ks_n = (M * 512 + 2147483646LL) / 2147483647LL;
+    rank_ks(pl.nrg_m, pl.nkb_m, 1, 0.4, c->ks_cand_m);
+    rank_ks(pl.nrg_n, pl.nkb_n, min_ks_n, 0.8, c->ks_cand_n);
+    pl.ks_m = c->ks_cand_m[0];
+    pl.ks_n = c->ks_cand_n[0];
+    c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
+    // overrides (development): GV_KS_M / GV_KS_N fix the K-splits of the ATx / Ax kernels, GV_AUTOTUNE=0 keeps the model's pick
+    if (const char* e = getenv("GV_KS_M")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= pl.nkb_m) { pl.ks_m = v; c->ks_fixed_m = true; }
+    }
     if (const char* e = getenv("GV_KS_N")) {
         int v = atoi(e);
-        if (v >= (M * 512 + 2147483646LL) / 2147483647LL && v >= 1 && v <= pl.nkb_n) pl.ks_n = v;
+        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n) { pl.ks_n = v; c->ks_fixed_n = true; }
     }
+    if (const char* e = getenv("GV_AUTOTUNE"))
+        if (atoi(e) == 0) c->ks_fixed_m = c->ks_fixed_n = true;
     return gv_set_mask(c, nullptr, N);
 }
 
@@ -531,7 +616,12 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
-        size_t pa = (size_t)pl.ks_m * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)pl.ks_n * 4 * pl.nrg_n * 64 * 8 * 4;
+        int km = pl.ks_m, kn = pl.ks_n;                     // room for every K-split candidate of autotune_ks
+        for (int j = 0; j < 3; j++) {
+            if (!c->ks_fixed_m && c->ks_cand_m[j] > km) km = c->ks_cand_m[j];
+            if (!c->ks_fixed_n && c->ks_cand_n[j] > kn) kn = c->ks_cand_n[j];
+        }
+        size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * 64 * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }

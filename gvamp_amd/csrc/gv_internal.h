@@ -41,6 +41,10 @@ struct gv_ctx {
     bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
     bool have_raw = false, have_stripes = false;
     gvm::Plan plan;
+    // K-split candidates of the cost model (best first) and whether the on-device pick among them has been made
+    int ks_cand_m[3] = {1, 1, 1}, ks_cand_n[3] = {1, 1, 1};
+    bool ks_fixed_m = false, ks_fixed_n = false;   // GV_KS_M / GV_KS_N given: nothing to pick
+    bool ks_tuned = false;
 
     // workspaces ---------------------------------------------------------------------------------
     double* t3 = nullptr;          // 3*M: per-marker Ax table {(2-mu)c, (1-mu)c, (0-mu)c}
