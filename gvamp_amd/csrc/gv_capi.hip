@@ -65,8 +65,17 @@ int vec_new(gv_ctx* c, int space, gv_vec** out) {
         delete v;
         return fail(c, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
+    c->live_vecs.insert(v);
     *out = v;
     return 0;
+}
+
+// every gv_vec of a context goes through vec_new / vec_del, so gv_destroy can release what a caller never freed
+void vec_del(gv_ctx* c, gv_vec* v) {
+    if (!v) return;
+    c->live_vecs.erase(v);
+    (void)hipFree(v->d);
+    delete v;
 }
 
 int ensure_work(gv_ctx* c) {
@@ -435,8 +444,7 @@ void free_dataset(gv_ctx* c) {
     for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p, &c->w_n2,
                       &c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
         if (*v) {
-            (void)hipFree((*v)->d);
-            delete *v;
+            vec_del(c, *v);
             *v = nullptr;
         }
     c->have_stats = false;
@@ -497,6 +505,7 @@ void gv_destroy(gv_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     free_dataset(c);
+    while (!c->live_vecs.empty()) vec_del(c, *c->live_vecs.begin());   // vectors the caller never gave back
     if (c->red_partial) (void)hipFree(c->red_partial);
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
@@ -759,8 +768,7 @@ int gv_vec_alloc(gv_ctx* c, int space, gv_vec** out) {
 void gv_vec_free(gv_ctx* c, gv_vec* v) {
     if (!v) return;
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(v->d);
-    delete v;
+    vec_del(c, v);
 }
 int64_t gv_vec_len(const gv_vec* v) { return v->len; }
 int gv_vec_upload(gv_ctx* c, gv_vec* v, const double* src) {
@@ -1251,7 +1259,7 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
     hipStream_t s = c->stream;
     const int64_t n = c->npad;
     gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG}) if (x) { (void)hipFree(x->d); delete x; } };
+    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG}) vec_del(c, x); };
     for (gv_vec** x : {&R, &Z, &P, &D, &DG})
         if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
     double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_out->d, *tmpM = c->cg_d->d;
@@ -1361,7 +1369,7 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
     const int64_t n = c->npad, M = c->M;
     const bool multi = is_multi(c);
     gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr, *MA = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) if (x) { (void)hipFree(x->d); delete x; } };
+    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) vec_del(c, x); };
     for (gv_vec** x : {&R, &Z, &P, &D, &DG})
         if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
     if (vec_new(c, GV_SPACE_M, &MA)) { cleanup(); return 1; }
@@ -1588,7 +1596,7 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
     std::vector<double> sums(4 * (M > 0 ? M : 1)), mave(M > 0 ? M : 1), msig(M > 0 ? M : 1), xh(M > 0 ? M : 1);
     std::vector<uint32_t> cnt(3 * (M > 0 ? M : 1));
     auto cleanup = [&]() {
-        for (gv_vec* v : {ymod, ych, sq, xch}) if (v) { (void)hipFree(v->d); delete v; }
+        for (gv_vec* v : {ymod, ych, sq, xch}) vec_del(c, v);
         if (sums_dev) (void)hipFree(sums_dev);
         if (chrom_dev) (void)hipFree(chrom_dev);
     };

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "gvamp.h"
@@ -62,6 +63,7 @@ struct gv_ctx {
     gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
     gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
     gv_vec *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_d = nullptr;  // CG work vectors
+    std::unordered_set<gv_vec*> live_vecs;   // every vector of this context (vec_new / vec_del): freed at gv_destroy
 
     // communicator ---------------------------------------------------------------------------------
     ncclComm_t comm = nullptr;
