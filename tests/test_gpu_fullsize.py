@@ -137,3 +137,23 @@ def test_ragged_multi_chunk_shard_with_na_phenotypes(oracle):
         z1 = sh.Ax(x1)
         lhs, rhs = float(z1 @ p), float(x1 @ w)
         assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+
+
+def test_kernel_families_agree_on_a_vamp_run_at_scale():
+    """A whole VAMP run (N=100k x M=200k, 5 GB shard) on the fp64 VALU family and on the i8 MFMA fixed-point family:
+    same CG / EM counts, estimates equal to the ~1e-9 that iteration 1's cancellation leaves."""
+    N, M = 100000, 200000
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(77, 5000)
+        sh.compute_markers_statistics()
+        beta, y = hostapi.sim_phen(sh, 0.5, 2000, 3)
+        kw = dict(iterations=3, CG_max_iter=50, rho=0.5, seed=3, true_signal=beta, history=False)
+        r0 = hostapi.infere_linear(sh, y, None, None, fuse_solves=0, **kw)           # kernel mode 0, reference sequence
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        r1 = hostapi.infere_linear(sh, y, None, None, fuse_solves=2, **kw)           # kernel mode 1, shared passes
+    assert r0.niter == r1.niter == 3
+    for a, b in zip(r0.trace, r1.trace):
+        assert (a["cg_iters"], a["onsager_iters"], a["L_after"]) == (b["cg_iters"], b["onsager_iters"], b["L_after"])
+        assert abs(a["gamw"] - b["gamw"]) < 1e-7 * abs(a["gamw"])
+    assert rel(r1.x_est, r0.x_est) < 1e-7
