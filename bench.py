@@ -123,6 +123,9 @@ def main():
     force_dist = os.environ.get("GVAMP_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the
     # N > 1 plumbing (rendezvous, id broadcast, RCCL communicator) on a single-GPU box under torchrun --nproc-per-node 1
     if world > 1 or force_dist:
+        # all ranks of this bench live on ONE node: keep RCCL's out-of-band bootstrap on the loopback interface unless the
+        # launcher says otherwise (the container's hostname / first NIC need not be reachable from inside it)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous + timing reductions only;
         # the data path's collectives are RCCL calls inside libgvamp (gv_comm_init below)
 
