@@ -1,6 +1,6 @@
 """Randomised differential test of the product (HIP, through the C ABI) against the CPU oracle on small random shapes.
 
-  python scripts/fuzz_parity.py [n_cases] [seed]
+  python scripts/fuzz_parity.py [n_cases] [seed] [sharded]
 
 Every case draws N, M, missing rate, NA-phenotype rate, shard offset, kernel family and a set of options, then checks the
 matvecs (1e-12) and a short VAMP run (1e-6, identical CG counts) against the oracle.  Development tool: the fixed cases
@@ -98,7 +98,66 @@ def one_case(rng, idx):
     return desc
 
 
+def sharded_case(rng, idx):
+    """Marker-sharded VAMP run on `nshards` contexts of this GPU (in-process communicator) against the oracle's sharded run."""
+    import threading
+    N = int(rng.choice([255, 600, 1003, 2000]))
+    Mt = int(rng.choice([257, 1000, 1501, 3000]))
+    nshards = int(rng.choice([2, 3, 5, 8]))
+    fuse = int(rng.integers(0, 3))
+    xxt = int(rng.random() < 0.3)
+    seed = int(rng.integers(1, 10**6))
+    desc = dict(case=idx, sharded=nshards, N=N, Mt=Mt, fuse=fuse, xxt=xxt, seed=seed)
+    bed = synth.synth_bed(N, Mt, seed=seed, miss_ppm=5000)
+    mb = (N + 3) // 4
+    beta, y = oracle.sim_phen(bed, N, Mt, 0.5, max(5, Mt // 30), seed % 89 + 1)
+    kw = dict(iterations=3, CG_max_iter=20, rho=0.5, seed=seed % 89 + 1)
+    if xxt:
+        kw["use_XXT_denoiser"] = 1
+    ref = oracle.infere(bed, N, Mt, y, [0.9, 0.1], [0, 0.02], nshards=nshards, true_signal=beta, **kw)
+    res, errs = [None] * nshards, []
+    group = 7000 + idx
+
+    def work(rank):
+        try:
+            size, modu = divmod(Mt, nshards)
+            M = size + 1 if rank < modu else size
+            S = sum(size + 1 if r < modu else size for r in range(rank))
+            with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+                sh.upload_bed(bed[S * mb:(S + M) * mb])
+                sh.set_kernel_mode(1)
+                sh.comm_init_local(group, nshards, rank)
+                res[rank] = hostapi.infere_linear(sh, y, [0.9, 0.1], [0, 0.02], true_signal=beta[S:S + M], rank=rank,
+                                                  fuse_solves=fuse, **kw)
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nshards)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs
+    x = np.concatenate([r.x_est for r in res])
+    assert [t["cg_iters"] for t in res[0].trace] == [int(t["cg_iters"]) for t in ref.trace], "cg counts"
+    assert rel(x, ref.x_est) < 1e-6, ("x_est", rel(x, ref.x_est))
+    return desc
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "sharded":
+        n, seed = int(sys.argv[1]), int(sys.argv[2])
+        rng = np.random.default_rng(seed)
+        bad = 0
+        for i in range(n):
+            try:
+                print("ok  ", sharded_case(rng, i), flush=True)
+            except Exception as e:   # noqa: BLE001
+                bad += 1
+                print("FAIL", i, repr(e), flush=True)
+                traceback.print_exc()
+        print("fuzz (sharded): %d cases, %d failures" % (n, bad))
+        sys.exit(1 if bad else 0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
