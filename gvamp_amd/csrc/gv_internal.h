@@ -59,6 +59,7 @@ struct gv_ctx {
     double* mbox_dev = nullptr;    // the same memory as the device sees it
     unsigned long long mbox_seq = 0;
     bool use_mbox = false;
+    void* xfer_pin = nullptr;      // 4 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
     gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
     gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
