@@ -157,3 +157,27 @@ def test_kernel_families_agree_on_a_vamp_run_at_scale():
         assert (a["cg_iters"], a["onsager_iters"], a["L_after"]) == (b["cg_iters"], b["onsager_iters"], b["L_after"])
         assert abs(a["gamw"] - b["gamw"]) < 1e-7 * abs(a["gamw"])
     assert rel(r1.x_est, r0.x_est) < 1e-7
+
+
+def test_config4_probit_run_properties():
+    """BASELINE config 4 (probit, N=100k x M=500k): reproducible, the same with and without shared passes / by-products to
+    rounding, and the estimate points along the simulated effects."""
+    N, M = 100000, 500000
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(False, True)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(515151, 5000)
+        sh.compute_markers_statistics()
+        beta, ylin = hostapi.sim_phen(sh, 0.5, 5000, 11)
+        y = (ylin > 0).astype(float)
+        kw = dict(iterations=4, CG_max_iter=50, rho=0.5, seed=11, gam1=1e-8, gamw=1.0, model="bin_class", history=False)
+        r2 = hostapi.infere_linear(sh, y, None, None, fuse_solves=2, **kw)
+        r2b = hostapi.infere_linear(sh, y, None, None, fuse_solves=2, **kw)
+        r0 = hostapi.infere_linear(sh, y, None, None, fuse_solves=0, **kw)
+    assert r2.niter == r0.niter == 4
+    assert np.array_equal(r2.x_est, r2b.x_est)
+    assert rel(r2.x_est, r0.x_est) < 1e-9
+    for a, b in zip(r2.trace, r0.trace):
+        assert (a["cg_iters"], a["onsager_iters"]) == (b["cg_iters"], b["onsager_iters"])
+        assert a["n_ax_pass"] + a["n_atx_pass"] < b["n_ax_pass"] + b["n_atx_pass"]
+    assert np.corrcoef(r2.x_est, beta)[0, 1] > 0.5
