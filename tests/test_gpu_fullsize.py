@@ -181,3 +181,24 @@ def test_config4_probit_run_properties():
         assert (a["cg_iters"], a["onsager_iters"]) == (b["cg_iters"], b["onsager_iters"])
         assert a["n_ax_pass"] + a["n_atx_pass"] < b["n_ax_pass"] + b["n_atx_pass"]
     assert np.corrcoef(r2.x_est, beta)[0, 1] > 0.5
+
+
+def test_config5_xxt_run_properties():
+    """BASELINE config 5 (--use-XXT-denoiser 1, N=50k; M=200k): the joint N-space / Onsager solver against the reference
+    sequence, and the Woodbury agreement with the M-space LMMSE path (two CG tolerances, 1e-4 / 1e-5)."""
+    N, M = 50000, 200000
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(616161, 5000)                     # raw rows + stripes: people statistics read the raw rows
+        sh.compute_markers_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        beta, y = hostapi.sim_phen(sh, 0.5, 2000, 13)
+        kw = dict(iterations=3, CG_max_iter=50, rho=0.5, seed=13, true_signal=beta, history=False)
+        x2 = hostapi.infere_linear(sh, y, None, None, use_XXT_denoiser=1, fuse_solves=2, **kw)
+        x0 = hostapi.infere_linear(sh, y, None, None, use_XXT_denoiser=1, fuse_solves=0, **kw)
+        std = hostapi.infere_linear(sh, y, None, None, fuse_solves=2, **kw)
+    assert rel(x2.x_est, x0.x_est) < 1e-9
+    for a, b in zip(x2.trace, x0.trace):
+        assert (a["cg_iters"], a["onsager_iters"]) == (b["cg_iters"], b["onsager_iters"])
+        assert a["n_ax_pass"] + a["n_atx_pass"] < 0.7 * (b["n_ax_pass"] + b["n_atx_pass"])
+    assert rel(x2.x_est, std.x_est) < 2e-2
