@@ -2,6 +2,7 @@
 #include "data.hpp"
 
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -180,7 +181,11 @@ void data::read_phen() {
 void data::read_genotype_data() {
     const size_t size_bytes = size_t(M) * mbytes;
     printf("INFO   : rank %d streams %zu bytes (%.3f GB) of raw data to the device.\n", rank, size_bytes, double(size_bytes) / 1.0E9);
+    const auto t0 = std::chrono::steady_clock::now();
     ck(ctx, gv_upload_bed_file(ctx, bedfp.c_str(), (int64_t)(3 + size_t(S) * mbytes)), "gv_upload_bed_file");
+    if (rank == 0)                                                                   // data.cpp:227-232
+        std::cout << "reading genotype data took "
+                  << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " seconds." << std::endl;
 }
 
 std::vector<int> data::read_chromosome_info(std::string bim_file) {
@@ -197,10 +202,15 @@ std::vector<int> data::read_chromosome_info(std::string bim_file) {
 }
 
 void data::compute_markers_statistics() {
+    const auto t0 = std::chrono::steady_clock::now();
     ck(ctx, gv_marker_stats(ctx, alpha_scale), "gv_marker_stats");
     mave.assign(M > 0 ? M : 1, 0.0);
     msig.assign(M > 0 ? M : 1, 0.0);
     ck(ctx, gv_get_marker_stats(ctx, mave.data(), msig.data()), "gv_get_marker_stats");
+    if (rank == 0 && !gv_host_quiet())                                                // data.cpp:543-545
+        std::cout << "rank = " << rank << ": statistics took "
+                  << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " seconds to run."
+                  << std::endl;
 }
 
 std::vector<double> data::Ax(double* __restrict__ phen) {

@@ -20,6 +20,7 @@ static int env_int(const char* k, int dflt) {
 }
 static bool g_quiet = false;
 void gv_host_set_quiet(bool quiet) { g_quiet = quiet; }
+bool gv_host_quiet() { return g_quiet; }
 int gv_env_rank() { return env_int("RANK", 0); }
 int gv_env_nranks() { return env_int("WORLD_SIZE", 1); }
 int gv_env_local_rank() { return env_int("LOCAL_RANK", gv_env_rank()); }

@@ -8,6 +8,7 @@
 int gv_env_rank();     // RANK (default 0)
 int gv_env_nranks();   // WORLD_SIZE (default 1)
 int gv_env_local_rank();
+bool gv_host_quiet();
 void gv_host_set_quiet(bool quiet);   // silence the informational prints of the helpers below (library use)
 
 // utilities.cpp:259-291 -- {M, S, Mm} of this rank

@@ -307,9 +307,17 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     }
 
     double fused_alpha2 = 0;
+    // the reference's named MPI_Wtime brackets (vamp.cpp:425-433,:515-530,:557,:617-637,:733-736), printed by rank 0 when
+    // verbose: the device is drained before each reading so that a phase is charged with its own kernels
+    auto tick = [&]() -> double {
+        if (!(verbose && rank == 0)) return 0.0;
+        ck(gv_synchronize(ctx), "gv_synchronize");
+        return now_s();
+    };
     for (int it = 1; it <= max_iter; it++) {
         const double t_start = now_s();
         double t_io = 0;
+        const double t_denoising = tick();
         gv_counters c0;
         gv_get_counters(ctx, &c0);
         vamp_iter_stats st;
@@ -363,7 +371,11 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         // below and its outputs follow the solve.
         // --use-XXT-denoiser 1 with --fuse-solves >= 1: it shares the pass of A r2 (denoiserXXT.cpp:41) instead.
         const bool z1_rides = (fuse_solves >= 2 && reverse == 0) || (fuse_solves >= 1 && reverse == 1);
-        if (!z1_rides) ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");
+        if (!z1_rides) {
+            const double tz1 = tick();
+            ck(gv_ax_dev(ctx, x1_hat, z1), "gv_ax_dev");
+            if (verbose && rank == 0) std::cout << "time needed to calculate z1 = " << tick() - tz1 << " seconds" << std::endl;
+        }
 
         double t0 = now_s();
         auto z1_outputs_a = [&]() {
@@ -421,8 +433,11 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         store_scaled(pre + "_r2_it_" + std::to_string(it) + ".bin", r2, nullptr);
         t_io += now_s() - t0;
 
+        if (verbose && rank == 0) std::cout << "denoising step took " << tick() - t_denoising << " seconds." << std::endl;
+
         // ---- LMMSE step (:547-620)
         if (verbose && rank == 0) std::cout << "______________________" << std::endl << "->LMMSE" << std::endl;
+        const double t_lmmse = tick(), t_cg = t_lmmse;
         if (reverse == 0) {
             if (!have_aty) {                                               // A^T y (:588) does not change: once
                 if (!aty) ck(gv_vec_alloc(ctx, GV_SPACE_M, &aty), "gv_vec_alloc");
@@ -499,8 +514,15 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         store_scaled(pre + "_it_" + std::to_string(it) + "_x2_hat.bin", x2_hat, &x2_hist);
         t_io += now_s() - t0;
 
+        if (verbose && rank == 0)
+            std::cout << (fuse_solves ? "CG + onsager (shared passes) took " : "CG took ") << tick() - t_cg << " seconds."
+                      << std::endl;
+        const double t_ons = tick();
         if (fuse_solves) alpha2 = fused_alpha2;                           // :631, solved together with x2_hat above
-        else alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);
+        else {
+            alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);
+            if (verbose && rank == 0) std::cout << "onsager took " << tick() - t_ons << " seconds." << std::endl;
+        }
         st.alpha2 = alpha2;
         if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
         if (it > 1 && diagnostics) {
@@ -528,6 +550,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         R2trains.push_back(st.R2_lmmse);
         st.gamw = gamw;
         if (verbose && rank == 0) std::cout << "R2 = " << st.R2_lmmse << std::endl << "gamw = " << gamw << std::endl;
+        if (verbose && rank == 0) std::cout << "lmmse step took " << tick() - t_lmmse << " seconds." << std::endl;
 
         st.L_after = (int)probs.size();
         gv_counters c1;
