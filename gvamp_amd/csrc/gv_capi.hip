@@ -378,7 +378,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 }
 
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
-int atx_device(gv_ctx* c, const double* p, double* out) {
+int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     if (c->kernel_mode == 1 && c->M > 0 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
@@ -387,13 +387,14 @@ int atx_device(gv_ctx* c, const double* p, double* out) {
         gv_ctx::EvRec* er = ev_next(c, 1);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out);
+        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2);
     } else {
         NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
         gv_ctx::EvRec* er = ev_next(c, 1);
         if (er) (void)hipEventRecord(er->a, c->stream);
         gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
         if (er) (void)hipEventRecord(er->b, c->stream);
+        if (addx) gvk::axpby(c->stream, out, tau, out, gam2, addx, c->M);
     }
     KCHK(c);
     t.stop();
@@ -434,10 +435,11 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     }
     return 0;
 }
-int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb) {
+int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
+                const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0) {
     if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
-        if (atx_device(c, pa, outa)) return 1;
-        return atx_device(c, pb, outb);
+        if (atx_device(c, pa, outa, addxa, tau, gam2)) return 1;
+        return atx_device(c, pb, outb, addxb, tau, gam2);
     }
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     if (!c->ks_tuned && autotune_ks(c)) return 1;
@@ -445,7 +447,8 @@ int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, dou
     gv_ctx::EvRec* er = ev_next(c, 1);
     c->plan.ev0 = er ? er->a : nullptr;
     c->plan.ev1 = er ? er->b : nullptr;
-    gvm::atx2(c->stream, c->plan, pa, pb, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, outa, outb);
+    gvm::atx2(c->stream, c->plan, pa, pb, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, outa, outb, addxa,
+              addxb, tau, gam2);
     KCHK(c);
     t.stop();
     c->cnt.n_atx += 2;
@@ -456,10 +459,7 @@ int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, dou
 int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out) {
     if (ensure_work(c)) return 1;
     if (ax_device(c, v, c->w_n->d)) return 1;
-    if (atx_device(c, c->w_n->d, out)) return 1;
-    gvk::axpby(c->stream, out, tau, out, gam2, v, c->M);   // res = tau * A^T A v + gam2 v  (vamp.cpp:1112-1115)
-    KCHK(c);
-    return 0;
+    return atx_device(c, c->w_n->d, out, v, tau, gam2);   // res = tau * A^T A v + gam2 v (vamp.cpp:1112-1115), in the ATx epilogue
 }
 
 void free_dataset(gv_ctx* c) {
@@ -469,6 +469,7 @@ void free_dataset(gv_ctx* c) {
     };
     F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial); F(c->counts);
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
+    F(c->plan.cv2); F(c->plan.ev2); F(c->plan.counters);
     F(c->plan.scal); F(c->plan.partial);
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
@@ -656,6 +657,10 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
+        HIPCHK(c, hipMalloc(&pl.cv2, sizeof(double) * (M > 0 ? M : 1)));
+        HIPCHK(c, hipMalloc(&pl.ev2, sizeof(double) * (M > 0 ? M : 1)));
+        HIPCHK(c, hipMalloc(&pl.counters, sizeof(unsigned int) * 4));
+        HIPCHK(c, hipMemsetAsync(pl.counters, 0, sizeof(unsigned int) * 4, c->stream));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
         int km = pl.ks_m, kn = pl.ks_n;                     // room for every K-split candidate of autotune_ks
         for (int j = 0; j < 3; j++) {
@@ -1052,11 +1057,7 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
     if (ensure_work(c)) return 1;
     if (!c->w_n2 && vec_new(c, GV_SPACE_N, &c->w_n2)) return 1;
     if (ax2_device(c, xa, xb, c->w_n->d, c->w_n2->d)) return 1;
-    if (atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb)) return 1;
-    gvk::axpby(c->stream, outa, tau, outa, gam2, xa, c->M);
-    gvk::axpby(c->stream, outb, tau, outb, gam2, xb, c->M);
-    KCHK(c);
-    return 0;
+    return atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb, xa, xb, tau, gam2);
 }
 
 // ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
@@ -1095,9 +1096,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             if (ride_x) {                                                 // Ax of the rider in the free slot
                 if (ensure_work(c)) return 1;
                 if (ax2_device(c, act[0]->req, ride_x, c->w_n->d, ride_out)) return 1;
-                if (atx_device(c, c->w_n->d, act[0]->res)) return 1;
-                gvk::axpby(c->stream, act[0]->res, tau, act[0]->res, gam2, act[0]->req, M);
-                KCHK(c);
+                if (atx_device(c, c->w_n->d, act[0]->res, act[0]->req, tau, gam2)) return 1;
                 ride_x = nullptr;
             } else if (lmmse_device(c, act[0]->req, tau, gam2, act[0]->res))
                 return 1;
@@ -1467,19 +1466,21 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
             } else if (ha.pending) todo[nt++] = &ha;
             else if (hb.pending) todo[nt++] = &hb;
             else break;
+            // system b's second half is the ATx of lmmse_mult: its tau * . + gam2 * req epilogue is fused as in gv_cg_solve
+            auto addx = [&](const HalfOp* h) -> const double* { return (h == &hb && h->stage == 1) ? sb.req : nullptr; };
             if (nt == 2) {
                 if (todo[0]->kind() == 0) MIX_TRY(ax2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
-                else MIX_TRY(atx2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
+                else MIX_TRY(atx2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out(), addx(todo[0]),
+                                         addx(todo[1]), tau, gam2));
             } else {
                 if (todo[0]->kind() == 0) MIX_TRY(ax_device(c, todo[0]->in(), todo[0]->out()));
-                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out()));
+                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out(), addx(todo[0]), tau, gam2));
             }
             for (int k = 0; k < nt; k++) {
                 HalfOp* h = todo[k];
                 if (h->stage == 0 && !h->one_half) { h->stage = 1; continue; }     // second half still to come
                 h->pending = false;
-                if (h == &hb) {                                                    // Q_B req complete
-                    gvk::axpby(s, sb.res, tau, sb.res, gam2, sb.req, M);
+                if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
                     sb.wslot = c->w_n->d;
                     CgSys* one[1] = {&sb};
                     MIX_TRY(cg_consume_all(c, one, 1, gam2, diag_b, max_iter, multi));

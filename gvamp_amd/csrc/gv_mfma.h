@@ -16,6 +16,9 @@ struct Plan {
     void* dig1 = nullptr;
     double* cv = nullptr;           // M doubles: c = msig * x
     double* ev = nullptr;           // M doubles: e = (mave - 3) * c
+    double* cv2 = nullptr;          // the same for the second vector of a two-vector Ax
+    double* ev2 = nullptr;
+    unsigned int* counters = nullptr;   // 2 ticket counters of the prep kernels (last block finalises), zero between launches
     double* scal = nullptr;         // 2 x 4 doubles: amax, sum, 2^(54-e), 2^(e-54) (second set: marker_sums2's p2)
     int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
     size_t partial_bytes = 0;
@@ -33,15 +36,18 @@ void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* ma
 void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
                   double* out4);
 // out[M] = data::ATx(p); p has npad entries (zero at NA / pad slots)
+// addx != NULL: out = tau * ATx(p) + gam2 * addx, the whole of vamp::lmmse_mult's epilogue (vamp.cpp:1112-1116)
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
-         double inv_sqrt_n, double* red_partial, double* out);
+         double inv_sqrt_n, double* red_partial, double* out, const double* addx = nullptr, double tau = 1.0,
+         double gam2 = 0.0);
 // out[npad] = mask * (A~ x) * post   (post = 1/sqrt(N), or 1 when a cross-rank all-reduce follows)
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
         int64_t npad, double post, double* red_partial, double* out);
 
 // two vectors per pass (the LMMSE and the Onsager CG of one VAMP iteration share the operator, vamp.cpp:593-596,:884)
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
-          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb);
+          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb,
+          const double* addxa = nullptr, const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb);
 

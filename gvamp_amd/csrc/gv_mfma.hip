@@ -149,56 +149,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// Ax operands: c = msig*x, e = (mave-3)*c  (out = sum r' c + sum miss e - K0, K0 = sum mave*c).
-// block partials: [0] = max(|c|,|e|), [1] = sum mave*c
-__global__ __launch_bounds__(256) void k_prep_ax(const double* __restrict__ x, const double* __restrict__ mave,
-                                                 const double* __restrict__ msig, int64_t M, double* __restrict__ cv,
-                                                 double* __restrict__ ev, double* __restrict__ partial) {
-    __shared__ double shm[4], shs[4];
-    double mx = 0.0, s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
-        double c = msig[i] * x[i], mu = mave[i];
-        double e = (mu - 3.0) * c;
-        cv[i] = c;
-        ev[i] = e;
-        mx = fmax(mx, fmax(fabs(c), fabs(e)));
-        s += mu * c;
-    }
-    mx = wave_max(mx);
-    s = wave_sum_d(s);
-    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
-        partial[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
-    }
-}
-// ATx operand p: block partials [0] = max|p|, [1] = sum p
-__global__ __launch_bounds__(256) void k_prep_atx(const double* __restrict__ p, int64_t n, double* __restrict__ partial) {
-    __shared__ double shm[4], shs[4];
-    double mx = 0.0, s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double v = p[i];
-        mx = fmax(mx, fabs(v));
-        s += v;
-    }
-    mx = wave_max(mx);
-    s = wave_sum_d(s);
-    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
-        partial[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
-    }
-}
 // scal[0] = amax, scal[1] = sum (ordered), scal[2] = 2^(54-e) (quantisation multiplier, 0 if amax is 0 / not finite),
-// scal[3] = 2^(e-54)
-__global__ __launch_bounds__(256) void k_prep_final(const double* __restrict__ partial, int nblocks, double* __restrict__ scal) {
-    __shared__ double shm[256], shs[256];
+// scal[3] = 2^(e-54).  Run by the LAST block of a prep launch to finish (ticket counter): the block partials are read
+// through the L2 (agent-scope atomic loads) and combined in a fixed order, so the scalars do not depend on which block
+// happens to be last.
+__device__ __forceinline__ double ld_l2(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ void prep_final(const double* partial, int nblocks, double* scal, double* shm, double* shs) {
     double mx = 0.0, s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) {
-        mx = fmax(mx, partial[2 * b]);
-        s += partial[2 * b + 1];
+        mx = fmax(mx, ld_l2(partial + 2 * b));
+        s += ld_l2(partial + 2 * b + 1);
     }
     shm[threadIdx.x] = mx;
     shs[threadIdx.x] = s;
@@ -224,14 +187,77 @@ __global__ __launch_bounds__(256) void k_prep_final(const double* __restrict__ p
         }
     }
 }
+// block partials written -> ticket; true in the block that took the last ticket (it also resets the counter)
+__device__ __forceinline__ bool last_block(double* partial_v, double mx, double s, unsigned int* counter, double* shm, double* shs) {
+    __shared__ bool is_last;
+    mx = wave_max(mx);
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial_v[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+        partial_v[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
+        __threadfence();
+        const unsigned int t = atomicAdd(counter, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) *counter = 0;
+    }
+    __syncthreads();
+    return is_last;
+}
+
+constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per vector
+
+// Ax operands: c = msig*x, e = (mave-3)*c  (out = sum r' c + sum miss e - K0, K0 = sum mave*c).  blockIdx.y = vector.
+// block partials: [0] = max(|c|,|e|), [1] = sum mave*c
+struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; };
+__global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
+                                                 int64_t M, double* __restrict__ partial, double* __restrict__ scal,
+                                                 unsigned int* __restrict__ counters) {
+    __shared__ double shm[256], shs[256];
+    const int v = blockIdx.y;
+    const double* __restrict__ x = a.x[v];
+    double* __restrict__ cv = a.cv[v];
+    double* __restrict__ ev = a.ev[v];
+    double mx = 0.0, s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        double c = msig[i] * x[i], mu = mave[i];
+        double e = (mu - 3.0) * c;
+        cv[i] = c;
+        ev[i] = e;
+        mx = fmax(mx, fmax(fabs(c), fabs(e)));
+        s += mu * c;
+    }
+    if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
+        prep_final(partial + v * PREP_STRIDE, gridDim.x, scal + 4 * v, shm, shs);
+}
+// ATx operand p: block partials [0] = max|p|, [1] = sum p.  blockIdx.y = vector.
+struct PrepAtx { const double* p[2]; };
+__global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* __restrict__ partial, double* __restrict__ scal,
+                                                  unsigned int* __restrict__ counters) {
+    __shared__ double shm[256], shs[256];
+    const int v = blockIdx.y;
+    const double* __restrict__ p = a.p[v];
+    double mx = 0.0, s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double val = p[i];
+        mx = fmax(mx, fabs(val));
+        s += val;
+    }
+    if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
+        prep_final(partial + v * PREP_STRIDE, gridDim.x, scal + 4 * v, shm, shs);
+}
 
 // fixed-point digits of v in MFMA B-operand order.  Thread = (kb, g, d, s): 4 entries k = 256kb+64g+16d+4t+s (t=0..3)
 // become byte t of one dword per digit c, stored at byte  ((kb*4 + d)*4 + g)*ncol*16 + (col0 + c)*16 + 4s.
 // Digit column 7 of each vector is zero.
 // ncol = 8 (ATx: 2 KiB per K-block) or 16 (Ax: [c | e], 4 KiB per K-block); col0 = first column of this vector.
-__global__ __launch_bounds__(256) void k_quant(const double* __restrict__ v, int64_t n, int64_t nkb,
-                                               const double* __restrict__ scal, uint32_t* __restrict__ out, int ncol,
-                                               int col0) {
+struct QuantArgs { const double* v[4]; const double* scal[4]; uint32_t* out[4]; int col0[4]; };
+__global__ __launch_bounds__(256) void k_quant(QuantArgs a, int64_t n, int64_t nkb, int ncol) {
+    const double* __restrict__ v = a.v[blockIdx.y];
+    const double* __restrict__ scal = a.scal[blockIdx.y];
+    uint32_t* __restrict__ out = a.out[blockIdx.y];
+    const int col0 = a.col0[blockIdx.y];
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nkb * 64) return;
     const int s = tid & 3, d = (tid >> 2) & 3, g = (tid >> 4) & 3;
@@ -483,11 +509,15 @@ __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, 
 
 // data::ATx epilogue (data.cpp:779, :825-832): out[m] = msig (sum a p - mave sum b p) / sqrt(N),
 // sum a p = (X - 3Y) scale, sum b p = P - Y scale.
+struct FinAtx { double* out[2]; const double* addx[2]; };   // addx != NULL: out = tau * ATx + gam2 * addx (lmmse_mult, vamp.cpp:1112-1116)
 __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
-                                                 const double* __restrict__ scal, const double* __restrict__ mave,
-                                                 const double* __restrict__ msig, double inv_sqrt_n,
-                                                 double* __restrict__ out, int ppk, int p0) {
-    // ppk = planes per K-split in `partial` (2, or 4 for the two-vector kernels), p0 = first plane of this vector
+                                                 const double* __restrict__ scal_base, const double* __restrict__ mave,
+                                                 const double* __restrict__ msig, double inv_sqrt_n, FinAtx a, double tau,
+                                                 double gam2, int ppk) {
+    // ppk = planes per K-split in `partial` (2, or 4 for the two-vector kernels); vector v = blockIdx.y owns planes 2v, 2v+1
+    const int v = blockIdx.y, p0 = 2 * v;
+    const double* __restrict__ scal = scal_base + 4 * v;
+    double* __restrict__ out = a.out[v];
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -504,14 +534,18 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     const double scale = scal[3], P = scal[1];
     const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
     const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
-    out[m] = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
+    const double r = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
+    out[m] = a.addx[v] ? tau * r + gam2 * a.addx[v][m] : r;
 }
 
 // data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
+struct FinAx { double* out[2]; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
-                                                int64_t npad, const double* __restrict__ scal,
-                                                const uint32_t* __restrict__ mask2, double post,
-                                                double* __restrict__ out, int ppk, int p0) {
+                                                int64_t npad, const double* __restrict__ scal_base,
+                                                const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk) {
+    const int v = blockIdx.y, p0 = 2 * v;       // vector v owns planes 2v (r'.c) and 2v+1 (miss.e)
+    const double* __restrict__ scal = scal_base + 4 * v;
+    double* __restrict__ out = a.out[v];
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= npad) return;
     const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
@@ -574,49 +608,41 @@ static int prep_blocks(int64_t n) {
     return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
 }
 
+// vector preparation of one (nv = 1) or two (nv = 2) N-vectors: scal[4v..] and the digit columns 8v.. of dig0
+static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, double* red_partial) {
+    const int nv = pb ? 2 : 1, nb = prep_blocks(npad);
+    PrepAtx pa_{{pa, pb}};
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb, nv), dim3(256), 0, s, pa_, npad, red_partial, pl.scal, pl.counters);
+    QuantArgs q{};
+    q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
+    q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), nv), dim3(256), 0, s, q, npad, pl.nkb_m, nv == 2 ? 16 : 8);
+}
+
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
-         double inv_sqrt_n, double* red_partial, double* out) {
-    int nb = prep_blocks(npad);
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p, npad, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p, npad, pl.nkb_m, pl.scal,
-                       (uint32_t*)pl.dig0, 8, 0);
+         double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2) {
+    prep_quant_atx(s, pl, p, nullptr, npad, red_partial);
     launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
-    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, out, 2, 0);
+    FinAtx f{{out, nullptr}, {addx, nullptr}};
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2);
 }
 
 // data::ATx of TWO N-vectors in one pass over stripes_m
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
-          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb) {
-    int nb = prep_blocks(npad);
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, pa, npad, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, pb, npad, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal + 4);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, pa, npad, pl.nkb_m, pl.scal,
-                       (uint32_t*)pl.dig0, 16, 0);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, pb, npad, pl.nkb_m, pl.scal + 4,
-                       (uint32_t*)pl.dig0, 16, 8);
+          const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb, const double* addxa,
+          const double* addxb, double tau, double gam2) {
+    prep_quant_atx(s, pl, pa, pb, npad, red_partial);
     launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
-    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, outa, 4, 0);
-    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal + 4, mave, msig, inv_sqrt_n, outb, 4, 2);
+    FinAtx f{{outa, outb}, {addxa, addxb}};
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 2), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4);
 }
 
 // one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
 void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
                   double* out4) {
-    int nb = prep_blocks(npad);
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p1, npad, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb), dim3(256), 0, s, p2, npad, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal + 4);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p1, npad, pl.nkb_m, pl.scal,
-                       (uint32_t*)pl.dig0, 16, 0);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256)), dim3(256), 0, s, p2, npad, pl.nkb_m, pl.scal + 4,
-                       (uint32_t*)pl.dig0, 16, 8);
+    prep_quant_atx(s, pl, p1, p2, npad, red_partial);
     {
         gvm::Plan q = pl;      // no roofline events around the p-value pass
         q.ev0 = q.ev1 = nullptr;
@@ -628,36 +654,35 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
 
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
         int64_t npad, double post, double* red_partial, double* out) {
-    int nb = prep_blocks(pl.M);
-    hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, x, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
-    hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, pl.scal);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, pl.scal,
-                       (uint32_t*)pl.dig0, 16, 0);
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256)), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, pl.scal,
-                       (uint32_t*)pl.dig0, 16, 8);
+    const int nb = prep_blocks(pl.M);
+    PrepAx pa{{x, nullptr}, {pl.cv, nullptr}, {pl.ev, nullptr}};
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 1), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
+    QuantArgs q{};   // dig0 = [c | e]
+    q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
+    q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
     launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, out, 2, 0);
+    FinAx f{{out, nullptr}};
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, f, 2);
 }
 
-// data::Ax of TWO M-vectors in one pass over stripes_n (dig0 / dig1 hold [c|e] of vector a / b)
+// data::Ax of TWO M-vectors in one pass over stripes_n: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb) {
-    int nb = prep_blocks(pl.M);
-    const int qb = nblk(pl.nkb_n * 64, 256);
-    for (int v = 0; v < 2; v++) {   // cv / ev are reused: vector b is prepared after vector a's digits are written
-        double* sc = pl.scal + 4 * v;
-        hipLaunchKernelGGL(k_prep_ax, dim3(nb), dim3(256), 0, s, v ? xb : xa, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
-        hipLaunchKernelGGL(k_prep_final, dim3(1), dim3(256), 0, s, red_partial, nb, sc);
-        // dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
-        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.cv, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig0, 16, 8 * v);
-        hipLaunchKernelGGL(k_quant, dim3(qb), dim3(256), 0, s, pl.ev, pl.M, pl.nkb_n, sc, (uint32_t*)pl.dig1, 16, 8 * v);
-    }
+    const int nb = prep_blocks(pl.M);
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}};
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 2), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
+    QuantArgs q{};
+    q.v[0] = pl.cv;  q.scal[0] = pl.scal;     q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
+    q.v[1] = pl.ev;  q.scal[1] = pl.scal;     q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;
+    q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
+    q.v[3] = pl.ev2; q.scal[3] = pl.scal + 4; q.out[3] = (uint32_t*)pl.dig1; q.col0[3] = 8;
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
     launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n);
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, outa, 4, 0);
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal + 4, mask2, post, outb, 4, 2);
+    FinAx f{{outa, outb}};
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 2), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, f, 4);
 }
 
 }  // namespace gvm

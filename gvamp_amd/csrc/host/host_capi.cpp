@@ -16,6 +16,7 @@ extern "C" {
 // noise streams; data::Ax carries the cross-rank all-reduce when a communicator is attached.
 int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, int CV, unsigned long seed,
                  double* beta_out, double* y_out) {
+    gv_host_set_quiet(true);   // library use: nothing on stdout (bench.py prints exactly one JSON line)
     std::vector<double> vars_true{0, h2 / CV};
     std::vector<double> probs_true{1 - (double)CV / Mt, (double)CV / Mt};
     const double gamw = 1 / (1 - h2);

@@ -271,3 +271,19 @@ def test_long_run_stays_on_the_oracle(oracle, fuse):
         assert np.isclose(t["gamw"], o["gamw"], rtol=1e-6) and np.isclose(t["gam1_next"], o["gam1_next"], rtol=1e-6), it
     worst = max(rel(r.x1[it], ref.x1[it]) for it in range(1, r.niter))
     assert worst < TIGHT and rel(r.x_est, ref.x_est) < TIGHT
+
+
+def test_bench_prints_exactly_one_json_line():
+    """The driver parses bench.py's stdout: one line, JSON, with the contract's keys -- at a tiny size, CPU baseline included."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--N", "20000", "--Mt", "60000", "--steps", "2", "--warmup", "1",
+                        "--vamp-iterations", "2", "--cpu-markers", "500"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "vamp"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["n_gpus"] == 1 and d["roofline"]["traffic"] is None     # no PMC profile for this size
