@@ -74,13 +74,29 @@ int vec_new(gv_ctx* c, int space, gv_vec** out) {
 void vec_del(gv_ctx* c, gv_vec* v) {
     if (!v) return;
     c->live_vecs.erase(v);
-    (void)hipFree(v->d);
+    if (v->owns) (void)hipFree(v->d);
     delete v;
 }
 
+// w_n and w_n2 (the N-space results of a two-vector Ax) share one allocation, w_n2 right behind w_n, so that a sharded
+// job all-reduces both in ONE call (ax2_device)
+int ensure_w2(gv_ctx* c) {
+    if (c->w_n2) return 0;
+    gv_vec* v = new gv_vec();
+    *v = *c->w_n;
+    v->d = c->w_n->d + c->npad;
+    v->owns = false;
+    c->live_vecs.insert(v);
+    c->w_n2 = v;
+    return 0;
+}
 int ensure_work(gv_ctx* c) {
     if (!c->w_n) {
         if (vec_new(c, GV_SPACE_N, &c->w_n)) return 1;
+        (void)hipFree(c->w_n->d);                              // twice the room: w_n2 lives in the second half
+        c->w_n->d = nullptr;
+        HIPCHK(c, hipMalloc(&c->w_n->d, sizeof(double) * 2 * c->npad));
+        HIPCHK(c, hipMemsetAsync(c->w_n->d, 0, sizeof(double) * 2 * c->npad, c->stream));
         if (vec_new(c, GV_SPACE_M, &c->cg_r)) return 1;
         if (vec_new(c, GV_SPACE_M, &c->cg_z)) return 1;
         if (vec_new(c, GV_SPACE_M, &c->cg_p)) return 1;
@@ -426,10 +442,15 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     c->cnt.n_ax_pass += 1;
     if (multi) {
         Timer t(c, &c->cnt.ms_allreduce);
-        if (comm_allreduce(c, outa, c->npad)) return 1;
-        if (comm_allreduce(c, outb, c->npad)) return 1;
-        gvk::scale_vec(c->stream, outa, c->npad, scale);
-        gvk::scale_vec(c->stream, outb, c->npad, scale);
+        if (c->w_n && c->w_n2 && outa == c->w_n->d && outb == c->w_n2->d) {   // w_n | w_n2 (one allocation): one message, one scaling pass
+            if (comm_allreduce(c, outa, 2 * c->npad)) return 1;
+            gvk::scale_vec(c->stream, outa, 2 * c->npad, scale);
+        } else {
+            if (comm_allreduce(c, outa, c->npad)) return 1;
+            if (comm_allreduce(c, outb, c->npad)) return 1;
+            gvk::scale_vec(c->stream, outa, c->npad, scale);
+            gvk::scale_vec(c->stream, outb, c->npad, scale);
+        }
         KCHK(c);
         t.stop();
     }
@@ -1055,7 +1076,7 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
 static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double tau, double gam2, double* outa,
                          double* outb) {
     if (ensure_work(c)) return 1;
-    if (!c->w_n2 && vec_new(c, GV_SPACE_N, &c->w_n2)) return 1;
+    if (ensure_w2(c)) return 1;
     if (ax2_device(c, xa, xb, c->w_n->d, c->w_n2->d)) return 1;
     return atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb, xa, xb, tau, gam2);
 }
@@ -1154,7 +1175,7 @@ int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
          "gv_cg_solve2x: ata_mu_b is M-space and must not alias v_b / mu_b");
     NEED(c, !ex->ata_mu_b || tau != 0.0, "gv_cg_solve2x: ata_mu_b needs tau != 0");
     if (ensure_work(c)) return 1;
-    if (!c->w_n2 && vec_new(c, GV_SPACE_N, &c->w_n2)) return 1;
+    if (ensure_w2(c)) return 1;
     for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
         if (!*w && vec_new(c, GV_SPACE_M, w)) return 1;
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;

@@ -18,6 +18,7 @@ struct gv_vec {
     int64_t len;    // logical length (M or 4*mbytes)
     int64_t cap;    // allocated doubles (M or npad); the tail beyond len is kept at 0
     double* d;
+    bool owns = true;   // false: d points into another vector's allocation (w_n2 behind w_n)
 };
 
 struct gv_ctx {
