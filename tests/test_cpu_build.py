@@ -115,3 +115,22 @@ def test_committed_bench_line_honours_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_run_sharded_launcher_sets_the_rank_environment(tmp_path):
+    """scripts/run_sharded.py: one process per shard with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a private rendezvous
+    path; the exit code of a failing rank is propagated."""
+    import subprocess
+    import sys
+    launcher = os.path.join(ROOT, "scripts", "run_sharded.py")
+    probe = ("import os,sys; open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write("
+             "' '.join(os.environ[k] for k in ('RANK','LOCAL_RANK','WORLD_SIZE','MASTER_ADDR','MASTER_PORT','GVAMP_RENDEZVOUS')))")
+    r = subprocess.run([sys.executable, launcher, "-n", "3", "--master-port", "29700", "--", sys.executable, "-c", probe, str(tmp_path)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    seen = sorted(open(tmp_path / ("r%d" % i)).read().split() for i in range(3))
+    assert [s[0] for s in seen] == ["0", "1", "2"] and all(s[1] == s[0] and s[2] == "3" and s[3] == "127.0.0.1" and s[4] == "29700" for s in seen)
+    assert len({s[5] for s in seen}) == 1
+    bad = subprocess.run([sys.executable, launcher, "-n", "2", "--", sys.executable, "-c",
+                          "import os,sys,time; sys.exit(7) if os.environ['RANK']=='1' else time.sleep(30)"], timeout=60)
+    assert bad.returncode == 7
