@@ -11,6 +11,8 @@
 #include <iostream>
 #include <limits>
 #include <sstream>
+#include <sys/stat.h>
+#include <ctime>
 
 #include "utilities.hpp"
 
@@ -63,10 +65,17 @@ void data::open_device(int device, int kernel_mode) {
             fclose(f);
             rename(tmp.c_str(), path.c_str());
         } else {
+            // a file left behind by a run that died before rank 0 removed it must not be taken for this run's id: only a
+            // file written after this process started (minus a launch skew of 30 s) counts
+            const time_t born = time(nullptr) - 30;
             FILE* f = nullptr;
-            for (int tries = 0; tries < 6000 && !(f = fopen(path.c_str(), "rb")); tries++) {
-                struct timespec ts = {0, 10000000};
-                nanosleep(&ts, nullptr);
+            for (int tries = 0; tries < 6000 && !f; tries++) {
+                struct stat sb;
+                if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= born) f = fopen(path.c_str(), "rb");
+                if (!f) {
+                    struct timespec ts = {0, 10000000};
+                    nanosleep(&ts, nullptr);
+                }
             }
             if (!f || fread(id, 1, 128, f) != 128) die("FATAL: cannot read " + path);
             fclose(f);
