@@ -1261,12 +1261,29 @@ int gv_probit_denoise(gv_ctx* c, const gv_vec* p1, const gv_vec* y, double tau1,
 // data::compute_people_statistics (data.cpp:558-716): three table passes of the fp64 Ax kernel over the raw rows.
 int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double* numb_people) {
     NEED(c, c->have_stats && c->mask2, "gv_people_stats: marker statistics must be computed first");
-    NEED(c, c->have_raw, "gv_people_stats: needs the raw row layout (gv_set_layout(raw_rows = 1))");
+    const bool from_stripes = c->have_stripes && (c->kernel_mode == 1 || !c->have_raw);
+    NEED(c, c->have_raw || from_stripes, "gv_people_stats: no genotype layout resident");
     if (ensure_work(c)) return 1;
     for (gv_vec** v : {&c->mave_p, &c->msig_p, &c->numb_p})
         if (!*v && vec_new(c, GV_SPACE_N, v)) return 1;
     gv_vec* dst[3] = {c->mave_p, c->numb_p, c->msig_p};   // kinds 0 (sum value), 1 (count), 2 (sum value^2)
-    for (int kind = 0; kind < 3; kind++) {
+    if (from_stripes) {
+        // four passes over stripes_n in exact fixed point: the sum is an Ax of the all-ones vector, the count and the
+        // two halves of the sum of squares have their own operand tables (k_prep_people); the quadratic half reads the
+        // a^2 plane of the codes (MODE 4 of the streaming kernel)
+        hipStream_t s = c->stream;
+        double* ones = c->cg_d->d;
+        gvk::fill(s, ones, c->M, 1.0);
+        gvm::ax(s, c->plan, ones, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, c->mave_p->d);
+        gvm::ax_people(s, c->plan, 0, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->numb_p->d);
+        gvm::ax_people(s, c->plan, 1, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->msig_p->d);
+        gvm::ax_people(s, c->plan, 2, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->w_n->d);
+        gvk::axpby(s, c->msig_p->d, 1.0, c->msig_p->d, 1.0, c->w_n->d, c->npad);
+        KCHK(c);
+        for (int kind = 0; kind < 3; kind++)
+            if (comm_allreduce(c, dst[kind]->d, c->npad)) return 1;     // data.cpp:604-606
+    }
+    for (int kind = 0; kind < 3 && !from_stripes; kind++) {
         gvk::people_table(c->stream, c->mave, c->msig, c->M, kind, c->t3);
         gvk::ax_f64(c->stream, c->bed, c->M, c->pitch, c->t3, c->ax_chunks, c->ax_partial, c->npad);
         gvk::ax_reduce(c->stream, c->ax_partial, c->ax_chunks, c->npad, c->mask2, 1.0, dst[kind]->d);

@@ -48,6 +48,8 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb,
           const double* addxa = nullptr, const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
+void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, const double* msig, const uint32_t* mask2,
+               int64_t npad, double* red_partial, double* out);
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb);
 

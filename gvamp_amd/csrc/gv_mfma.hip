@@ -231,6 +231,38 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
         prep_final(partial + v * PREP_STRIDE, gridDim.x, scal + 4 * v, shm, shs);
 }
+// Operands of the three per-individual sums behind data::compute_people_statistics (data.cpp:590-624), in the Ax form
+// out = sum_m plane_m c_m + sum_m miss_m e_m - K0 with sigma = msig, mu = mave:
+//   kind 0: count of non-missing markers          c = 0,             e = -1,            K0 = -M                  (r' plane)
+//   kind 1: sigma^2 a^2 + mu^2 sigma^2 if present   c = sigma^2,       e = -mu^2 sigma^2, K0 = -sum mu^2 sigma^2   (a^2 plane)
+//   kind 2: -2 mu sigma^2 a if present              c = -2 mu sigma^2, e = 6 mu sigma^2,  K0 = 0                   (r' plane)
+// (r' = a for a present genotype and 3 for a missing one, which contributes 0 to every sum: the miss term takes back
+// what the code 3 and K0 put in.)  kind 1 + kind 2 = sum_m b ((a - mu) sigma)^2.
+__global__ __launch_bounds__(256) void k_prep_people(int kind, const double* __restrict__ mave, const double* __restrict__ msig,
+                                                     int64_t M, double* __restrict__ cv, double* __restrict__ ev,
+                                                     double* __restrict__ partial, double* __restrict__ scal,
+                                                     unsigned int* __restrict__ counters) {
+    __shared__ double shm[256], shs[256];
+    double mx = 0.0, s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const double mu = mave[i], s2 = msig[i] * msig[i];
+        double c, e, k;
+        if (kind == 0) {
+            c = 0.0; e = -1.0; k = -1.0;
+        } else if (kind == 1) {
+            // present: sigma^2 a^2 + mu^2 sigma^2 ; missing: plane 0, so the miss term removes mu^2 sigma^2
+            c = s2; e = -mu * mu * s2; k = -mu * mu * s2;
+        } else {
+            // present: -2 mu sigma^2 a ; missing (r' = 3): -6 mu sigma^2 + e = 0
+            c = -2.0 * mu * s2; e = 6.0 * mu * s2; k = 0.0;
+        }
+        cv[i] = c;
+        ev[i] = e;
+        mx = fmax(mx, fmax(fabs(c), fabs(e)));
+        s += k;
+    }
+    if (last_block(partial, mx, s, counters, shm, shs)) prep_final(partial, gridDim.x, scal, shm, shs);
+}
 // ATx operand p: block partials [0] = max|p|, [1] = sum p.  blockIdx.y = vector.
 struct PrepAtx { const double* p[2]; };
 __global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* __restrict__ partial, double* __restrict__ scal,
@@ -336,7 +368,13 @@ __device__ __forceinline__ void compute_step(const ABuf& a, const BFrag<MODE>& b
             const uint32_t w = a.t[i][d];
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
-            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            // MODE 4: the first plane is a^2 instead of r' (byte LUT r' -> {0,1,4,0}: code 3 = missing -> 0), for sums that are
+            // quadratic in the genotype (compute_people_statistics, data.cpp:608-624)
+            const v4i X = (MODE == 4) ? (v4i){(int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e0),
+                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e1),
+                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e2),
+                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e3)}
+                                      : (v4i){(int)e0, (int)e1, (int)e2, (int)e3};
             accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BX, accX[i], 0, 0, 0);
             const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     if (!live) return;
     const int64_t rows_p = nrg * 64;
     const int cd = c & 7;
-    if (MODE >= 2) {
+    if (MODE == 2 || MODE == 3) {
         const int pv = (c >> 3) * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -665,6 +703,25 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
     FinAx f{{out, nullptr}};
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
                        pl.scal, mask2, post, f, 2);
+}
+
+// one of the three per-individual sums of compute_people_statistics from stripes_n (k_prep_people): out[n] = mask * sum
+void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, const double* msig, const uint32_t* mask2,
+               int64_t npad, double* red_partial, double* out) {
+    const int nb = prep_blocks(pl.M);
+    hipLaunchKernelGGL(k_prep_people, dim3(nb), dim3(256), 0, s, kind, mave, msig, pl.M, pl.cv, pl.ev, red_partial, pl.scal,
+                       pl.counters);
+    QuantArgs q{};
+    q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
+    q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+    gvm::Plan pq = pl;      // no roofline events around the statistics passes
+    pq.ev0 = pq.ev1 = nullptr;
+    if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
+    else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
+    FinAx f{{out, nullptr}};
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, 1.0, f, 2);
 }
 
 // data::Ax of TWO M-vectors in one pass over stripes_n: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)

@@ -166,7 +166,8 @@ int gv_probit_denoise_cov(gv_ctx* ctx, const gv_vec* p1, const gv_vec* y, const 
 /* ---- --use-XXT-denoiser 1 (vamp.cpp:169-170, :599-606; denoiserXXT.cpp): LMMSE through CG in N-space, matrix-free --
  * data::compute_people_statistics (data.cpp:558-716): per-individual mean, inverse std and count of the standardised
  * genotypes, all-reduced over ranks; kept on the device for gv_cg_solve_aat.  Host copies (4*mbytes doubles each) are
- * optional (NULL).  Needs the raw row layout. */
+ * optional (NULL).  Kernel mode 0: three fp64 passes over the raw rows.  Kernel mode 1 (or no raw rows resident): four
+ * exact fixed-point passes over stripes_n, the quadratic one on the a^2 plane of the 2-bit codes. */
 int gv_people_stats(gv_ctx* ctx, double* mave_people, double* msig_people, double* numb_people);
 /* vamp::CG_solverAAT (denoiserXXT.cpp:52-130): solves (tau A A^T + gam2 I) mu = v in N-space with the per-individual
  * diagonal preconditioner, stopping at ||r||/||v|| < 1e-4.  mu_start may be NULL (zeros). */

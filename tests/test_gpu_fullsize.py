@@ -187,9 +187,19 @@ def test_config5_xxt_run_properties():
     """BASELINE config 5 (--use-XXT-denoiser 1, N=50k; M=200k): the joint N-space / Onsager solver against the reference
     sequence, and the Woodbury agreement with the M-space LMMSE path (two CG tolerances, 1e-4 / 1e-5)."""
     N, M = 50000, 200000
-    with capi.Shard(N, M) as sh:
-        sh.synth_bed(616161, 5000)                     # raw rows + stripes: people statistics read the raw rows
+    with capi.Shard(N, M) as sh:                       # people statistics: fp64 on the raw rows vs fixed point on the stripes
+        sh.synth_bed(616161, 5000)
         sh.compute_markers_statistics()
+        p0 = sh.compute_people_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        p1 = sh.compute_people_statistics()
+    for a, b in zip(p1, p0):
+        assert np.allclose(a, b, rtol=1e-10, atol=1e-12)     # the means are sums that cancel to ~1e-3
+    assert np.array_equal(p1[2], p0[2]) and p0[2].min() > 0.98 * M
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(False, True)                     # stripes only
+        sh.synth_bed(616161, 5000)
         sh.set_kernel_mode(1)
         sh.compute_markers_statistics()
         beta, y = hostapi.sim_phen(sh, 0.5, 2000, 13)

@@ -163,3 +163,15 @@ def test_modes_predict(world, oracle):
     for i in (0, 7, NT - 1):
         row = np.loadtxt(w["out"] + "g_predict_%d.csv" % i)
         assert np.allclose(row, [z2[i], z[i]], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kmode", [0, 1])
+def test_driver_xxt_denoiser(world, oracle, kmode):
+    """--use-XXT-denoiser 1 through the driver.  Kernel mode 1 keeps only the stripes resident (data.cpp ingest), so the
+    people statistics come from the stripes as well."""
+    w = world
+    run(["--run-mode", "infere", "--out-name", "x%d" % kmode, "--iterations", "3", "--use-XXT-denoiser", "1",
+         "--kernel-mode", kmode] + w["base"])
+    x = np.fromfile(w["out"] + "x%d_it_3.bin" % kmode)
+    ref = _oracle_run(oracle, w, iterations=3, use_XXT_denoiser=1)
+    assert np.linalg.norm(x - ref.x1[2]) / np.linalg.norm(ref.x1[2]) < 1e-6

@@ -33,6 +33,41 @@ def test_people_statistics_vs_oracle(oracle):
     assert np.all(g[0][:N][~present] == 0) and np.all(g[1][:N][~present] == 0)
 
 
+@pytest.mark.parametrize("N,M,miss", [(1003, 700, 15000), (257, 3001, 0), (4099, 1500, 200000), (64, 256, 5000)])
+def test_people_statistics_from_stripes(oracle, N, M, miss):
+    """Kernel mode 1 / stripes-only layout: the three per-individual sums come from four fixed-point passes over
+    stripes_n (one of them on the a^2 plane of the codes, MODE 4) instead of three fp64 passes over the raw rows."""
+    rng = np.random.default_rng(N)
+    bed = synth.synth_bed(N, M, seed=75, miss_ppm=miss)
+    present = rng.random(N) >= 0.03
+    m4 = np.zeros((N + 3) // 4, dtype=np.uint8)
+    for n in np.nonzero(present)[0]:
+        m4[n >> 2] |= 1 << (n & 3)
+    nonas = int(present.sum())
+    o = oracle.people_stats(bed, N, M, mask4=m4, nonas=nonas)
+    with capi.Shard(N, M) as sh:          # both layouts: mode 0 reads the raw rows, mode 1 the stripes
+        sh.upload_bed(bed)
+        sh.set_mask(m4, nonas)
+        sh.compute_markers_statistics()
+        g0 = sh.compute_people_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        g1 = sh.compute_people_statistics()
+    with capi.Shard(N, M) as sh:          # stripes only
+        sh.set_layout(False, True)
+        sh.upload_bed(bed)
+        sh.set_mask(m4, nonas)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        g2 = sh.compute_people_statistics()
+    for a, b, c, d in zip(g1, g2, g0, o):
+        assert np.array_equal(a, b)
+        assert np.allclose(a[:N], c[:N], rtol=1e-10, atol=1e-13)
+        assert np.allclose(a[:N], d[:N], rtol=1e-10, atol=1e-13)
+    assert np.array_equal(g1[2][:N][present], g0[2][:N][present])          # the counts are integers: exact
+    assert np.all(g1[0][:N][~present] == 0) and np.all(g1[1][:N][~present] == 0)
+
+
 @pytest.mark.parametrize("mode,fuse", [(0, 1), (1, 0), (1, 1), (1, 2)])
 def test_xxt_run_vs_oracle(oracle, mode, fuse):
     N, M = 600, 2000
@@ -73,10 +108,9 @@ def test_joint_nspace_and_onsager_solves_equal_the_separate_ones(warm):
     tau, gam2 = 2.0, 0.8
     with capi.Shard(N, M) as sh:
         sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
         sh.compute_markers_statistics()
-        sh.compute_people_statistics()              # on the raw rows (kernel mode 0) ...
-        sh.set_kernel_mode(1)                       # ... the solves on the MFMA kernels
-        sh.compute_markers_statistics()
+        sh.compute_people_statistics()
         dv, du = sh.vecN(v), sh.vecM(u)
         dm0 = sh.vecN(mu0) if warm else None
         a1, b1, a2, b2, at1, at2 = sh.vecN(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM()
