@@ -548,38 +548,49 @@ __global__ __launch_bounds__(256) void k_denoise(const double* __restrict__ r1, 
 }
 
 // vamp::updatePrior E-step (vamp.cpp:953-1013).  pr.probs[j] holds omegas[j] (j >= 1), pr.vars[j] the variances.
-// 64-thread blocks; per-thread accumulators and the num_j scratch live in LDS columns (no bank conflicts).
+// 64-thread blocks; per-thread accumulators and the num_j scratch live in LDS columns (no bank conflicts).  Everything
+// that depends on the component only (the exponent coefficient, the Gaussian prefactor, the posterior mean gain and
+// variance) is computed once per block, so an element costs one exp and a few FMAs per component instead of the nine
+// divisions / square roots of the formulas as written (same values up to the rounding of the re-association).
 __global__ __launch_bounds__(64) void k_prior_estep(const double* __restrict__ r1, int64_t n, double gam1,
                                                     double lambda, gv_prior pr, double* __restrict__ partial) {
     __shared__ double sh_num[GV_LMAX - 1][64];
     __shared__ double sh_R[GV_LMAX - 1][64];
     __shared__ double sh_G[GV_LMAX - 1][64];
+    __shared__ double c_exp[GV_LMAX - 1], c_pre[GV_LMAX - 1], c_gain[GV_LMAX - 1], c_var[GV_LMAX - 1];
     const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
     const double noise_var = 1 / gam1;
     double max_sigma = pr.vars[0];
     for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
+    if (t < Lm1) {
+        const double v = pr.vars[t + 1];
+        c_exp[t] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
+        c_pre[t] = lambda * pr.probs[t + 1] / sqrt(v + noise_var) / sqrt(2 * M_PI);
+        c_gain[t] = gam1 / (1 / v + gam1);
+        c_var[t] = 1.0 / (1.0 / v + gam1);
+    }
+    const double c0 = (1 - lambda) / sqrt(2 * M_PI * noise_var);
+    const double e0 = 0.5 * max_sigma / noise_var / (noise_var + max_sigma);
     for (int j = 0; j < Lm1; j++) sh_R[j][t] = sh_G[j][t] = 0.0;
+    __syncthreads();
     double acc_pin = 0.0;
     int64_t stride = (int64_t)gridDim.x * 64;
     for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
-        double r = r1[i], sum_of_elems = 0.0;
-        for (int j = 1; j < pr.L; j++) {
-            double num = lambda * pr.probs[j] *
-                         exp(-(r * r) / 2 * (max_sigma - pr.vars[j]) / (pr.vars[j] + noise_var) / (max_sigma + noise_var)) /
-                         sqrt(pr.vars[j] + noise_var) / sqrt(2 * M_PI);
-            sh_num[j - 1][t] = num;
+        const double r = r1[i], r2 = r * r;
+        double sum_of_elems = 0.0;
+        for (int j = 0; j < Lm1; j++) {
+            double num = c_pre[j] * exp(-r2 * c_exp[j]);
+            sh_num[j][t] = num;
             sum_of_elems += num;
         }
-        double pin = 1 / (1 + (1 - lambda) / sqrt(2 * M_PI * noise_var) *
-                                  exp(-(r * r) / 2 * max_sigma / noise_var / (noise_var + max_sigma)) / sum_of_elems);
+        const double inv = 1 / sum_of_elems;
+        const double pin = 1 / (1 + c0 * exp(-r2 * e0) * inv);
         acc_pin += pin;
-        for (int j = 1; j < pr.L; j++) {
-            double beta = sh_num[j - 1][t] / sum_of_elems;
-            double gm = gam1 * r / (1 / pr.vars[j] + gam1);
-            double vj = 1.0 / (1.0 / pr.vars[j] + gam1);
-            double gg = beta * (gm * gm + vj);
-            sh_R[j - 1][t] += beta * pin;
-            sh_G[j - 1][t] += gg * pin;
+        for (int j = 0; j < Lm1; j++) {
+            double beta = sh_num[j][t] * inv;
+            double gm = c_gain[j] * r;
+            sh_R[j][t] += beta * pin;
+            sh_G[j][t] += beta * (gm * gm + c_var[j]) * pin;
         }
     }
     double* o = partial + (int64_t)blockIdx.x * K;
