@@ -299,33 +299,38 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
     return r;
 }
 
-// The K-split of each streaming kernel is picked by measurement among the cost model's three candidates: one warm-up and
-// two timed launches each, on the resident stripes, with throw-away vectors (no counters, no collectives).  Once per
-// shard, before its first matvec in kernel mode 1.
+// The work decomposition of each streaming-kernel class (ATx, two-vector ATx, Ax, two-vector Ax) is picked by measurement
+// among the candidates gv_set_dims lists (uniform K-splits short-listed by the cost model, balanced grids, each with and
+// without progress-based wave priority): one warm-up and three timed launches each, on the resident stripes, with
+// throw-away vectors (no counters, no collectives).  Once per shard, before its first matvec in kernel mode 1.  Results
+// do not depend on the decomposition (exact integer accumulation), so tuning never changes a bit of output.
 int autotune_ks(gv_ctx* c) {
     c->ks_tuned = true;
     if ((c->ks_fixed_m && c->ks_fixed_n) || !c->have_stripes || c->M <= 0 || !c->have_stats) return 0;
     gvm::Plan& pl = c->plan;
-    double *xm = nullptr, *wm = nullptr, *pn = nullptr, *zn = nullptr;
+    double *xm = nullptr, *wm = nullptr, *wm2 = nullptr, *pn = nullptr, *zn = nullptr, *zn2 = nullptr;
     auto done = [&](int rc) {
-        for (double* q : {xm, wm, pn, zn}) if (q) (void)hipFree(q);
+        for (double* q : {xm, wm, wm2, pn, zn, zn2}) if (q) (void)hipFree(q);
         pl.ev0 = pl.ev1 = nullptr;
         return rc;
     };
     if (hipMalloc(&xm, sizeof(double) * c->M) != hipSuccess || hipMalloc(&wm, sizeof(double) * c->M) != hipSuccess ||
-        hipMalloc(&pn, sizeof(double) * c->npad) != hipSuccess || hipMalloc(&zn, sizeof(double) * c->npad) != hipSuccess) {
+        hipMalloc(&wm2, sizeof(double) * c->M) != hipSuccess || hipMalloc(&pn, sizeof(double) * c->npad) != hipSuccess ||
+        hipMalloc(&zn, sizeof(double) * c->npad) != hipSuccess || hipMalloc(&zn2, sizeof(double) * c->npad) != hipSuccess) {
         (void)hipGetLastError();
         return done(0);                      // no room for the scratch vectors: keep the model's pick
     }
     gvk::fill(c->stream, xm, c->M, 1.0);
     gvk::fill(c->stream, pn, c->npad, 1.0);
     pl.ev0 = pl.ev1 = nullptr;
-    auto time_one = [&](bool is_ax) -> double {
+    auto time_one = [&](int cls) -> double {   // cls: 0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax
         float best = 1e30f;
-        for (int rep = 0; rep < 3; rep++) {   // rep 0 warms up
+        for (int rep = 0; rep < 4; rep++) {   // rep 0 warms up
             (void)hipEventRecord(c->ev0, c->stream);
-            if (is_ax) gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
-            else gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
+            if (cls == 0) gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
+            else if (cls == 1) gvm::atx2(c->stream, pl, pn, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm, wm2, nullptr, nullptr, 1.0, 0.0);
+            else if (cls == 2) gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
+            else gvm::ax2(c->stream, pl, xm, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn, zn2);
             (void)hipEventRecord(c->ev1, c->stream);
             if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
             float ms = 0;
@@ -334,21 +339,27 @@ int autotune_ks(gv_ctx* c) {
         }
         return best;
     };
-    for (int side = 0; side < 2; side++) {
-        const bool is_ax = side == 1;
+    const bool verbose = getenv("GV_AUTOTUNE_VERBOSE") != nullptr;
+    if (time_one(0) < 0 || time_one(2) < 0) { KCHK(c); return done(1); }   // clocks and caches up before anything is compared
+    for (int cls = 0; cls < 4; cls++) {
+        const bool is_ax = cls >= 2;
         if (is_ax ? c->ks_fixed_n : c->ks_fixed_m) continue;
-        const int* cand = is_ax ? c->ks_cand_n : c->ks_cand_m;
-        int& ks = is_ax ? pl.ks_n : pl.ks_m;
-        int best_ks = cand[0];
+        const std::vector<gvm::Decomp>& cand = is_ax ? c->dec_cand_n : c->dec_cand_m;
+        gvm::Decomp& d = is_ax ? pl.dn[cls - 2] : pl.dm[cls];
+        if (cand.empty()) continue;
+        size_t best = 0;
         double best_t = -1;
-        for (int j = 0; j < 3; j++) {
-            if (j > 0 && (cand[j] == cand[0] || (j == 2 && cand[2] == cand[1]))) continue;
-            ks = cand[j];
-            const double t = time_one(is_ax);
-            if (t < 0) { ks = cand[0]; KCHK(c); return done(1); }
-            if (best_t < 0 || t < best_t * 0.995) { best_t = t; best_ks = cand[j]; }   // the model's order breaks near-ties
+        for (size_t j = 0; j < cand.size(); j++) {
+            d = cand[j];
+            const double t = time_one(cls);
+            if (t < 0) { d = cand[0]; KCHK(c); return done(1); }
+            if (verbose)
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d : %.4f ms\n", cls, d.ks, (long long)d.skL, d.prio, t);
+            if (best_t < 0 || t < best_t * 0.995) { best_t = t; best = j; }   // the list order breaks near-ties
         }
-        ks = best_ks;
+        d = cand[best];
+        if (verbose)
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld prio %d\n", cls, d.ks, (long long)d.skL, d.prio);
     }
     KCHK(c);
     return done(0);
@@ -638,22 +649,67 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
         for (int j = n; j < 3; j++) out3[j] = out3[n > 0 ? n - 1 : 0];
     };
     const int64_t min_ks_n = (M * 512 + 2147483646LL) / 2147483647LL;
-    rank_ks(pl.nrg_m, pl.nkb_m, 1, 0.4, c->ks_cand_m);
-    rank_ks(pl.nrg_n, pl.nkb_n, min_ks_n, 0.8, c->ks_cand_n);
-    pl.ks_m = c->ks_cand_m[0];
-    pl.ks_n = c->ks_cand_n[0];
+    int ks3_m[3], ks3_n[3];
+    rank_ks(pl.nrg_m, pl.nkb_m, 1, 0.4, ks3_m);
+    rank_ks(pl.nrg_n, pl.nkb_n, min_ks_n, 0.8, ks3_n);
+    // balanced decomposition (k_mfma_matvec<., true>): cells per workgroup for a grid of G workgroups.  A segment is at most
+    // min(skL, nkb) K-blocks long; on the Ax side it must respect the int32 bound that min_ks_n expresses.
+    auto skL_of = [](int64_t nrg, int64_t nkb, int64_t G) -> int64_t {
+        const int64_t U = ((nrg + 3) / 4) * nkb;
+        if (U <= 0 || G <= 0) return 0;
+        const int64_t L = (U + G - 1) / G;
+        return L < 8 ? 8 : L;
+    };
+    // Candidate list per side, default first: the uniform splits in the model's order without priority, the same with
+    // priority, then balanced grids of one and two workgroups per slot (always with priority: without it the staggered
+    // workgroups of a balanced launch lose ~10 % to the arbiter's oldest-first tail).
+    int prio_only = -1;                                    // GV_PRIO=0/1 (development): restrict to one setting
+    if (const char* e = getenv("GV_PRIO")) prio_only = atoi(e) ? 1 : 0;
+    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, bool balanced_ok, std::vector<gvm::Decomp>& out) {
+        out.clear();
+        for (int prio = 0; prio < 2; prio++) {
+            if (prio_only >= 0 && prio != prio_only) continue;
+            for (int j = 0; j < 3; j++) {
+                if (j > 0 && (ks3[j] == ks3[0] || (j == 2 && ks3[2] == ks3[1]))) continue;
+                gvm::Decomp d; d.ks = ks3[j]; d.skL = 0; d.prio = prio;
+                out.push_back(d);
+            }
+        }
+        if (balanced_ok && prio_only != 0 && nkb >= 2)
+            for (int r = 1; r <= 2; r++) {
+                gvm::Decomp d; d.ks = 1; d.skL = skL_of(nrg, nkb, 768 * r); d.prio = 1;
+                if (d.skL > 0) out.push_back(d);
+            }
+    };
+    build(ks3_m, pl.nrg_m, pl.nkb_m, true, c->dec_cand_m);
+    build(ks3_n, pl.nrg_n, pl.nkb_n, min_ks_n <= 1, c->dec_cand_n);
     c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
-    // overrides (development): GV_KS_M / GV_KS_N fix the K-splits of the ATx / Ax kernels, GV_AUTOTUNE=0 keeps the model's pick
+    // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
+    // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
+    // first candidate
+    auto fix = [&](std::vector<gvm::Decomp>& cand, bool& fixed, gvm::Decomp d) { cand.assign(1, d); fixed = true; };
     if (const char* e = getenv("GV_KS_M")) {
         int v = atoi(e);
-        if (v >= 1 && v <= pl.nkb_m) { pl.ks_m = v; c->ks_fixed_m = true; }
+        if (v >= 1 && v <= pl.nkb_m) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; fix(c->dec_cand_m, c->ks_fixed_m, d); }
     }
     if (const char* e = getenv("GV_KS_N")) {
         int v = atoi(e);
-        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n) { pl.ks_n = v; c->ks_fixed_n = true; }
+        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; fix(c->dec_cand_n, c->ks_fixed_n, d); }
+    }
+    if (const char* e = getenv("GV_SK_M")) {
+        gvm::Decomp d; d.skL = skL_of(pl.nrg_m, pl.nkb_m, atoi(e)); d.prio = prio_only != 0;
+        if (d.skL > 0) fix(c->dec_cand_m, c->ks_fixed_m, d);
+    }
+    if (const char* e = getenv("GV_SK_N")) {
+        gvm::Decomp d; d.skL = min_ks_n > 1 ? 0 : skL_of(pl.nrg_n, pl.nkb_n, atoi(e)); d.prio = prio_only != 0;
+        if (d.skL > 0) fix(c->dec_cand_n, c->ks_fixed_n, d);
     }
     if (const char* e = getenv("GV_AUTOTUNE"))
         if (atoi(e) == 0) c->ks_fixed_m = c->ks_fixed_n = true;
+    if (c->dec_cand_m.empty()) c->dec_cand_m.assign(1, gvm::Decomp());
+    if (c->dec_cand_n.empty()) { gvm::Decomp d; d.ks = (int)(min_ks_n > 1 ? min_ks_n : 1); c->dec_cand_n.assign(1, d); }
+    pl.dm[0] = pl.dm[1] = c->dec_cand_m[0];
+    pl.dn[0] = pl.dn[1] = c->dec_cand_n[0];
     return gv_set_mask(c, nullptr, N);
 }
 
@@ -683,11 +739,15 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.counters, sizeof(unsigned int) * 4));
         HIPCHK(c, hipMemsetAsync(pl.counters, 0, sizeof(unsigned int) * 4, c->stream));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
-        int km = pl.ks_m, kn = pl.ks_n;                     // room for every K-split candidate of autotune_ks
-        for (int j = 0; j < 3; j++) {
-            if (!c->ks_fixed_m && c->ks_cand_m[j] > km) km = c->ks_cand_m[j];
-            if (!c->ks_fixed_n && c->ks_cand_n[j] > kn) kn = c->ks_cand_n[j];
-        }
+        auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
+            int k = 1;
+            for (const gvm::Decomp& d : cand) {
+                const int p = d.skL > 0 ? (int)((nkb + d.skL - 1) / d.skL) + 1 : d.ks;
+                if (p > k) k = p;
+            }
+            return k;
+        };
+        const int km = pieces(c->dec_cand_m, pl.nkb_m), kn = pieces(c->dec_cand_n, pl.nkb_n);
         size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * 64 * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));

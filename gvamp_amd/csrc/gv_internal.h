@@ -43,9 +43,10 @@ struct gv_ctx {
     bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
     bool have_raw = false, have_stripes = false;
     gvm::Plan plan;
-    // K-split candidates of the cost model (best first) and whether the on-device pick among them has been made
-    int ks_cand_m[3] = {1, 1, 1}, ks_cand_n[3] = {1, 1, 1};
-    bool ks_fixed_m = false, ks_fixed_n = false;   // GV_KS_M / GV_KS_N given: nothing to pick
+    // candidate work decompositions of the ATx-side / Ax-side streaming kernels (default first) and whether the on-device
+    // pick among them has been made (autotune_ks)
+    std::vector<gvm::Decomp> dec_cand_m, dec_cand_n;
+    bool ks_fixed_m = false, ks_fixed_n = false;   // an override fixed the decomposition: nothing to pick
     bool ks_tuned = false;
 
     // workspaces ---------------------------------------------------------------------------------

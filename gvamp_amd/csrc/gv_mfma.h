@@ -5,11 +5,19 @@
 
 namespace gvm {
 
+struct Decomp {
+    int ks = 1;          // uniform: K-segments per quad (workgroups per group of 4 row groups)
+    int64_t skL = 0;     // > 0: balanced decomposition, cells (quad x K-block) per workgroup; 0: uniform K-split
+    int prio = 0;        // 1: waves lower their issue priority as they progress (k_mfma_matvec)
+};
+
 struct Plan {
     int64_t M = 0, N = 0;
     int64_t nrg_m = 0, nkb_m = 0;   // stripes_m: row groups of 64 markers x K-blocks of 256 individuals
     int64_t nrg_n = 0, nkb_n = 0;   // stripes_n: row groups of 64 individuals x K-blocks of 256 markers
-    int ks_m = 1, ks_n = 1;         // K-splits (workgroups per group of 4 row groups)
+    // work decomposition of the streaming kernel, per kernel class: dm[0] ATx (MODE 0), dm[1] two-vector ATx / p-value sums
+    // (MODE 2), dn[0] Ax and the people sums (MODE 1, 4), dn[1] two-vector Ax (MODE 3)
+    Decomp dm[2], dn[2];
     void* stripes_m = nullptr;
     void* stripes_n = nullptr;
     void* dig0 = nullptr;           // digit buffers, max(nkb_m, nkb_n) * 2048 bytes each

@@ -392,28 +392,87 @@ __device__ __forceinline__ void wg_barrier_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// grid: ceil(nrg / 4) * ksplit workgroups.
-// partial layout (int32): [(ks * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1) or 4 (MODE 2, 3:
-// planes 2v, 2v+1 belong to vector v)
-template <int MODE>
+// Work decomposition.  The work is the grid of (quad = 4 row groups, K-block) cells, linearised quad-major:
+// u = quad * nkb + kb.
+//   uniform (skL == 0): grid = ceil(nrg / 4) * ksplit workgroups; workgroup (quad, ks) walks the ks-th of ksplit equal
+//       K-segments of its quad.  All workgroups resident on an XCD walk the same K range in step.
+//   balanced (skL > 0): workgroup w walks cells [w skL, (w+1) skL) whatever quads they fall in, flushing its accumulators
+//       where the range crosses into the next quad.  With a grid of exactly the resident workgroups (768 = 256 CUs x 3)
+//       every workgroup gets the same number of cells and the launch has no ragged last round -- worth 10-17 % when
+//       ceil(nrg / 4) * ksplit is just above a multiple of 768 for every admissible ksplit (e.g. N = 50k: 782 quads).
+// partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1, 4) or 4
+// (MODE 2, 3: planes 2v, 2v+1 belong to vector v); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
+// workgroups that touch a quad are consecutive).  pieces_of() below is the count the epilogue kernels sum over.
+__device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL) {
+    if (skL <= 0) return ksplit;
+    const int64_t q = row >> 8;
+    return (int)(((q + 1) * nkb - 1) / skL - (q * nkb) / skL + 1);
+}
+
+#ifdef GV_WGTIME
+__device__ unsigned long long g_wgt[4 * 16384];   // development build only: per-workgroup start / end clock, XCC id, CU id
+#endif
+template <int MODE, bool SK>
 __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                  const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
-                                                 int32_t* __restrict__ partial) {
+                                                 int64_t skL, int prio, int32_t* __restrict__ partial) {
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
     constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
     __shared__ u32x4 sB[2][SS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t nq = (nrg + 3) >> 2;
-    const int64_t q = (int64_t)blockIdx.x % nq;
-    const int ks = (int)((int64_t)blockIdx.x / nq);
+    const int c = lane & 15, g = lane >> 4;
+    const int bofs = (MODE == 0) ? g * 8 + (c & 7) : lane;
+    const int dofs = (MODE == 0) ? (tid & 127) : tid;   // MODE 0: the block is 128 pieces; threads 128..255 copy pieces 0..127
+    // again into the unused half of the stage, so that the copy has no divergent branch (the loop body stays one basic block)
+    // cells of this workgroup: uniform over the workgroup, kept in SGPRs (32-bit: nq * nkb = M N / 65536 cells)
+    uint32_t u, uend;
+    const uint32_t nkb32 = (uint32_t)nkb, skL32 = (uint32_t)skL;
+    if (SK) {
+        const uint32_t U = (uint32_t)nq * nkb32;
+        u = blockIdx.x * skL32;
+        uend = u + skL32 < U ? u + skL32 : U;
+    } else {
+        const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
+        u = q0 * nkb32 + (uint32_t)(nkb * ks0 / ksplit);
+        uend = q0 * nkb32 + (uint32_t)(nkb * (ks0 + 1) / ksplit);
+    }
+    // Wave priority by remaining work (prio != 0).  The instruction arbiter favours the oldest wave of a SIMD, so the three
+    // workgroups of a CU finish one after the other (measured: 245 / 320 / 385 us for equal work) and a launch ends on a
+    // long, thinly occupied tail; a workgroup that is ahead of its neighbours now yields to them.  Four levels, lowered at
+    // each quarter of the workgroup's cells.  Whether it pays depends on the shape (many short rounds: yes; few long
+    // rounds: no), so it is one of the things autotune_ks measures.
+    const uint32_t p_quarter = (uend - u + 3) / 4;
+    uint32_t p_thr = prio ? u + p_quarter : 0xffffffffu, p_lvl = 3;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    ABuf a0, a1, a2;          // carried across the segments of a balanced range: a0 / a1 enter a segment holding its cells 0 / 1
+    u32x4 r0, r1;
+    bool primed = false;      // the previous segment already fetched this one's first two supertiles and first digit block
+    uint32_t par = 0;         // LDS stage of this segment's cell 0 (steps done so far, mod 2)
+    if (u >= uend) return;
+#ifdef GV_WGTIME
+    if (tid == 0 && blockIdx.x < 16384) {
+        g_wgt[4 * blockIdx.x] = wall_clock64();
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_wgt[4 * blockIdx.x + 2] = xcc & 0xf;
+        g_wgt[4 * blockIdx.x + 3] = hw;
+    }
+#endif
+#pragma unroll 1
+  do {
+    const uint32_t q32 = __builtin_amdgcn_readfirstlane(u / nkb32);
+    const int64_t q = q32, kb0 = u - q32 * nkb32;
+    const uint32_t seg = nkb32 - (uint32_t)kb0 < uend - u ? nkb32 - (uint32_t)kb0 : uend - u;   // to the end of the quad or of the range
+    const int64_t nsteps = seg;
+    const int ks = SK ? (int)__builtin_amdgcn_readfirstlane(blockIdx.x - (q32 * nkb32) / skL32)
+                      : (int)(blockIdx.x / (uint32_t)nq);
+    const uint32_t useg0 = u;   // first cell of this segment
+    u += seg;
     int64_t rg = q * 4 + (tid >> 6);
     const bool live = rg < nrg;      // a dead wave still loads digits and meets the barriers; it re-reads the last row group
     if (!live) rg = nrg - 1;
-    const int64_t kb0 = nkb * ks / ksplit, kb1 = nkb * (ks + 1) / ksplit;
-    const int64_t nsteps = kb1 - kb0;   // uniform over the workgroup
-    if (nsteps <= 0) return;
-    const int c = lane & 15, g = lane >> 4;
-    const int bofs = (MODE == 0) ? g * 8 + (c & 7) : lane;
 
     v4i accX[4], accY[4];
 #pragma unroll
@@ -421,37 +480,47 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         accX[i] = (v4i){0, 0, 0, 0};
         accY[i] = (v4i){0, 0, 0, 0};
     }
-    const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
-    // MODE 0: the block is 128 pieces; threads 128..255 copy pieces 0..127 again into the unused half of the stage, so
-    // that the copy has no divergent branch (the loop body stays one basic block)
-    const u32x4* g0 = dig0 + kb0 * KBS + (MODE == 0 ? (tid & 127) : tid);
-    const u32x4* g1 = (MODE == 3) ? dig1 + kb0 * KBS + tid : nullptr;
     const int64_t last = nsteps - 1;
+    const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
+    const u32x4* g0 = dig0 + kb0 * KBS + dofs;
+    const u32x4* g1 = (MODE == 3) ? dig1 + kb0 * KBS + tid : nullptr;
+    // Look-ahead past the end of the segment.  Uniform K-split, or last segment of a balanced range: the last cell again
+    // (clamped: no branches around loads).  Balanced range with another segment to come: that segment's first cells -- it
+    // starts at K-block 0 of quad q + 1 -- so the stream of loads never drains at a quad boundary.
+    const bool has_next = SK && u < uend && nkb32 >= 2;
+    int64_t rgn = (q + 1) * 4 + (tid >> 6);
+    if (rgn >= nrg) rgn = nrg - 1;
+    const u32x4* apn = has_next ? stripes + rgn * nkb * 256 + lane : ap + last * 256;
+    const u32x4* g0n = has_next ? dig0 + dofs : g0 + last * KBS;
+    const u32x4* g1n = (MODE == 3) ? (has_next ? dig1 + tid : g1 + last * KBS) : nullptr;
+    const int64_t nlastn = has_next ? (int64_t)(uend - u < nkb32 ? uend - u : nkb32) - 1 : 0;
+#define GV_A_AT(I) ((I) <= last ? ap + (I) * 256 : apn + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * 256)
+#define GV_D_AT(G, GN, I) ((I) <= last ? (G) + (I) * KBS : (GN) + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * KBS)
 
-    ABuf a0, a1, a2;
-    u32x4 r0, r1;
-    r0 = g0[0];
-    if (MODE == 3) r1 = g1[0];
-    load_a(a0, ap);
-    load_a(a1, ap + (last < 1 ? last : 1) * 256);
-    sB[0][tid] = r0;
-    if (MODE == 3) sB[0][256 + tid] = r1;
-    wg_barrier_lds();
+    if (!primed) {
+        r0 = g0[0];
+        if (MODE == 3) r1 = g1[0];
+        load_a(a0, ap);
+        load_a(a1, GV_A_AT((int64_t)1));
+        sB[par][tid] = r0;
+        if (MODE == 3) sB[par][256 + tid] = r1;
+        wg_barrier_lds();
+    }
 
-    // One step: prefetch the digits of K-block S+1 and the stripes of K-block S+2 (clamped: no branches around loads),
-    // multiply K-block S out of CUR and LDS stage S&1, park the digits in the other stage, meet the workgroup.
+    // One step: prefetch the digits of cell S+1 and the stripes of cell S+2, multiply cell S out of CUR and its LDS stage,
+    // park the digits in the other stage, meet the workgroup.
     // vmcnt retires in order: the digit load is issued BEFORE the 4 stripe loads so that the ds_write waits for it only.
 #define GV_WG_STEP(CUR, NXT, S)                                                        \
     {                                                                                  \
         const int64_t sv = (S);                                                        \
-        const int64_t n2 = sv + 2 < last ? sv + 2 : last, n1 = sv + 1 < last ? sv + 1 : last; \
-        r0 = g0[n1 * KBS];                                                             \
-        if (MODE == 3) r1 = g1[n1 * KBS];                                              \
-        load_a(NXT, ap + n2 * 256);                                                    \
+        const int64_t n2 = sv + 2, n1 = sv + 1;                                        \
+        r0 = *GV_D_AT(g0, g0n, n1);                                                    \
+        if (MODE == 3) r1 = *GV_D_AT(g1, g1n, n1);                                     \
+        load_a(NXT, GV_A_AT(n2));                                                      \
         BFrag<MODE> bf;                                                                \
-        lds_read_b<MODE>(bf, sB[sv & 1], bofs);                                        \
+        lds_read_b<MODE>(bf, sB[(sv + par) & 1], bofs);                                \
         compute_step<MODE>(CUR, bf, accX, accY);                                     \
-        u32x4* sw = sB[(sv + 1) & 1];                                                  \
+        u32x4* sw = sB[(sv + 1 + par) & 1];                                            \
         sw[tid] = r0;                                                                  \
         if (MODE == 3) sw[256 + tid] = r1;                                             \
         wg_barrier_lds();                                                              \
@@ -468,12 +537,24 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     }
 #pragma unroll 1
     for (; st < nsteps; st += 3) {
+        if (useg0 + (uint32_t)st >= p_thr) {
+            p_thr += p_quarter;
+            p_lvl = p_lvl > 0 ? p_lvl - 1 : 0;
+            if (p_lvl == 2) __builtin_amdgcn_s_setprio(2);
+            else if (p_lvl == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         GV_WG_STEP(a0, a2, st)
         GV_WG_STEP(a1, a0, st + 1)
         GV_WG_STEP(a2, a1, st + 2)
     }
 #undef GV_WG_STEP
-    if (!live) return;
+#undef GV_A_AT
+#undef GV_D_AT
+    par = (par + (uint32_t)nsteps) & 1u;
+    primed = has_next;
+    // (every wave has passed the barrier of the last step: nobody still reads the LDS ring when the next segment refills it)
+    if (!live) continue;
     const int64_t rows_p = nrg * 64;
     const int cd = c & 7;
     if (MODE == 2 || MODE == 3) {
@@ -487,7 +568,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
                 partial[(((int64_t)ks * 4 + pv + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
             }
         }
-        return;
+        continue;
     }
     const bool stX = c < 8;
     const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);
@@ -500,7 +581,23 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
             if (stY) partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
         }
     }
+  } while (SK && u < uend);
+#ifdef GV_WGTIME
+    if (tid == 0 && blockIdx.x < 16384) g_wgt[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
+#ifdef GV_WGTIME
+}  // namespace
+extern "C" int gv_debug_wgtime(unsigned long long* out, int n) {
+    if (!out) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wgt)) != hipSuccess) return 1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * 4 * 16384);
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(unsigned long long) * 4 * (size_t)n);
+}
+namespace {
+#endif
 
 __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
 
@@ -509,9 +606,10 @@ __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, 
 // (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N): the ingredients of data::pvals_calc, data.cpp:1150-1170)
 __global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                    const double* __restrict__ scal1, const double* __restrict__ scal2,
-                                                   double* __restrict__ out) {
+                                                   double* __restrict__ out, int64_t nkb, int64_t skL) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
+    ksplit = pieces_of(m, ksplit, nkb, skL);
     long long s[4][7];
 #pragma unroll
     for (int pl = 0; pl < 4; pl++)
@@ -551,7 +649,7 @@ struct FinAtx { double* out[2]; const double* addx[2]; };   // addx != NULL: out
 __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                  const double* __restrict__ scal_base, const double* __restrict__ mave,
                                                  const double* __restrict__ msig, double inv_sqrt_n, FinAtx a, double tau,
-                                                 double gam2, int ppk) {
+                                                 double gam2, int ppk, int64_t nkb, int64_t skL) {
     // ppk = planes per K-split in `partial` (2, or 4 for the two-vector kernels); vector v = blockIdx.y owns planes 2v, 2v+1
     const int v = blockIdx.y, p0 = 2 * v;
     const double* __restrict__ scal = scal_base + 4 * v;
@@ -559,6 +657,7 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
+    ksplit = pieces_of(m, ksplit, nkb, skL);
     for (int ks = 0; ks < ksplit; ks++) {
         const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
         const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
@@ -580,7 +679,8 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
 struct FinAx { double* out[2]; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
-                                                const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk) {
+                                                const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
+                                                int64_t nkb, int64_t skL) {
     const int v = blockIdx.y, p0 = 2 * v;       // vector v owns planes 2v (r'.c) and 2v+1 (miss.e)
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
@@ -592,6 +692,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
         return;
     }
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
+    ksplit = pieces_of(n, ksplit, nkb, skL);
     for (int ks = 0; ks < ksplit; ks++) {
         for (int plane = 0; plane < 2; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
             const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + plane) * rows_p + n) * 8);
@@ -610,11 +711,16 @@ inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 // launch of the streaming kernel of one matvec (HIP events around it when the roofline timing is on)
 template <int MODE>
 void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, const void* dig0, const void* dig1, int64_t nrg,
-                   int64_t nkb, int ks) {
+                   int64_t nkb, const gvm::Decomp& d) {
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
-    hipLaunchKernelGGL(k_mfma_matvec<MODE>, dim3((unsigned)(nq * ks)), dim3(256), 0, s, (const u32x4*)stripes,
-                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, ks, pl.partial);
+    const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    if (d.skL > 0)
+        hipLaunchKernelGGL((k_mfma_matvec<MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, pl.partial);
+    else
+        hipLaunchKernelGGL((k_mfma_matvec<MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, pl.partial);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 
@@ -663,10 +769,10 @@ static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, cons
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
          double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2) {
     prep_quant_atx(s, pl, p, nullptr, npad, red_partial);
-    launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
+    launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[0]);
     FinAtx f{{out, nullptr}, {addx, nullptr}};
-    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2);
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 1), dim3(256), 0, s, pl.partial, pl.dm[0].ks, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2, pl.nkb_m, pl.dm[0].skL);
 }
 
 // data::ATx of TWO N-vectors in one pass over stripes_m
@@ -674,10 +780,10 @@ void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb, const double* addxa,
           const double* addxb, double tau, double gam2) {
     prep_quant_atx(s, pl, pa, pb, npad, red_partial);
-    launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
+    launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
     FinAtx f{{outa, outb}, {addxa, addxb}};
-    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 2), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4);
+    hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 2), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4, pl.nkb_m, pl.dm[1].skL);
 }
 
 // one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
@@ -687,10 +793,10 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
     {
         gvm::Plan q = pl;      // no roofline events around the p-value pass
         q.ev0 = q.ev1 = nullptr;
-        launch_stream<2>(s, q, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.ks_m);
+        launch_stream<2>(s, q, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
     }
-    hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.ks_m, pl.nrg_m * 64, pl.M,
-                       pl.scal, pl.scal + 4, out4);
+    hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
+                       pl.scal, pl.scal + 4, out4, pl.nkb_m, pl.dm[1].skL);
 }
 
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
@@ -702,10 +808,10 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
     q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
     q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
-    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
+    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
     FinAx f{{out, nullptr}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 2);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, f, 2, pl.nkb_n, pl.dn[0].skL);
 }
 
 // one of the three per-individual sums of compute_people_statistics from stripes_n (k_prep_people): out[n] = mask * sum
@@ -720,11 +826,11 @@ void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, cons
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
     gvm::Plan pq = pl;      // no roofline events around the statistics passes
     pq.ev0 = pq.ev1 = nullptr;
-    if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
-    else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.ks_n);
+    if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
+    else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
     FinAx f{{out, nullptr}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, 1.0, f, 2);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, 1.0, f, 2, pl.nkb_n, pl.dn[0].skL);
 }
 
 // data::Ax of TWO M-vectors in one pass over stripes_n: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
@@ -739,10 +845,10 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
     q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
     q.v[3] = pl.ev2; q.scal[3] = pl.scal + 4; q.out[3] = (uint32_t*)pl.dig1; q.col0[3] = 8;
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
-    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.ks_n);
+    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[1]);
     FinAx f{{outa, outb}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 2), dim3(256), 0, s, pl.partial, pl.ks_n, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 4);
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 2), dim3(256), 0, s, pl.partial, pl.dn[1].ks, pl.nrg_n * 64, npad,
+                       pl.scal, mask2, post, f, 4, pl.nkb_n, pl.dn[1].skL);
 }
 
 }  // namespace gvm

@@ -7,6 +7,8 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gvamp_amd import capi
+if os.environ.get("GV_DBG_LIB"):
+    capi.LIB_PATH = os.environ["GV_DBG_LIB"]          # development: an experimental build of the library
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=100000)
