@@ -187,7 +187,7 @@ def main():
     ms_atx = cnt["ms_atx_kernel"] / max(cnt["n_atx_kernel"], 1)
     ax_gbps = shard_bytes / (ms_ax * 1e-3) / 1e9 if ms_ax > 0 else 0.0
     atx_gbps = shard_bytes / (ms_atx * 1e-3) / 1e9 if ms_atx > 0 else 0.0
-    kname = "k_mfma_matvec<1> (Ax)" if a.mode == 1 else "k_ax_f64"
+    kname = "k_mfma_matvec<1, SK> (Ax)" if a.mode == 1 else "k_ax_f64"
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes of this same command (counters cannot be
     # read from inside the process); the committed summary is quoted when it was taken on the same configuration.
     traffic = None

@@ -49,8 +49,8 @@ def main():
                 "FETCH_SIZE counts wide streaming reads at half, MI355X_MICROARCH.md section HBM)",
         "N": N, "Mt": Mt, "n_gpus": 1, "kernel_mode": 1,
     }
-    for key, frag in (("ax", "k_mfma_matvec<1>"), ("atx", "k_mfma_matvec<0>"), ("ax2", "k_mfma_matvec<3>"),
-                      ("atx2", "k_mfma_matvec<2>")):
+    for key, frag in (("ax", "k_mfma_matvec<1,"), ("atx", "k_mfma_matvec<0,"), ("ax2", "k_mfma_matvec<3,"),
+                      ("atx2", "k_mfma_matvec<2,")):
         fk, wk = pick(fetch, frag), pick(write, frag)
         if fk is None or wk is None:
             continue

@@ -45,9 +45,10 @@ with capi.Shard(N, M) as sh:
         first.sum(), np.median(dur[first]), (~first).sum(), np.median(dur[~first]) if (~first).any() else 0,
         np.median(st[~first]) if (~first).any() else 0))
     # chip occupancy over time: resident workgroups sampled every 10 us
-    ts = np.arange(0, en.max(), 10.0)
+    step = 10.0 if en.max() < 1000 else en.max() / 60
+    ts = np.arange(0, en.max(), step)
     occ = [(int(((st <= t) & (en > t)).sum())) for t in ts]
-    print("resident wgs every 10 us:", " ".join(str(o) for o in occ))
+    print("resident wgs every %.0f us:" % step, " ".join(str(o) for o in occ))
     xcc = a[:, 2]
     for k in range(8):
         m = xcc == k
