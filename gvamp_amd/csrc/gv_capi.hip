@@ -612,6 +612,8 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     HIPCHK(c, hipMalloc(&c->ax_partial, sizeof(double) * c->ax_chunks * c->npad));
     // i8 MFMA family: int32 digit sums must not overflow (|r'| <= 3, |digit| <= 128; Ax adds the miss plane)
     NEED(c, N * 384 < 2147483647LL, "gv_set_dims: N too large for the int32 accumulators of kernel mode 1");
+    // the streaming kernel counts (quad, K-block) cells in 32 bits: M N / 65536 of them (35 TB of genotypes at the limit)
+    NEED(c, ((M + 255) / 256 + 1) * ((N + 255) / 256 + 1) < 2147483647LL, "gv_set_dims: shard too large for the 32-bit cell index");
     gvm::Plan& pl = c->plan;
     pl.M = M; pl.N = N;
     pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
