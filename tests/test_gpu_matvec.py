@@ -287,3 +287,47 @@ def test_bandwidth_probes_report_plausible_rates():
         r2 = sh.read_bandwidth(1 << 28, 3)
     for v in (r1, r2, c1):
         assert 200.0 < v < 20000.0, v
+
+
+@pytest.mark.parametrize("N,M", [(3000, 5000), (1003, 20011), (70001, 777)])
+def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
+    """The streaming kernel's work decomposition (uniform K-split, balanced ranges that cross quad boundaries, with or without
+    progress-based wave priority) only changes who adds which int32 partial sums: every product must
+    come out bit for bit the same.  The decomposition is fixed per context through the development overrides."""
+    import os
+    rng = np.random.default_rng(N + M)
+    bed = synth.synth_bed(N, M, seed=91, miss_ppm=20000)
+    x, x2 = rng.standard_normal(M), rng.standard_normal(M) * 1e-3
+    npad = 4 * ((N + 3) // 4)
+    p, p2 = np.zeros(npad), np.zeros(npad)
+    p[:N], p2[:N] = rng.standard_normal(N), rng.standard_normal(N) * 50.0
+    settings = [
+        {"GV_AUTOTUNE": "0"},                                     # the cost model's first uniform split
+        {"GV_KS_M": "1", "GV_KS_N": "1"},
+        {"GV_KS_M": "3", "GV_KS_N": "5", "GV_PRIO": "1"},
+        {"GV_SK_M": "37", "GV_SK_N": "53"},                       # balanced, ranges of >= 8 cells across quad boundaries
+        {"GV_SK_M": "768", "GV_SK_N": "1536", "GV_PRIO": "0"},
+        {},                                                       # whatever the on-device autotune picks
+    ]
+    results = []
+    for env in settings:
+        for k in ("GV_AUTOTUNE", "GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_PRIO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with capi.Shard(N, M) as sh:
+            sh.upload_bed(bed)
+            sh.set_kernel_mode(1)
+            sh.compute_markers_statistics()
+            dx, dx2, dp, dp2 = sh.vecM(x), sh.vecM(x2), sh.vecN(p), sh.vecN(p2)
+            o1, o2, o3, o4, o5, o6 = sh.vecN(), sh.vecM(), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM()
+            sh.ax_dev(dx, o1)
+            sh.atx_dev(dp, o2)
+            sh.ax2_dev(dx, dx2, o3, o4)
+            sh.atx2_dev(dp, dp2, o5, o6)
+            people = sh.compute_people_statistics()
+            results.append([v.download() for v in (o1, o2, o3, o4, o5, o6)] + list(people))
+    for r in results[1:]:
+        for a, b in zip(r, results[0]):
+            assert np.array_equal(a, b)
+    assert np.array_equal(results[0][0], results[0][2]) and np.array_equal(results[0][1], results[0][4])   # one- vs two-vector pass
