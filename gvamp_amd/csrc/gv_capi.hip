@@ -301,7 +301,8 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 
 // The work decomposition of each streaming-kernel class (ATx, two-vector ATx, Ax, two-vector Ax) is picked by measurement
 // among the candidates gv_set_dims lists (uniform K-splits short-listed by the cost model, balanced grids, each with and
-// without progress-based wave priority): one warm-up and three timed launches each, on the resident stripes, with
+// without progress-based wave priority; then tapered segment lengths for the winner if it is a uniform split): one warm-up and
+// two timed runs of 2 to 16 Ax / ATx pairs each (the shorter the kernels the more), on the resident stripes, with
 // throw-away vectors (no counters, no collectives).  Once per shard, before its first matvec in kernel mode 1.  Results
 // do not depend on the decomposition (exact integer accumulation), so tuning never changes a bit of output.
 int autotune_ks(gv_ctx* c) {
@@ -323,43 +324,75 @@ int autotune_ks(gv_ctx* c) {
     gvk::fill(c->stream, xm, c->M, 1.0);
     gvk::fill(c->stream, pn, c->npad, 1.0);
     pl.ev0 = pl.ev1 = nullptr;
-    auto time_one = [&](int cls) -> double {   // cls: 0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax
+    // What is timed is the pair the solvers issue -- an Ax-side product followed by an ATx-side product, launched
+    // asynchronously -- not a kernel back to back with itself: a decomposition that wins in isolation by 2 % was measured
+    // 10 % behind inside the alternating sequence (N = 50k x M = 200k, two-vector Ax).  The side that is not being tuned runs
+    // its current pick.
+    auto run_pair = [&](int dual) {
+        if (dual) {
+            gvm::ax2(c->stream, pl, xm, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn, zn2);
+            gvm::atx2(c->stream, pl, pn, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm, wm2, nullptr, nullptr, 1.0, 0.0);
+        } else {
+            gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
+            gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
+        }
+    };
+    auto time_pair = [&](int dual) -> double {   // ms per pair; short kernels get more repetitions (>= ~25 ms per candidate)
+        int reps = 1;
         float best = 1e30f;
-        for (int rep = 0; rep < 4; rep++) {   // rep 0 warms up
+        for (int round = 0; round < 3; round++) {   // round 0 warms up and sizes the repetition count
             (void)hipEventRecord(c->ev0, c->stream);
-            if (cls == 0) gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
-            else if (cls == 1) gvm::atx2(c->stream, pl, pn, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm, wm2, nullptr, nullptr, 1.0, 0.0);
-            else if (cls == 2) gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
-            else gvm::ax2(c->stream, pl, xm, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn, zn2);
+            for (int r = 0; r < reps; r++) run_pair(dual);
             (void)hipEventRecord(c->ev1, c->stream);
             if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
             float ms = 0;
             (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            if (rep > 0 && ms < best) best = ms;
+            if (round == 0) {
+                const int want = (int)(12.5f / (ms > 1e-3f ? ms : 1e-3f)) + 1;
+                reps = want < 2 ? 2 : (want > 16 ? 16 : want);
+            } else if (ms / reps < best) {
+                best = ms / reps;
+            }
         }
         return best;
     };
     const bool verbose = getenv("GV_AUTOTUNE_VERBOSE") != nullptr;
-    if (time_one(0) < 0 || time_one(2) < 0) { KCHK(c); return done(1); }   // clocks and caches up before anything is compared
-    for (int cls = 0; cls < 4; cls++) {
-        const bool is_ax = cls >= 2;
+    if (time_pair(0) < 0) { KCHK(c); return done(1); }   // clocks and caches up before anything is compared
+    for (int step = 0; step < 4; step++) {
+        const int dual = step >> 1;
+        const bool is_ax = (step & 1) == 0;             // Ax side first, then the ATx side against the tuned Ax
+        const int cls = is_ax ? 2 + dual : dual;        // 0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax
         if (is_ax ? c->ks_fixed_n : c->ks_fixed_m) continue;
         const std::vector<gvm::Decomp>& cand = is_ax ? c->dec_cand_n : c->dec_cand_m;
-        gvm::Decomp& d = is_ax ? pl.dn[cls - 2] : pl.dm[cls];
+        gvm::Decomp& d = is_ax ? pl.dn[dual] : pl.dm[dual];
         if (cand.empty()) continue;
         size_t best = 0;
         double best_t = -1;
         for (size_t j = 0; j < cand.size(); j++) {
             d = cand[j];
-            const double t = time_one(cls);
+            const double t = time_pair(dual);
             if (t < 0) { d = cand[0]; KCHK(c); return done(1); }
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d : %.4f ms\n", cls, d.ks, (long long)d.skL, d.prio, t);
-            if (best_t < 0 || t < best_t * 0.995) { best_t = t; best = j; }   // the list order breaks near-ties
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d : %.4f ms / pair\n", cls, d.ks, (long long)d.skL, d.prio, t);
+            if (best_t < 0 || t < best_t * 0.997) { best_t = t; best = j; }   // the list order breaks near-ties
         }
         d = cand[best];
+        // second stage, uniform splits with more than one segment: taper the segment lengths so that the workgroups
+        // dispatched last are the shortest (the launch's tail is one workgroup-duration long)
+        if (d.skL <= 0 && d.ks > 1 && d.taper == 0.f) {
+            gvm::Decomp keep = d;
+            for (float tp : {0.5f, 0.9f}) {
+                d = keep; d.taper = tp;
+                const double t = time_pair(dual);
+                if (t < 0) { d = cand[0]; KCHK(c); return done(1); }
+                if (verbose)
+                    fprintf(stderr, "[gvamp autotune] class %d ks %d taper %.1f prio %d : %.4f ms / pair\n", cls, d.ks, tp, d.prio, t);
+                if (t < best_t * 0.997) { best_t = t; keep = d; }
+            }
+            d = keep;
+        }
         if (verbose)
-            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld prio %d\n", cls, d.ks, (long long)d.skL, d.prio);
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld prio %d taper %.1f\n", cls, d.ks, (long long)d.skL, d.prio, d.taper);
     }
     KCHK(c);
     return done(0);
@@ -690,13 +723,14 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
     // first candidate
     auto fix = [&](std::vector<gvm::Decomp>& cand, bool& fixed, gvm::Decomp d) { cand.assign(1, d); fixed = true; };
+    const float taper_env = getenv("GV_TAPER") ? (float)atof(getenv("GV_TAPER")) : 0.f;
     if (const char* e = getenv("GV_KS_M")) {
         int v = atoi(e);
-        if (v >= 1 && v <= pl.nkb_m) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; fix(c->dec_cand_m, c->ks_fixed_m, d); }
+        if (v >= 1 && v <= pl.nkb_m && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_m, c->ks_fixed_m, d); }
     }
     if (const char* e = getenv("GV_KS_N")) {
         int v = atoi(e);
-        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; fix(c->dec_cand_n, c->ks_fixed_n, d); }
+        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_n, c->ks_fixed_n, d); }
     }
     if (const char* e = getenv("GV_SK_M")) {
         gvm::Decomp d; d.skL = skL_of(pl.nrg_m, pl.nkb_m, atoi(e)); d.prio = prio_only != 0;

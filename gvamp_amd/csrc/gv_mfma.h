@@ -9,6 +9,8 @@ struct Decomp {
     int ks = 1;          // uniform: K-segments per quad (workgroups per group of 4 row groups)
     int64_t skL = 0;     // > 0: balanced decomposition, cells (quad x K-block) per workgroup; 0: uniform K-split
     int prio = 0;        // 1: waves lower their issue priority as they progress (k_mfma_matvec)
+    float taper = 0.f;   // uniform split only: K-segment j is (1 + taper (ks-1-2j)/(ks-1)) times the mean length, so the
+                         // workgroups dispatched last (the last segment) are the shortest and the launch's tail is short
 };
 
 struct Plan {

@@ -412,10 +412,14 @@ __device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, i
 #ifdef GV_WGTIME
 __device__ unsigned long long g_wgt[4 * 16384];   // development build only: per-workgroup start / end clock, XCC id, CU id
 #endif
+// K-block boundaries of the segments of a uniform split (b[0] = 0 ... b[ks] = nkb; ks <= GV_MAX_KS)
+constexpr int GV_MAX_KS = 64;
+struct KBounds { uint32_t b[GV_MAX_KS + 1]; };
+
 template <int MODE, bool SK>
 __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                  const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
-                                                 int64_t skL, int prio, int32_t* __restrict__ partial) {
+                                                 int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial) {
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
     constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
     __shared__ u32x4 sB[2][SS];
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         uend = u + skL32 < U ? u + skL32 : U;
     } else {
         const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
-        u = q0 * nkb32 + (uint32_t)(nkb * ks0 / ksplit);
-        uend = q0 * nkb32 + (uint32_t)(nkb * (ks0 + 1) / ksplit);
+        u = q0 * nkb32 + kbnd.b[ks0];
+        uend = q0 * nkb32 + kbnd.b[ks0 + 1];
     }
     // Wave priority by remaining work (prio != 0).  The instruction arbiter favours the oldest wave of a SIMD, so the three
     // workgroups of a CU finish one after the other (measured: 245 / 320 / 385 us for equal work) and a launch ends on a
@@ -715,12 +719,27 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    KBounds kb{};
+    if (d.skL <= 0) {
+        const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
+        double acc = 0.0;
+        kb.b[0] = 0;
+        for (int j = 0; j < ks; j++) {      // cumulative tapered lengths, every segment at least one K-block (ks <= nkb)
+            const double w = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
+            acc += w;
+            int64_t e = (int64_t)((double)nkb * acc / (double)ks + 0.5);
+            const int64_t lo = (int64_t)kb.b[j] + 1, hi = nkb - (ks - 1 - j);
+            e = e < lo ? lo : (e > hi ? hi : e);
+            kb.b[j + 1] = (uint32_t)e;
+        }
+        kb.b[ks] = (uint32_t)nkb;
+    }
     if (d.skL > 0)
         hipLaunchKernelGGL((k_mfma_matvec<MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, pl.partial);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial);
     else
         hipLaunchKernelGGL((k_mfma_matvec<MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, pl.partial);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 
