@@ -1,6 +1,6 @@
-# development: tapered uniform splits at one shape.  usage: taperprobe.sh N M "ksm list" "ksn list"
+# development: tapered uniform splits at one shape.  usage: taperprobe.sh N M "km:kn pairs" "tapers" "prios"
 N=$1; M=$2
-for prio in 0 1; do for taper in 0 0.3 0.6 0.9; do
+for prio in ${5:-0 1}; do for taper in ${4:-0 0.5 0.9}; do
   for pair in $3; do
     km=${pair%:*}; kn=${pair#*:}
     echo -n "prio $prio taper $taper ks_m $km ks_n $kn : "
