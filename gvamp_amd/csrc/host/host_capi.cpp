@@ -4,18 +4,30 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 
 #include "data.hpp"
 #include "gvamp_host.h"
 #include "utilities.hpp"
 #include "vamp.hpp"
 
+// Exceptions of the host classes (the reference lets them terminate the program, e.g. initialize_prior's
+// "No probabilities or variances were specified and Mt < 50,000", utilities.cpp:91-140) stop at the C boundary: the entry
+// points return 1 and gvh_last_error() holds the message.
+static thread_local std::string g_host_err;
+#define GVH_TRY try {
+#define GVH_CATCH } catch (const std::exception& e) { g_host_err = e.what(); return 1; } \
+                    catch (...) { g_host_err = "unknown C++ exception"; return 1; }
+
 extern "C" {
+
+const char* gvh_last_error(void) { return g_host_err.c_str(); }
 
 // sim.cpp:78-79,153,183-218 on an already-resident shard: beta (local M), y (N).  Every rank draws the same beta /
 // noise streams; data::Ax carries the cross-rank all-reduce when a communicator is attached.
 int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, int CV, unsigned long seed,
                  double* beta_out, double* y_out) {
+    GVH_TRY
     gv_host_set_quiet(true);   // library use: nothing on stdout (bench.py prints exactly one JSON line)
     std::vector<double> vars_true{0, h2 / CV};
     std::vector<double> probs_true{1 - (double)CV / Mt, (double)CV / Mt};
@@ -33,12 +45,14 @@ int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, 
     memcpy(beta_out, beta_all.data() + S, sizeof(double) * M);
     memcpy(y_out, y.data(), sizeof(double) * N);
     return 0;
+    GVH_CATCH
 }
 
 int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int S, int rank, const double* y,
                       const unsigned char* mask4, int nonas, const double* true_signal, double* x_est,
                       gvh_iter* iters, int iters_cap, int* n_iters, double* x1_hist, double* x2_hist, double* r1_hist,
                       double* probs_out, double* vars_out, int* L_out) {
+    GVH_TRY
     std::vector<double> yv(y, y + N);
     std::vector<unsigned char> m4;
     if (mask4) m4.assign(mask4, mask4 + (N + 3) / 4);
@@ -102,6 +116,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
         if (vars_out) vars_out[i] = v[i];
     }
     return 0;
+    GVH_CATCH
 }
 
 }  // extern "C"

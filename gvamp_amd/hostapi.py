@@ -47,6 +47,7 @@ def load():
         L.gvh_infere_linear.argtypes = [C.c_void_p, C.POINTER(Opts), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, up,
                                         C.c_int, dp, dp, C.POINTER(Iter), C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp,
                                         C.POINTER(C.c_int)]
+        L.gvh_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -59,7 +60,7 @@ def sim_phen(shard, h2, CV, seed, rank=0):
     """sim.cpp:78-79,153,183-218 on a resident shard: (beta of this rank's markers, y)."""
     beta, y = np.empty(max(shard.M, 1)), np.empty(shard.N)
     if load().gvh_sim_phen(shard.h, shard.N, shard.M, shard.Mt, shard.S, rank, h2, CV, seed, _dp(beta), _dp(y)):
-        raise capi.GvError("gvh_sim_phen failed")
+        raise capi.GvError("gvh_sim_phen failed: " + load().gvh_last_error().decode())
     return beta[:shard.M].copy(), y
 
 
@@ -110,8 +111,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
                              shard.N if nonas is None else nonas, _dp(ts), _dp(x_est), iters, iterations, C.byref(n),
                              _dp(hist[0]), _dp(hist[1]), _dp(hist[2]), _dp(pout), _dp(vout), C.byref(Lout))
     if rc:
-        raise capi.GvError("gvh_infere_linear failed: " + L.gv_last_error(shard.h).decode()
-                           if hasattr(L, "gv_last_error") else "gvh_infere_linear failed")
+        raise capi.GvError("gvh_infere_linear failed: " + L.gvh_last_error().decode())
     r = Result()
     r.niter = n.value
     r.x_est = x_est[:M].copy()

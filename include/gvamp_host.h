@@ -44,6 +44,9 @@ typedef struct {
 } gvh_iter;
 
 /* sim.cpp data recipe on a resident shard: beta_out[M] (this rank's slice), y_out[N] (identical on every rank) */
+/* message of the last failed gvh_* call of this thread (a C++ exception of the host classes, caught at the boundary) */
+const char* gvh_last_error(void);
+
 int gvh_sim_phen(gv_ctx* ctx, int N, int M, int Mt, int S, int rank, double h2, int CV, unsigned long seed,
                  double* beta_out, double* y_out);
 

@@ -18,7 +18,8 @@ with capi.Shard(N, M) as sh:
     sh.synth_bed(4242, 5000)
     sh.compute_markers_statistics()
     beta, y = hostapi.sim_phen(sh, 0.5, max(1, M // 100), 1)
-    r = hostapi.infere_linear(sh, y, None, None, iterations=iters, CG_max_iter=50, rho=0.5, seed=1, true_signal=beta,
+    prior = (None, None) if M >= 50000 else ([0.9, 0.1], [0, 0.5 / max(1, M // 100) * 0.1])
+    r = hostapi.infere_linear(sh, y, prior[0], prior[1], iterations=iters, CG_max_iter=50, rho=0.5, seed=1, true_signal=beta,
                               history=False, fuse_solves=fuse, use_XXT_denoiser=xxt)
 for t in r.trace:
     print(round(t["seconds"], 4), t["cg_iters"], t["n_ax_pass"] + t["n_atx_pass"])

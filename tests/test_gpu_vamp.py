@@ -287,3 +287,16 @@ def test_bench_prints_exactly_one_json_line():
               "dtype", "data", "config", "roofline", "cpu_baseline", "vamp"):
         assert k in d, k
     assert d["steps"] == 2 and d["n_gpus"] == 1 and d["roofline"]["traffic"] is None     # no PMC profile for this size
+
+
+def test_host_exceptions_stop_at_the_c_boundary():
+    """initialize_prior (utilities.cpp:91-140) throws when no prior is given and Mt < 50 000; the reference lets that end the
+    program.  Behind the flat C entry points it comes back as an error code and a message, not as an abort of the caller."""
+    N, M = 300, 500
+    bed = synth.synth_bed(N, M, seed=5)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        with pytest.raises(capi.GvError, match="Mt < 50,000"):
+            hostapi.infere_linear(sh, np.zeros(N), None, None, iterations=1)
+        r = hostapi.infere_linear(sh, np.random.default_rng(0).standard_normal(N), [0.9, 0.1], [0, 0.01], iterations=1)   # still usable
+        assert r.niter == 1
