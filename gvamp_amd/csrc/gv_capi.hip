@@ -237,25 +237,6 @@ int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes) {
     return 0;
 }
 
-// the Student-t tails of the p-values are independent per marker and run on the host: spread over the host cores
-template <class F>
-void host_parallel_for(int64_t n, F f) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 32) nt = 32;
-    if (nt < 2 || n < 4096) {
-        for (int64_t k = 0; k < n; k++) f(k);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const int64_t chunk = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; t++) {
-        const int64_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
-        if (lo >= hi) break;
-        pool.emplace_back([=, &f]() { for (int64_t k = lo; k < hi; k++) f(k); });
-    }
-    for (std::thread& th : pool) th.join();
-}
-
 struct Timer {
     gv_ctx* c;
     double* acc;
@@ -1677,55 +1658,7 @@ done:
 }
 
 // ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------
-// Student-t two-sided tail P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2): Lentz continued fraction of the incomplete beta
-// function (DLMF 8.17.22); the reference calls Boost's students_t (utilities.cpp:330-331).
-static double beta_cf(double a, double b, double x) {
-    const double tiny = 1e-300;
-    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
-    if (fabs(d) < tiny) d = tiny;
-    d = 1.0 / d;
-    double h = d;
-    for (int m = 1; m <= 100000; m++) {
-        const double m2 = 2.0 * m;
-        double num = m * (b - m) * x / ((a - 1.0 + m2) * (a + m2));
-        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        h *= d * c;
-        num = -(a + m) * (a + b + m) * x / ((a + m2) * (a + 1.0 + m2));
-        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        const double delta = d * c;
-        h *= delta;
-        if (fabs(delta - 1.0) < 1e-16) break;
-    }
-    return h;
-}
-static double t_two_sided(double t, double nu) {
-    if (std::isnan(t) || !(nu > 0)) return NAN;
-    if (t == 0) return 1.0;
-    if (std::isinf(t)) return 0.0;
-    const double a = 0.5 * nu, b = 0.5, w = t * t / nu, x = 1.0 / (1.0 + w);
-    double lnB;   // -ln B(a, 1/2); asymptotic series of lgamma(a + 1/2) - lgamma(a) for large a (DLMF 5.11.13)
-    if (a >= 30.0) {
-        const double ia = 1.0 / a, ia2 = ia * ia;
-        lnB = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
-    } else
-        lnB = lgamma(a + b) - lgamma(a) - lgamma(b);
-    const double front = exp(lnB - a * log1p(w) + b * (log(w) - log1p(w)));
-    if (x < (a + 1.0) / (a + b + 2.0)) return front * beta_cf(a, b, x) / a;
-    return 1.0 - front * beta_cf(b, a, w / (1.0 + w)) / b;
-}
-// utilities.cpp:321-334
-static double reg1d_pval(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, double n) {
-    const double s2y = (sumsqy - sumy * sumy / n) / (n - 1), s2x = (sumsqx - sumx * sumx / n) / (n - 1);
-    const double sxy = (sumxy - sumx * sumy / n) / (n - 1);
-    const double rxy = sxy / sqrt(s2x * s2y);
-    const double t = rxy * sqrt((n - 2) / (1 - rxy * rxy));
-    return t_two_sided(fabs(t), n - 2);
-}
-
+// (the per-marker regression test and its Student-t tail: k_pvals_test, gv_kernels.hip)
 // out4[4m..] = {sum a p, sum b p, sum a p^2, sum b p^2} for the N-space device vector p (one pass in kernel mode 1)
 static int marker_sums_p_p2(gv_ctx* c, const double* p, double* p2_scratch, double* out4_dev) {
     gvk::mul(c->stream, p2_scratch, p, p, c->npad);
@@ -1749,68 +1682,48 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
     const int64_t M = c->M;
     const double sqrtN = sqrt((double)c->N);
     gv_vec *ymod = nullptr, *ych = nullptr, *sq = nullptr, *xch = nullptr;
-    double* sums_dev = nullptr;
+    double *sums_dev = nullptr, *pv_dev = nullptr;
     int* chrom_dev = nullptr;
     int rc = 0;
-    std::vector<double> sums(4 * (M > 0 ? M : 1)), mave(M > 0 ? M : 1), msig(M > 0 ? M : 1), xh(M > 0 ? M : 1);
-    std::vector<uint32_t> cnt(3 * (M > 0 ? M : 1));
+    const size_t Mn = (size_t)(M > 0 ? M : 1);
     auto cleanup = [&]() {
         for (gv_vec* v : {ymod, ych, sq, xch}) vec_del(c, v);
         if (sums_dev) (void)hipFree(sums_dev);
+        if (pv_dev) (void)hipFree(pv_dev);
         if (chrom_dev) (void)hipFree(chrom_dev);
     };
 #define PV_TRY(expr) do { if ((rc = (expr)) != 0) { cleanup(); return rc; } } while (0)
 #define PV_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
     PV_TRY(vec_new(c, GV_SPACE_N, &ymod));
     PV_TRY(vec_new(c, GV_SPACE_N, &sq));
-    PV_HIP(hipMalloc(&sums_dev, sizeof(double) * 4 * (M > 0 ? M : 1)));
+    PV_HIP(hipMalloc(&sums_dev, sizeof(double) * 4 * Mn));
+    PV_HIP(hipMalloc(&pv_dev, sizeof(double) * Mn));
+    PV_HIP(hipMemsetAsync(pv_dev, 0, sizeof(double) * Mn, c->stream));
     gvk::axpby(c->stream, ymod->d, 1.0, y->d, -1.0, z1->d, c->npad);            // y_mod = y - z1 (data.cpp:1117-1119)
-    PV_HIP(hipMemcpyAsync(mave.data(), c->mave, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-    PV_HIP(hipMemcpyAsync(msig.data(), c->msig, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-    PV_HIP(hipMemcpyAsync(cnt.data(), c->counts, sizeof(uint32_t) * 3 * M, hipMemcpyDeviceToHost, c->stream));
-    PV_HIP(hipMemcpyAsync(xh.data(), x1_hat->d, sizeof(double) * M, hipMemcpyDeviceToHost, c->stream));
-    auto marker_test = [&](int64_t k, double cself) {
-        // exact masked sums of the standardised column from the genotype counts (the reference sums them in fp64)
-        const double n2 = cnt[3 * k], n1 = cnt[3 * k + 1], n0 = cnt[3 * k + 2], mu = mave[k], sg = msig[k];
-        const double count = n0 + n1 + n2;
-        const double sumx = sg * (2.0 * n2 + n1 - mu * count);
-        const double sumsqx = sg * sg * (n2 * (2.0 - mu) * (2.0 - mu) + n1 * (1.0 - mu) * (1.0 - mu) + n0 * mu * mu);
-        const double* s4 = &sums[4 * k];
-        const double svy = sg * (s4[0] - mu * s4[1]);                            // sum value * y
-        const double sumxy = svy + cself * sumsqx;
-        const double sumy = s4[1] + cself * sumx;
-        const double sumsqy = s4[3] + 2.0 * cself * svy + cself * cself * sumsqx;
-        return reg1d_pval(sumx, sumsqx, sumxy, sumy, sumsqy, count);
-    };
     if (!chrom) {
         PV_TRY(marker_sums_p_p2(c, ymod->d, sq->d, sums_dev));
-        PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
-        PV_HIP(hipStreamSynchronize(c->stream));
         // y_mark = y_mod + gen_part * x1_hat[k] (data.cpp:1145-1148): the marker's own column, c = x1_hat[k] / sqrt(N)
-        host_parallel_for(M, [&](int64_t k) { pvals[k] = marker_test(k, xh[k] / sqrtN); });
+        gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, x1_hat->d, 1.0 / sqrtN, nullptr, 0, M, pv_dev);
     } else {
         PV_TRY(vec_new(c, GV_SPACE_N, &ych));
         PV_TRY(vec_new(c, GV_SPACE_M, &xch));
-        PV_HIP(hipMalloc(&chrom_dev, sizeof(int) * (M > 0 ? M : 1)));
+        PV_HIP(hipMalloc(&chrom_dev, sizeof(int) * Mn));
         PV_HIP(hipMemcpyAsync(chrom_dev, chrom, sizeof(int) * M, hipMemcpyHostToDevice, c->stream));
         double present[24];
         for (int ch = 0; ch < 24; ch++) present[ch] = 0;
         for (int64_t k = 0; k < M; k++) if (chrom[k] >= 1 && chrom[k] <= 23) present[chrom[k]] += 1;
         PV_TRY(allreduce_scalars(c, present, 24));
-        for (int64_t k = 0; k < M; k++) pvals[k] = 0.0;
         for (int ch = 1; ch <= 23; ch++) {
             if (present[ch] == 0) continue;      // no rank holds a marker of this chromosome
             gvk::select_eq(c->stream, xch->d, x1_hat->d, chrom_dev, ch, M);
             PV_TRY(ax_device(c, xch->d, ych->d));                                // chromosome predictor, all ranks (:1268-1272)
             gvk::axpby(c->stream, ych->d, 1.0, ych->d, 1.0, ymod->d, c->npad);   // + y_mod (:1284)
             PV_TRY(marker_sums_p_p2(c, ych->d, sq->d, sums_dev));
-            PV_HIP(hipMemcpyAsync(sums.data(), sums_dev, sizeof(double) * 4 * M, hipMemcpyDeviceToHost, c->stream));
-            PV_HIP(hipStreamSynchronize(c->stream));
-            host_parallel_for(M, [&](int64_t k) {
-                if (chrom[k] == ch) pvals[k] = marker_test(k, 0.0);
-            });
+            gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, nullptr, 0.0, chrom_dev, ch, M, pv_dev);
         }
     }
+    KCHK(c);
+    if (M > 0) PV_TRY(to_host(c, pvals, pv_dev, sizeof(double) * M));
 #undef PV_TRY
 #undef PV_HIP
     cleanup();

@@ -136,6 +136,8 @@ void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_p
              double* partial, double* out);                   // out[0] = sum g1d, out[1] = sum (x1-r1)^2
 void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& om_vars,
                  double* partial, double* out);               // out[0..1+2(L-1))
+void pvals_test(hipStream_t s, const uint32_t* cnt, const double* mave, const double* msig, const double* sums4,
+                const double* xself, double self_scale, const int* chrom, int ch, int64_t M, double* pvals);
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n);
 void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink);
 }  // namespace gvk
