@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgvamp.so")
-SOURCES = ["gv_kernels.hip", "gv_mfma.hip", "gv_capi.hip"]
+SOURCES = ["gv_kernels.hip", "gv_mfma.hip", "gv_capi.hip", "gv_solvers.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
 
@@ -23,7 +23,8 @@ def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, "gv_internal.h"), os.path.join(ROOT, "include", "gvamp.h")]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
-    if not force and not _newer(LIB, deps):
+    have_objs = all(os.path.exists(os.path.join(CSRC, os.path.basename(x) + ".o")) for x in srcs)
+    if not force and have_objs and not _newer(LIB, deps):
         return LIB
     objs = []
     for s in srcs:

@@ -13,7 +13,7 @@
 
 #include "gv_internal.h"
 
-namespace {
+namespace gvi {
 
 thread_local std::string g_create_err;
 
@@ -27,22 +27,6 @@ int fail(gv_ctx* c, const char* fmt, ...) {
     else g_create_err = buf;
     return 1;
 }
-
-#define HIPCHK(c, call)                                                                      \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define NCCLCHK(c, call)                                                                     \
-    do {                                                                                     \
-        ncclResult_t r_ = (call);                                                            \
-        if (r_ != ncclSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
-    } while (0)
-#define KCHK(c) HIPCHK(c, hipGetLastError())
-#define NEED(c, cond, msg)                 \
-    do {                                   \
-        if (!(cond)) return fail(c, msg);  \
-    } while (0)
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -237,23 +221,6 @@ int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes) {
     return 0;
 }
 
-struct Timer {
-    gv_ctx* c;
-    double* acc;
-    bool on;
-    Timer(gv_ctx* c_, double* acc_) : c(c_), acc(acc_), on(c_->timing == 1) {
-        if (on) (void)hipEventRecord(c->ev0, c->stream);
-    }
-    void stop() {
-        if (!on) return;
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        *acc += ms;
-        on = false;
-    }
-};
 
 // timing == 2: resolve the pending event pairs into the kernel counters
 void ev_resolve(gv_ctx* c) {
@@ -419,7 +386,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 }
 
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
-int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0) {
+int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, double tau, double gam2) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     if (c->kernel_mode == 1 && c->M > 0 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
@@ -481,8 +448,8 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     }
     return 0;
 }
-int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
-                const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0) {
+int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
+                const double* addxb, double tau, double gam2) {
     if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
         if (atx_device(c, pa, outa, addxa, tau, gam2)) return 1;
         return atx_device(c, pb, outb, addxb, tau, gam2);
@@ -528,7 +495,9 @@ void free_dataset(gv_ctx* c) {
     c->have_stats = false;
 }
 
-}  // namespace
+}  // namespace gvi
+
+using namespace gvi;
 
 extern "C" {
 
@@ -1000,292 +969,6 @@ int gv_set_phen(gv_ctx* c, gv_vec* y_out, const double* y_host) {
     return 0;
 }
 
-// ---- solver ---------------------------------------------------------------------------------------------
-int gv_lmmse_mult(gv_ctx* c, const gv_vec* v, double tau, double gam2, gv_vec* out) {
-    NEED(c, v->space == GV_SPACE_M && out->space == GV_SPACE_M && v != out, "gv_lmmse_mult: M-space, no aliasing");
-    return lmmse_device(c, v->d, tau, gam2, out->d);
-}
-
-// vamp::precondCG_solver (vamp.cpp:1130-1229) as a small state machine, so that TWO solves on the same operator
-// (the LMMSE solve and the Onsager probe solve of one VAMP iteration, vamp.cpp:593-596 / :884) can share every pass
-// over the genotype shard: each round gathers the pending operator applications Q p of the active systems and runs
-// them as one two-vector Ax / ATx pair.  Per system the recurrences, stopping rules and results are exactly those of
-// a stand-alone solve.  Deviations from the reference, all result-neutral: <r,z> and ||v|| are
-// computed once per step instead of three times / every step; lmmse_mult's all-zero shortcut (:1079) is replaced by
-// "mu_start == NULL"; the scalar reductions of one step travel in packed all-reduces.
-struct CgSys {
-    const double* v = nullptr;
-    const double* mu0 = nullptr;   // warm start or NULL
-    double *mu = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *d = nullptr;
-    int denoiser = 1;
-    double* relres = nullptr;
-    // state
-    bool active = true;
-    int phase = 1;                 // 0: waiting for Q mu0 (initial residual), 1: waiting for Q p
-    double rz = 0, norm_v = 0, prev_onsager = 0, onsager = 0, rel_err = 0;
-    int iters = 0, n_relres = 0, converged = 0;
-    const double* req = nullptr;   // operand of the pending operator application
-    double* res = nullptr;         // where its result goes
-    // by-products (gv_cg_solve2x)
-    double* az = nullptr;          // N-space: A mu, accumulated from the A p_k of the operator applications
-    const double* wslot = nullptr; // N-space buffer holding A req after the last application
-    bool keep_resid = false;       // keep r = v - Q mu exact on the Onsager-rule exit too
-};
-
-static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
-    // z = r / diag (:1152), <r,z>, ||v||^2 ; p = z (:1154)
-    const int64_t M = c->M;
-    double sc[4];
-    gvk::cg_step_b(c->stream, s.r, s.d, 0.0, diag, s.z, s.mu, M, c->red_partial, c->red_out);
-    KCHK(c);
-    if (read_scalars(c, 4, sc)) return 1;
-    const double* vv[1] = {s.v};
-    gvk::dots(c->stream, 1, vv, vv, M, c->red_partial, c->red_out);
-    KCHK(c);
-    double vn2;
-    if (read_scalars(c, 1, &vn2)) return 1;
-    double pk[2] = {sc[0], vn2};
-    if (multi && allreduce_scalars(c, pk, 2)) return 1;
-    s.rz = pk[0];
-    s.norm_v = sqrt(pk[1]);
-    HIPCHK(c, hipMemcpyAsync(s.p, s.z, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
-    s.phase = 1;
-    s.req = s.p;
-    s.res = s.d;
-    return 0;
-}
-
-// One CG step (:1160-1223) of every system whose operator application has just come back.  The systems move through
-// the three reductions of a step TOGETHER: their scalars sit in disjoint slots of red_out (8 doubles per system), so a
-// step costs three all-reduce + read-back round trips however many systems are active (sharded jobs: the latency of
-// these small messages is what remains of a CG step besides the two passes over the shard).
-static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double diag, int max_iter, bool multi) {
-    const int64_t M = c->M;
-    hipStream_t st = c->stream;
-    CgSys* stp[2];
-    int slot[2];
-    int ns = 0;
-    for (int k = 0; k < na; k++) {
-        CgSys& s = *act[k];
-        if (s.phase == 0) {                                               // r = v - Q mu0 (:1142-1145)
-            gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
-            if (s.az) HIPCHK(c, hipMemcpyAsync(s.az, s.wslot, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, st));   // A mu0
-            KCHK(c);
-            if (cg_finish_init(c, s, diag, multi)) return 1;
-            if (max_iter <= 0) s.active = false;
-        } else {
-            slot[ns] = k;
-            stp[ns++] = &s;
-        }
-    }
-    if (ns == 0) return 0;
-    const int K = 8 * (slot[ns - 1] + 1);
-    double sc[16], alpha[2] = {0, 0};
-    auto part = [&](int j) { return c->red_partial + (size_t)slot[j] * RED_BLOCKS * 8; };
-    auto outp = [&](int j) { return c->red_out + 8 * slot[j]; };
-    // <d, p>
-    for (int j = 0; j < ns; j++) {
-        const double* xs[1] = {stp[j]->d};
-        const double* ys[1] = {stp[j]->p};
-        gvk::dots(st, 1, xs, ys, M, part(j), outp(j));
-    }
-    KCHK(c);
-    if (read_scalars_global(c, K, sc, multi)) return 1;
-    bool any_onsager = false;
-    for (int j = 0; j < ns; j++) {
-        CgSys& s = *stp[j];
-        alpha[j] = s.rz / sc[8 * slot[j]];                                // :1167
-        gvk::cg_step_a(st, s.mu, s.p, alpha[j], s.v, M, part(j), outp(j));   // mu += alpha p (:1169-1172)
-        if (s.az) gvk::axpby(st, s.az, 1.0, s.az, alpha[j], s.wslot, c->npad);   // A mu += alpha A p
-        any_onsager |= s.denoiser == 0;
-    }
-    KCHK(c);
-    bool stepping[2] = {true, true};
-    if (any_onsager) {                                                    // :1174-1193
-        if (read_scalars_global(c, K, sc, multi)) return 1;
-        for (int j = 0; j < ns; j++) {
-            CgSys& s = *stp[j];
-            s.iters++;
-            if (s.denoiser != 0) continue;
-            s.onsager = gam2 * sc[8 * slot[j]];
-            const double oerr = (s.onsager != 0) ? fabs((s.onsager - s.prev_onsager) / s.onsager) : 1.0;
-            if (oerr < 1e-8) {
-                if (s.keep_resid) gvk::axpby(st, s.r, 1.0, s.r, -alpha[j], s.d, M);   // the reference leaves r one step behind
-                s.converged = 1;
-                s.active = false;
-                stepping[j] = false;
-            }
-            s.prev_onsager = s.onsager;
-        }
-    } else
-        for (int j = 0; j < ns; j++) stp[j]->iters++;
-    bool any = false;
-    for (int j = 0; j < ns; j++) {
-        if (!stepping[j]) continue;
-        CgSys& s = *stp[j];
-        gvk::cg_step_b(st, s.r, s.d, alpha[j], diag, s.z, s.mu, M, part(j), outp(j));   // :1195-1216
-        any = true;
-    }
-    KCHK(c);
-    if (!any) return 0;
-    if (read_scalars_global(c, K, sc, multi)) return 1;
-    for (int j = 0; j < ns; j++) {
-        if (!stepping[j]) continue;
-        CgSys& s = *stp[j];
-        const double* q = sc + 8 * slot[j];
-        const double beta = q[0] / s.rz;                                  // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
-        s.rz = q[0];
-        gvk::axpby(st, s.p, 1.0, s.z, beta, s.p, M);                      // p = z + beta p (:1209-1210)
-        s.rel_err = sqrt(q[2]) / s.norm_v;                                // :1215
-        if (s.relres) s.relres[s.iters - 1] = s.rel_err;
-        s.n_relres = s.iters;
-        if (s.rel_err < 1e-5) {                                           // :1217,:1222
-            s.converged = 1;
-            s.active = false;
-        } else if (s.iters >= max_iter)
-            s.active = false;
-    }
-    KCHK(c);
-    return 0;
-}
-
-// two-vector operator: outa = tau A^T A xa + gam2 xa, outb likewise, ONE Ax pass and ONE ATx pass (kernel mode 1)
-static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double tau, double gam2, double* outa,
-                         double* outb) {
-    if (ensure_work(c)) return 1;
-    if (ensure_w2(c)) return 1;
-    if (ax2_device(c, xa, xb, c->w_n->d, c->w_n2->d)) return 1;
-    return atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb, xa, xb, tau, gam2);
-}
-
-// ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
-// one system is still active (a two-vector pass costs what a one-vector pass costs), else by a pass of its own.
-static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x = nullptr,
-                  double* ride_out = nullptr) {
-    const int64_t M = c->M;
-    const bool multi = is_multi(c);
-    const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
-    for (int k = 0; k < nsys; k++) {
-        CgSys& s = sys[k];
-        if (s.mu0) {
-            HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
-            s.phase = 0;
-            s.req = s.mu;
-            s.res = s.r;
-        } else {
-            gvk::fill(c->stream, s.mu, M, 0.0);
-            if (s.az) gvk::fill(c->stream, s.az, c->npad, 0.0);
-            HIPCHK(c, hipMemcpyAsync(s.r, s.v, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
-            if (cg_finish_init(c, s, diag, multi)) return 1;
-        }
-        if (max_iter <= 0 && s.phase == 1) s.active = false;
-    }
-    for (;;) {
-        CgSys* act[2];
-        int na = 0;
-        for (int k = 0; k < nsys; k++)
-            if (sys[k].active) act[na++] = &sys[k];
-        if (na == 0) break;
-        if (na == 2) {
-            if (lmmse2_device(c, act[0]->req, act[1]->req, tau, gam2, act[0]->res, act[1]->res)) return 1;
-            act[0]->wslot = c->w_n->d;
-            act[1]->wslot = c->w_n2->d;
-        } else {
-            if (ride_x) {                                                 // Ax of the rider in the free slot
-                if (ensure_work(c)) return 1;
-                if (ax2_device(c, act[0]->req, ride_x, c->w_n->d, ride_out)) return 1;
-                if (atx_device(c, c->w_n->d, act[0]->res, act[0]->req, tau, gam2)) return 1;
-                ride_x = nullptr;
-            } else if (lmmse_device(c, act[0]->req, tau, gam2, act[0]->res))
-                return 1;
-            act[0]->wslot = c->w_n->d;
-        }
-        if (cg_consume_all(c, act, na, gam2, diag, max_iter, multi)) return 1;
-    }
-    if (ride_x && ax_device(c, ride_x, ride_out)) return 1;
-    return 0;
-}
-
-static void cg_fill_stats(const CgSys& s, gv_cg_stats* st) {
-    if (!st) return;
-    st->iters = s.iters;
-    st->converged = s.converged;
-    st->rel_res = s.rel_err;
-    st->onsager = s.onsager;
-    st->n_relres = s.n_relres;
-}
-
-int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int denoiser,
-                int max_iter, gv_vec* mu_out, gv_cg_stats* st, double* relres) {
-    NEED(c, v->space == GV_SPACE_M && mu_out->space == GV_SPACE_M, "gv_cg_solve: M-space vectors required");
-    NEED(c, mu_out != v && mu_out != mu_start, "gv_cg_solve: mu_out must not alias v or mu_start");
-    if (ensure_work(c)) return 1;
-    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
-    CgSys s;
-    s.v = v->d; s.mu0 = mu_start ? mu_start->d : nullptr; s.mu = mu_out->d;
-    s.r = c->cg_r->d; s.z = c->cg_z->d; s.p = c->cg_p->d; s.d = c->cg_d->d;
-    s.denoiser = denoiser; s.relres = relres;
-    if (cg_run(c, &s, 1, tau, gam2, max_iter)) return 1;
-    cg_fill_stats(s, st);
-    if (st) {
-        st->n_ax = (int)(c->cnt.n_ax - ax0);
-        st->n_atx = (int)(c->cnt.n_atx - atx0);
-    }
-    return 0;
-}
-
-// The LMMSE solve (denoiser = 1, optional warm start) and the Onsager probe solve (denoiser = 0, zero start) of one VAMP
-// iteration in lock-step.  n_ax / n_atx of the stats count vector products (2 per shared pass).
-int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
-                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
-                  double* relres_b, const gv_cg_extras* ex) {
-    NEED(c, v_a->space == GV_SPACE_M && v_b->space == GV_SPACE_M && mu_a->space == GV_SPACE_M && mu_b->space == GV_SPACE_M,
-         "gv_cg_solve2: M-space vectors required");
-    NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && mu_a != mu_b, "gv_cg_solve2: outputs must not alias inputs");
-    gv_cg_extras none{};
-    if (!ex) ex = &none;
-    NEED(c, (ex->ride_x == nullptr) == (ex->ride_out == nullptr), "gv_cg_solve2x: ride_x and ride_out go together");
-    NEED(c, !ex->ride_x || (ex->ride_x->space == GV_SPACE_M && ex->ride_out->space == GV_SPACE_N),
-         "gv_cg_solve2x: ride_x is M-space, ride_out N-space");
-    NEED(c, !ex->a_mu_a || ex->a_mu_a->space == GV_SPACE_N, "gv_cg_solve2x: a_mu_a is N-space");
-    NEED(c, !ex->ata_mu_b || (ex->ata_mu_b->space == GV_SPACE_M && ex->ata_mu_b != mu_b && ex->ata_mu_b != v_b),
-         "gv_cg_solve2x: ata_mu_b is M-space and must not alias v_b / mu_b");
-    NEED(c, !ex->ata_mu_b || tau != 0.0, "gv_cg_solve2x: ata_mu_b needs tau != 0");
-    if (ensure_work(c)) return 1;
-    if (ensure_w2(c)) return 1;
-    for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
-        if (!*w && vec_new(c, GV_SPACE_M, w)) return 1;
-    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
-    CgSys s[2];
-    s[0].v = v_a->d; s[0].mu0 = mu_start_a ? mu_start_a->d : nullptr; s[0].mu = mu_a->d;
-    s[0].r = c->cg_r->d; s[0].z = c->cg_z->d; s[0].p = c->cg_p->d; s[0].d = c->cg_d->d;
-    s[0].denoiser = 1; s[0].relres = relres_a;
-    s[0].az = ex->a_mu_a ? ex->a_mu_a->d : nullptr;
-    s[1].v = v_b->d; s[1].mu0 = nullptr; s[1].mu = mu_b->d;
-    s[1].r = c->cg2_r->d; s[1].z = c->cg2_z->d; s[1].p = c->cg2_p->d; s[1].d = c->cg2_d->d;
-    s[1].denoiser = 0; s[1].relres = relres_b;
-    s[1].keep_resid = ex->ata_mu_b != nullptr;
-    if (cg_run(c, s, 2, tau, gam2, max_iter, ex->ride_x ? ex->ride_x->d : nullptr, ex->ride_out ? ex->ride_out->d : nullptr))
-        return 1;
-    if (ex->ata_mu_b) {   // Q mu_b = v_b - r_b  =>  A^T A mu_b = (v_b - r_b - gam2 mu_b) / tau
-        double* o = ex->ata_mu_b->d;
-        gvk::axpby(c->stream, o, 1.0 / tau, s[1].v, -1.0 / tau, s[1].r, c->M);
-        gvk::axpby(c->stream, o, 1.0, o, -gam2 / tau, s[1].mu, c->M);
-        KCHK(c);
-    }
-    cg_fill_stats(s[0], st_a);
-    cg_fill_stats(s[1], st_b);
-    if (st_a) { st_a->n_ax = (int)(c->cnt.n_ax - ax0); st_a->n_atx = (int)(c->cnt.n_atx - atx0); }
-    if (st_b) { st_b->n_ax = st_a ? st_a->n_ax : 0; st_b->n_atx = st_a ? st_a->n_atx : 0; }
-    return 0;
-}
-
-int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
-                 int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
-                 double* relres_b) {
-    return gv_cg_solve2x(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, st_a, st_b, relres_a, relres_b, nullptr);
-}
-
 // ---- denoiser side ------------------------------------------------------------------------------------------
 static int fill_prior(gv_ctx* c, gv_prior& pr, const double* probs, const double* vars, int L) {
     NEED(c, L >= 1 && L <= GV_LMAX, "prior: 1 <= L <= 32");
@@ -1375,286 +1058,6 @@ int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double*
     if (numb_people) HIPCHK(c, hipMemcpyAsync(numb_people, c->numb_p->d, n4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
-}
-
-// vamp::lmmse_multAAT (denoiserXXT.cpp:15-35): out = tau A A^T u + gam2 u on N-space device pointers
-static int lmmse_aat_device(gv_ctx* c, const double* u, double tau, double gam2, double* tmpM, double* out) {
-    if (atx_device(c, u, tmpM)) return 1;
-    if (ax_device(c, tmpM, out)) return 1;
-    gvk::axpby(c->stream, out, tau, out, gam2, u, c->npad);
-    KCHK(c);
-    return 0;
-}
-
-// vamp::CG_solverAAT (denoiserXXT.cpp:52-130): per-individual diagonal preconditioner, tolerance 1e-4, inner
-// products not all-reduced (N-vectors are replicated).  mu_start may be NULL (zeros).
-int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, double gam2, int max_iter,
-                    gv_vec* mu_out, gv_cg_stats* st, double* relres) {
-    NEED(c, v->space == GV_SPACE_N && mu_out->space == GV_SPACE_N, "gv_cg_solve_aat: N-space vectors required");
-    NEED(c, mu_out != v && mu_out != mu_start, "gv_cg_solve_aat: mu_out must not alias v or mu_start");
-    NEED(c, c->mave_p, "gv_cg_solve_aat: gv_people_stats must run first");
-    if (ensure_work(c)) return 1;
-    hipStream_t s = c->stream;
-    const int64_t n = c->npad;
-    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG}) vec_del(c, x); };
-    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
-        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
-    double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_out->d, *tmpM = c->cg_d->d;
-    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
-    int rc = 0, iters = 0, converged = 0, n_relres = 0;
-    double sc[2], rel_err = 0;
-#define AAT_TRY(expr) do { if ((expr) != 0) { rc = 1; goto done; } } while (0)
-#define AAT_HIP(expr) do { if ((expr) != hipSuccess) { rc = fail(c, "%s failed", #expr); goto done; } } while (0)
-    {
-        gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
-        if (mu_start) {
-            AAT_HIP(hipMemcpyAsync(mu, mu_start->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            AAT_TRY(lmmse_aat_device(c, mu, tau, gam2, tmpM, r));
-            gvk::axpby(s, r, 1.0, v->d, -1.0, r, n);                       // r = v - Q mu (:71-73)
-        } else {
-            gvk::fill(s, mu, n, 0.0);
-            AAT_HIP(hipMemcpyAsync(r, v->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        }
-        gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);   // z = r / diag (:76-77)
-        AAT_TRY(read_scalars(c, 2, sc));
-        double rz = sc[0];
-        const double* vv[1] = {v->d};
-        gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
-        double vn2;
-        AAT_TRY(read_scalars(c, 1, &vn2));
-        AAT_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        for (int i = 0; i < max_iter; i++) {
-            iters = i + 1;
-            AAT_TRY(lmmse_aat_device(c, p, tau, gam2, tmpM, d));              // d = Q p (:86)
-            const double* xs[1] = {d};
-            const double* ys[1] = {p};
-            gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
-            double dp;
-            AAT_TRY(read_scalars(c, 1, &dp));
-            const double alpha = rz / dp;                                     // :88
-            gvk::axpby(s, mu, 1.0, mu, alpha, p, n);                           // mu += alpha p (:90-93)
-            gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);   // :95-105
-            AAT_TRY(read_scalars(c, 2, sc));
-            const double beta = sc[0] / rz;                                    // :98,:107
-            rz = sc[0];
-            gvk::axpby(s, p, 1.0, z, beta, p, n);                              // :109-110
-            rel_err = sqrt(sc[1] / vn2);                                       // :113-114
-            if (relres) relres[i] = rel_err;
-            n_relres = i + 1;
-            if (rel_err < 1e-4) {                                              // :117,:120
-                converged = 1;
-                break;
-            }
-        }
-        AAT_HIP(hipGetLastError());
-    }
-done:
-#undef AAT_TRY
-#undef AAT_HIP
-    if (st) {
-        st->iters = iters;
-        st->converged = converged;
-        st->rel_res = rel_err;
-        st->onsager = 0;
-        st->n_ax = (int)(c->cnt.n_ax - ax0);
-        st->n_atx = (int)(c->cnt.n_atx - atx0);
-        st->n_relres = n_relres;
-    }
-    (void)hipStreamSynchronize(s);
-    cleanup();
-    return rc;
-}
-
-// ---- --use-XXT-denoiser 1: the N-space LMMSE solve and the M-space Onsager solve of one iteration on shared passes ------
-// System A (vamp::CG_solverAAT): Q_A u = tau A (A^T u) + gam2 u -- an ATx followed by an Ax.
-// System B (precondCG_solver, denoiser = 0, zero start): Q_B x = tau A^T (A x) + gam2 x -- an Ax followed by an ATx.
-// The two operators are made of the same two passes in opposite order, so run in step -- A half an application out of
-// phase with B -- every pass over the shard after the first carries one half-application of each (two-vector
-// kernels).  Per system the iterates, scalars, stopping rules and results are those of gv_cg_solve_aat / gv_cg_solve.
-// When A has finished its A^T mu_a (wanted for x2_hat = r2 + gamw A^T mu_a, denoiserXXT.cpp:47-49) is taken the same way.
-namespace {
-struct HalfOp {
-    bool pending = false;
-    int first = 0;          // kind of the first half: 0 = Ax, 1 = ATx
-    int stage = 0;          // 0: first half to do, 1: second half to do
-    bool one_half = false;  // only the first half is wanted (A^T mu_a)
-    const double* src = nullptr;
-    double* mid = nullptr;
-    double* dst = nullptr;
-    int kind() const { return stage == 0 ? first : 1 - first; }
-    const double* in() const { return stage == 0 ? src : mid; }
-    double* out() const { return (stage == 0 && !one_half) ? mid : dst; }
-};
-}  // namespace
-
-int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
-                     int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
-                     double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b) {
-    NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
-         "gv_cg_solve_aat2: system a lives in N-space");
-    NEED(c, v_b->space == GV_SPACE_M && mu_b->space == GV_SPACE_M && at_mu_a->space == GV_SPACE_M,
-         "gv_cg_solve_aat2: system b and A^T mu_a live in M-space");
-    NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && at_mu_a != mu_b && at_mu_a != v_b,
-         "gv_cg_solve_aat2: outputs must not alias inputs");
-    NEED(c, !aat_mu_a || (aat_mu_a->space == GV_SPACE_N && aat_mu_a != mu_a && aat_mu_a != v_a), "gv_cg_solve_aat2: aat_mu_a");
-    NEED(c, !ata_mu_b || (ata_mu_b->space == GV_SPACE_M && ata_mu_b != mu_b && ata_mu_b != v_b && ata_mu_b != at_mu_a),
-         "gv_cg_solve_aat2: ata_mu_b");
-    NEED(c, !(aat_mu_a || ata_mu_b) || tau != 0.0, "gv_cg_solve_aat2: the by-products need tau != 0");
-    NEED(c, c->mave_p, "gv_cg_solve_aat2: gv_people_stats must run first");
-    if (ensure_work(c)) return 1;
-    hipStream_t s = c->stream;
-    const int64_t n = c->npad, M = c->M;
-    const bool multi = is_multi(c);
-    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr, *MA = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) vec_del(c, x); };
-    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
-        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
-    if (vec_new(c, GV_SPACE_M, &MA)) { cleanup(); return 1; }
-    double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_a->d;
-    const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
-    int rc = 0;
-#define MIX_TRY(expr) do { if ((expr) != 0) { rc = 1; goto done; } } while (0)
-#define MIX_HIP(expr) do { if ((expr) != hipSuccess) { rc = fail(c, "%s failed", #expr); goto done; } } while (0)
-    // ---- system A state (denoiserXXT.cpp:52-130)
-    int a_iters = 0, a_conv = 0, a_nrel = 0, a_phase = 0;   // phase 0: waiting for Q mu0, 1: waiting for Q p, 2: A^T mu, 3: done
-    double a_rz = 0, a_vn2 = 0, a_rel = 0;
-    HalfOp ha, hb;
-    ha.first = 1;
-    hb.first = 0;
-    // ---- system B state: the M-space machinery of gv_cg_solve
-    CgSys sb;
-    const double diag_b = tau * (double)(c->N - 1) / (double)c->N + gam2;
-    {
-        sb.v = v_b->d; sb.mu0 = nullptr; sb.mu = mu_b->d;
-        sb.r = c->cg_r->d; sb.z = c->cg_z->d; sb.p = c->cg_p->d; sb.d = c->cg_d->d;
-        sb.denoiser = 0; sb.relres = relres_b;
-        sb.keep_resid = ata_mu_b != nullptr;
-        gvk::fill(s, sb.mu, M, 0.0);
-        MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
-        MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
-        if (max_iter <= 0) sb.active = false;
-    }
-    {
-        auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
-            double sc[2];
-            gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);
-            if (read_scalars(c, 2, sc)) return 1;
-            a_rz = sc[0];
-            const double* vv[1] = {v_a->d};
-            gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
-            if (read_scalars(c, 1, &a_vn2)) return 1;
-            if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
-            return 0;
-        };
-        auto a_post = [&](const double* src, double* dst) {   // request Q_A src -> dst
-            ha.pending = true; ha.stage = 0; ha.one_half = false; ha.src = src; ha.mid = MA->d; ha.dst = dst;
-        };
-        auto a_finish = [&]() {                                // the solve is over: A^T mu_a is the last request
-            a_phase = 2;
-            ha.pending = true; ha.stage = 0; ha.one_half = true; ha.src = mu; ha.mid = nullptr; ha.dst = at_mu_a->d;
-        };
-        gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
-        if (mu_start_a) {
-            MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            a_phase = 0;
-            a_post(mu, r);
-        } else {
-            gvk::fill(s, mu, n, 0.0);
-            MIX_HIP(hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            MIX_TRY(a_init_scalars());
-            a_phase = 1;
-            if (max_iter > 0) a_post(p, d); else a_finish();
-        }
-        auto b_post = [&]() {
-            hb.pending = sb.active;
-            hb.stage = 0; hb.one_half = false; hb.src = sb.req; hb.mid = c->w_n->d; hb.dst = sb.res;
-        };
-        b_post();
-
-        for (;;) {
-            HalfOp* todo[2];
-            int nt = 0;
-            if (ha.pending && hb.pending) {
-                if (ha.kind() == hb.kind()) { todo[nt++] = &ha; todo[nt++] = &hb; }
-                else todo[nt++] = &ha;             // out of phase: one single pass puts them in phase
-            } else if (ha.pending) todo[nt++] = &ha;
-            else if (hb.pending) todo[nt++] = &hb;
-            else break;
-            // system b's second half is the ATx of lmmse_mult: its tau * . + gam2 * req epilogue is fused as in gv_cg_solve
-            auto addx = [&](const HalfOp* h) -> const double* { return (h == &hb && h->stage == 1) ? sb.req : nullptr; };
-            if (nt == 2) {
-                if (todo[0]->kind() == 0) MIX_TRY(ax2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
-                else MIX_TRY(atx2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out(), addx(todo[0]),
-                                         addx(todo[1]), tau, gam2));
-            } else {
-                if (todo[0]->kind() == 0) MIX_TRY(ax_device(c, todo[0]->in(), todo[0]->out()));
-                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out(), addx(todo[0]), tau, gam2));
-            }
-            for (int k = 0; k < nt; k++) {
-                HalfOp* h = todo[k];
-                if (h->stage == 0 && !h->one_half) { h->stage = 1; continue; }     // second half still to come
-                h->pending = false;
-                if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
-                    sb.wslot = c->w_n->d;
-                    CgSys* one[1] = {&sb};
-                    MIX_TRY(cg_consume_all(c, one, 1, gam2, diag_b, max_iter, multi));
-                    b_post();
-                    continue;
-                }
-                if (a_phase == 2) { a_phase = 3; continue; }                        // A^T mu_a done
-                gvk::axpby(s, ha.dst, tau, ha.dst, gam2, ha.src, n);                // Q_A src complete
-                if (a_phase == 0) {                                                // r = v - Q mu0 (:71-73)
-                    gvk::axpby(s, r, 1.0, v_a->d, -1.0, r, n);
-                    MIX_TRY(a_init_scalars());
-                    a_phase = 1;
-                    if (max_iter > 0) a_post(p, d); else a_finish();
-                    continue;
-                }
-                const int i = a_iters++;                                           // one CG step (:86-120)
-                const double* xs[1] = {d};
-                const double* ys[1] = {p};
-                gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
-                double dp, sc[2];
-                MIX_TRY(read_scalars(c, 1, &dp));
-                const double alpha = a_rz / dp;
-                gvk::axpby(s, mu, 1.0, mu, alpha, p, n);
-                gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);
-                MIX_TRY(read_scalars(c, 2, sc));
-                const double beta = sc[0] / a_rz;
-                a_rz = sc[0];
-                gvk::axpby(s, p, 1.0, z, beta, p, n);
-                a_rel = sqrt(sc[1] / a_vn2);
-                if (relres_a) relres_a[i] = a_rel;
-                a_nrel = i + 1;
-                if (a_rel < 1e-4) { a_conv = 1; a_finish(); }
-                else if (a_iters >= max_iter) a_finish();
-                else a_post(p, d);
-            }
-        }
-        if (aat_mu_a) {   // Q_A mu_a = v_a - r  =>  A A^T mu_a = (v_a - r - gam2 mu_a) / tau
-            gvk::axpby(s, aat_mu_a->d, 1.0 / tau, v_a->d, -1.0 / tau, r, n);
-            gvk::axpby(s, aat_mu_a->d, 1.0, aat_mu_a->d, -gam2 / tau, mu, n);
-        }
-        if (ata_mu_b) {
-            gvk::axpby(s, ata_mu_b->d, 1.0 / tau, sb.v, -1.0 / tau, sb.r, M);
-            gvk::axpby(s, ata_mu_b->d, 1.0, ata_mu_b->d, -gam2 / tau, sb.mu, M);
-        }
-        MIX_HIP(hipGetLastError());
-    }
-done:
-#undef MIX_TRY
-#undef MIX_HIP
-    if (st_a) {
-        st_a->iters = a_iters; st_a->converged = a_conv; st_a->rel_res = a_rel; st_a->onsager = 0; st_a->n_relres = a_nrel;
-        st_a->n_ax = (int)(c->cnt.n_ax - ax0);
-        st_a->n_atx = (int)(c->cnt.n_atx - atx0);
-    }
-    cg_fill_stats(sb, st_b);
-    if (st_b) { st_b->n_ax = (int)(c->cnt.n_ax - ax0); st_b->n_atx = (int)(c->cnt.n_atx - atx0); }
-    (void)hipStreamSynchronize(s);
-    cleanup();
-    return rc;
 }
 
 // ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------

@@ -141,3 +141,61 @@ void pvals_test(hipStream_t s, const uint32_t* cnt, const double* mave, const do
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n);
 void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink);
 }  // namespace gvk
+
+// ---- internals shared by the translation units of the C ABI (gv_capi.hip, gv_solvers.hip) ------------------------------
+namespace gvi {
+int fail(gv_ctx* c, const char* fmt, ...);
+int vec_new(gv_ctx* c, int space, gv_vec** out);
+void vec_del(gv_ctx* c, gv_vec* v);
+int ensure_w2(gv_ctx* c);       // the second N-space scratch vector (behind w_n in one allocation)
+int ensure_work(gv_ctx* c);     // scratch vectors of the matvecs and the CG
+int read_scalars(gv_ctx* c, int K, double* out);                            // red_out[0..K) -> host (mailbox or copy)
+int read_scalars_global(gv_ctx* c, int K, double* out, bool multi);         // the same, summed over the ranks first
+int allreduce_scalars(gv_ctx* c, double* buf, int K);                       // MPI_Allreduce(SUM) of K host scalars
+bool is_multi(const gv_ctx* c);
+int comm_allreduce(gv_ctx* c, double* dev, size_t n);
+int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes);
+int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes);
+// data::Ax / data::ATx (and their two-vector forms) on device pointers, in the kernel family of the context
+int ax_device(gv_ctx* c, const double* x, double* out);
+int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0);
+int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb);
+int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
+                const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
+int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out);
+
+struct Timer {
+    gv_ctx* c;
+    double* acc;
+    bool on;
+    Timer(gv_ctx* c_, double* acc_) : c(c_), acc(acc_), on(c_->timing == 1) {
+        if (on) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    void stop() {
+        if (!on) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        *acc += ms;
+        on = false;
+    }
+};
+}  // namespace gvi
+
+#define HIPCHK(c, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCHK(c, call)                                                                     \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(c) HIPCHK(c, hipGetLastError())
+#define NEED(c, cond, msg)                 \
+    do {                                   \
+        if (!(cond)) return fail(c, msg);  \
+    } while (0)
+
