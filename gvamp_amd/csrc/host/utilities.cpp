@@ -42,7 +42,7 @@ std::vector<double> divide_work(int Mt) {
     return {(double)M, (double)S, (double)Mm};
 }
 
-std::vector<double> simulate(int M, std::vector<double> eta, std::vector<double> pi, long unsigned int seed) {
+std::vector<double> simulate(int M, const std::vector<double>& eta, const std::vector<double>& pi, unsigned long seed) {
     std::vector<double> signal(M, 0.0);
     const size_t K = eta.size();
     for (int i = 0; i < M; i++) {
@@ -85,14 +85,14 @@ void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int
     }
 }
 
-double noise_prec_calc(double SNR, std::vector<double> vars, std::vector<double> probs, int Mt, int N) {
+double noise_prec_calc(double SNR, const std::vector<double>& vars, const std::vector<double>& probs, int Mt, int N) {
     (void)N;
     double expe = 0;
     for (size_t i = 0; i < vars.size(); i++) expe += vars[i] * probs[i];
     return SNR / Mt / expe;
 }
 
-std::vector<double> read_vec_from_file(std::string filename, int M, int S) {
+std::vector<double> read_vec_from_file(const std::string& filename, int M, int S) {
     std::vector<double> v;
     std::ifstream in(filename);
     double value;
@@ -101,12 +101,12 @@ std::vector<double> read_vec_from_file(std::string filename, int M, int S) {
     return v;
 }
 
-void store_vec_to_file(std::string filepath, std::vector<double> vec) {
+void store_vec_to_file(const std::string& filepath, const std::vector<double>& vec) {
     std::ofstream file(filepath);
     for (double x : vec) file << x << std::endl;   // default ostream precision, one value per line
 }
 
-void mpi_store_vec_to_file(std::string filepath_out, std::vector<double> vec, int S, int M) {
+void mpi_store_vec_to_file(const std::string& filepath_out, const std::vector<double>& vec, int S, int M) {
     int fd = open(filepath_out.c_str(), O_CREAT | O_WRONLY, 0644);
     if (fd < 0) return;
     ssize_t w = pwrite(fd, vec.data(), sizeof(double) * (size_t)M, (off_t)S * (off_t)sizeof(double));
@@ -114,7 +114,7 @@ void mpi_store_vec_to_file(std::string filepath_out, std::vector<double> vec, in
     close(fd);
 }
 
-std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S) {
+std::vector<double> mpi_read_vec_from_file(const std::string& filename, int M, int S) {
     std::vector<double> vec(M, 0.0);
     int fd = open(filename.c_str(), O_RDONLY);
     if (fd < 0) return vec;
@@ -124,15 +124,15 @@ std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S) {
     return vec;
 }
 
-double inner_prod(std::vector<double> const& u, std::vector<double> const& v, int sync) {
+double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync) {
     (void)sync;
     double acc = 0;
     for (size_t i = 0; i < u.size(); i++) acc += u[i] * v[i];
     return acc;
 }
-double l2_norm2(std::vector<double> const& u, int sync) { return inner_prod(u, u, sync); }
+double l2_norm2(const std::vector<double>& u, int sync) { return inner_prod(u, u, sync); }
 
-double calc_stdev(std::vector<double> vec, int sync) {
+double calc_stdev(const std::vector<double>& vec, int sync) {
     (void)sync;
     const double sum = std::accumulate(vec.begin(), vec.end(), 0.0);
     const double sq = std::inner_product(vec.begin(), vec.end(), vec.begin(), 0.0);

@@ -15,17 +15,17 @@ void gv_host_set_quiet(bool quiet);   // silence the informational prints of the
 std::vector<double> divide_work(int Mt);
 void divide_work(int Mt, int nranks, int rank, int* M, int* S, int* Mm);
 // utilities.cpp:48-88 -- spike-and-slab draw per marker from mt19937{seed + i}
-std::vector<double> simulate(int M, std::vector<double> eta, std::vector<double> pi, long unsigned int seed);
+std::vector<double> simulate(int M, const std::vector<double>& eta, const std::vector<double>& pi, unsigned long seed);
 // utilities.cpp:91-140 -- default 23-component prior when neither --probs nor --vars is given
 void initialize_prior(std::vector<double>& probs, std::vector<double>& vars, int N, int Mt, int rank);
-double noise_prec_calc(double SNR, std::vector<double> vars, std::vector<double> probs, int Mt, int N);
-std::vector<double> read_vec_from_file(std::string filename, int M, int S);          // utilities.cpp:156-174 (text)
-void store_vec_to_file(std::string filepath, std::vector<double> vec);                // utilities.cpp:178-187 (text)
-void mpi_store_vec_to_file(std::string filepath_out, std::vector<double> vec, int S, int M);   // :293-301 (binary at S*8)
-std::vector<double> mpi_read_vec_from_file(std::string filename, int M, int S);       // :303-319
-double inner_prod(std::vector<double> const& u, std::vector<double> const& v, int sync);   // host vectors, sync ignored
-double l2_norm2(std::vector<double> const& u, int sync);
-double calc_stdev(std::vector<double> vec, int sync = 0);
+double noise_prec_calc(double SNR, const std::vector<double>& vars, const std::vector<double>& probs, int Mt, int N);
+std::vector<double> read_vec_from_file(const std::string& filename, int M, int S);          // utilities.cpp:156-174 (text)
+void store_vec_to_file(const std::string& filepath, const std::vector<double>& vec);                // utilities.cpp:178-187 (text)
+void mpi_store_vec_to_file(const std::string& filepath_out, const std::vector<double>& vec, int S, int M);   // :293-301 (binary at S*8)
+std::vector<double> mpi_read_vec_from_file(const std::string& filename, int M, int S);       // :303-319
+double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync);   // host vectors, sync ignored
+double l2_norm2(const std::vector<double>& u, int sync);
+double calc_stdev(const std::vector<double>& vec, int sync = 0);
 double normal_cdf(double value);                                                        // utilities.cpp:336-339
 double erfcx(double x);                                                                // utilities.cpp:345-409: exp(x^2) erfc(x)
 // A x = b for a dense n x n system (row-major) by LU with partial pivoting -- what the reference takes from Boost uBLAS
