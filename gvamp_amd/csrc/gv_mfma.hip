@@ -400,8 +400,8 @@ __device__ __forceinline__ void wg_barrier_lds() {
 //       where the range crosses into the next quad.  With a grid of exactly the resident workgroups (768 = 256 CUs x 3)
 //       every workgroup gets the same number of cells and the launch has no ragged last round -- worth 10-17 % when
 //       ceil(nrg / 4) * ksplit is just above a multiple of 768 for every admissible ksplit (e.g. N = 50k: 782 quads).
-// partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1, 4) or 4
-// (MODE 2, 3: planes 2v, 2v+1 belong to vector v); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
+// partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1, 3, 4) or 4
+// (MODE 2: planes 2v, 2v+1 belong to vector v; MODE 3: plane v is vector v, its two products already added); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
 // workgroups that touch a quad are consecutive).  pieces_of() below is the count the epilogue kernels sum over.
 __device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL) {
     if (skL <= 0) return ksplit;
@@ -561,7 +561,21 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     if (!live) continue;
     const int64_t rows_p = nrg * 64;
     const int cd = c & 7;
-    if (MODE == 2 || MODE == 3) {
+    if (MODE == 3) {
+        // vector v = c >> 3 needs r'.c_v + miss.e_v only: both sit in the same lanes, so one plane per vector is stored
+        // (|sum| <= 512 K per digit, the bound gv_set_dims sizes the K-segments for)
+        const int pv = c >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+                partial[(((int64_t)ks * 2 + pv) * rows_p + row) * 8 + cd] = accX[i][reg] + accY[i][reg];
+            }
+        }
+        continue;
+    }
+    if (MODE == 2) {
         const int pv = (c >> 3) * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -685,7 +699,9 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
                                                 int64_t nkb, int64_t skL) {
-    const int v = blockIdx.y, p0 = 2 * v;       // vector v owns planes 2v (r'.c) and 2v+1 (miss.e)
+    // one vector (MODE 1, 4; ppk = 2): planes 0 (r'.c) and 1 (miss.e).  Two vectors (MODE 3; ppk = 2): the kernel has
+    // already added the two, vector v owns plane v.
+    const int v = blockIdx.y, npl = gridDim.y == 2 ? 1 : 2, p0 = gridDim.y == 2 ? v : 0;
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
     ksplit = pieces_of(n, ksplit, nkb, skL);
     for (int ks = 0; ks < ksplit; ks++) {
-        for (int plane = 0; plane < 2; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
+        for (int plane = 0; plane < npl; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
             const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + plane) * rows_p + n) * 8);
             int4 x0 = px[0], x1 = px[1];
             sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
@@ -867,7 +883,7 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
     launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[1]);
     FinAx f{{outa, outb}};
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 2), dim3(256), 0, s, pl.partial, pl.dn[1].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 4, pl.nkb_n, pl.dn[1].skL);
+                       pl.scal, mask2, post, f, 2, pl.nkb_n, pl.dn[1].skL);
 }
 
 }  // namespace gvm
