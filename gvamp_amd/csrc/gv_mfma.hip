@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_quant(QuantArgs a, int64_t n, int64_t n
 //   MODE 0 (ATx):  digit block = digits(p), 8 columns (2 KiB); lanes c >= 8 alias column c-8 (their results are never
 //                  stored).  result rows: X = accX[:, 0:8], Y = accY[:, 0:8].
 //   MODE 1 (Ax):   digit block = [digits(c) | digits(e)], 16 columns (4 KiB).  r'.c comes out in accX[:, 0:8] and
-//                  miss.e in accY[:, 8:16]; both are stored as two "planes" and added (exactly) by k_fin_ax.
+//                  miss.e in accY[:, 8:16]; their sum is stored as one plane per piece.
 //   MODE 2 (two N-vectors, ATx / p-value sums): [digits(p_a) | digits(p_b)]; columns 0..7 / 8..15 = vector a / b.
 //   MODE 3 (two M-vectors, Ax): the r' plane multiplies dig0 = [c_a | c_b], the miss plane dig1 = [e_a | e_b] (8 KiB):
 //                  vector a = accX[:, 0:8] + accY[:, 0:8], vector b = accX[:, 8:16] + accY[:, 8:16].
@@ -400,8 +400,8 @@ __device__ __forceinline__ void wg_barrier_lds() {
 //       where the range crosses into the next quad.  With a grid of exactly the resident workgroups (768 = 256 CUs x 3)
 //       every workgroup gets the same number of cells and the launch has no ragged last round -- worth 10-17 % when
 //       ceil(nrg / 4) * ksplit is just above a multiple of 768 for every admissible ksplit (e.g. N = 50k: 782 quads).
-// partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg, P = 2 (MODE 0, 1, 3, 4) or 4
-// (MODE 2: planes 2v, 2v+1 belong to vector v; MODE 3: plane v is vector v, its two products already added); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
+// partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg; P = 2 (MODE 0: sum r' p, sum miss p),
+// 4 (MODE 2: planes 2v, 2v+1 belong to vector v), 1 (MODE 1, 4: the two products already added) or 2 (MODE 3: plane v = vector v); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
 // workgroups that touch a quad are consecutive).  pieces_of() below is the count the epilogue kernels sum over.
 __device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL) {
     if (skL <= 0) return ksplit;
@@ -588,15 +588,30 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         }
         continue;
     }
-    const bool stX = c < 8;
-    const bool stY = (MODE == 0) ? (c < 8) : (c >= 8);
+    if (MODE == 1 || MODE == 4) {
+        // r'.c sits in lanes c < 8 of accX, miss.e in lanes c >= 8 of accY: bring the latter 8 lanes down within each row of
+        // 16 (DPP row_shl:8) and store their sum as the one plane of this piece (|sum| <= 512 K per digit, as for MODE 3)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
+                const int ye = __builtin_amdgcn_mov_dpp(accY[i][reg], 0x108 /* row_shl:8 */, 0xf, 0xf, true);
+                if (c < 8) partial[((int64_t)ks * rows_p + row) * 8 + cd] = accX[i][reg] + ye;
+            }
+        }
+        continue;
+    }
+    // MODE 0: sum r' p and sum miss p are needed separately (the row's mean multiplies the second), two planes
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int64_t row = rg * 64 + 16 * i + 4 * g + reg;
-            if (stX) partial[(((int64_t)ks * 2 + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
-            if (stY) partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
+            if (c < 8) {
+                partial[(((int64_t)ks * 2 + 0) * rows_p + row) * 8 + cd] = accX[i][reg];
+                partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[i][reg];
+            }
         }
     }
   } while (SK && u < uend);
@@ -699,9 +714,9 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
                                                 int64_t nkb, int64_t skL) {
-    // one vector (MODE 1, 4; ppk = 2): planes 0 (r'.c) and 1 (miss.e).  Two vectors (MODE 3; ppk = 2): the kernel has
-    // already added the two, vector v owns plane v.
-    const int v = blockIdx.y, npl = gridDim.y == 2 ? 1 : 2, p0 = gridDim.y == 2 ? v : 0;
+    // the streaming kernel has already added the r'.c and miss.e products: one plane per vector and piece, ppk = number of
+    // vectors of the pass (1: MODE 1, 4; 2: MODE 3)
+    const int v = blockIdx.y;
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -714,11 +729,9 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
     ksplit = pieces_of(n, ksplit, nkb, skL);
     for (int ks = 0; ks < ksplit; ks++) {
-        for (int plane = 0; plane < npl; plane++) {   // r'.c digits + miss.e digits (same fixed-point scale)
-            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + plane) * rows_p + n) * 8);
-            int4 x0 = px[0], x1 = px[1];
-            sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
-        }
+        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
+        int4 x0 = px[0], x1 = px[1];
+        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
     }
     long long xh, xl;
     combine(sx, xh, xl);
@@ -846,7 +859,7 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
     launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
     FinAx f{{out, nullptr}};
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 2, pl.nkb_n, pl.dn[0].skL);
+                       pl.scal, mask2, post, f, 1, pl.nkb_n, pl.dn[0].skL);
 }
 
 // one of the three per-individual sums of compute_people_statistics from stripes_n (k_prep_people): out[n] = mask * sum
@@ -865,7 +878,7 @@ void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, cons
     else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
     FinAx f{{out, nullptr}};
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, 1.0, f, 2, pl.nkb_n, pl.dn[0].skL);
+                       pl.scal, mask2, 1.0, f, 1, pl.nkb_n, pl.dn[0].skL);
 }
 
 // data::Ax of TWO M-vectors in one pass over stripes_n: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
