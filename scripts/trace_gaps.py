@@ -1,5 +1,5 @@
 """Timeline summary of a rocprofv3 kernel trace: from the first to the last streaming-kernel launch, the time inside each
-kernel and the idle time between kernels (development tool).   python scripts/trace_gaps.py <kernel_trace.csv> [skip]"""
+kernel and the idle time between kernels (development tool).   python scripts/trace_gaps.py <kernel_trace.csv> [skip | -last]"""
 import csv
 import re
 import collections
@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # streaming launches to skip (autotune, sim_phen, iteration 1)
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 idx = [i for i, e in enumerate(ev) if "k_mfma_matvec" in e[2]]
-lo, hi = idx[skip], idx[-1]
+lo, hi = idx[skip if skip >= 0 else max(0, len(idx) + skip)], idx[-1]     # skip < 0: only the last -skip streaming launches
 seg = ev[lo:hi + 1]
 span = seg[-1][1] - seg[0][0]
 by = collections.defaultdict(lambda: [0, 0])
