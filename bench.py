@@ -88,6 +88,16 @@ def cpu_baseline(N, seed, want_markers, device):
             "cpu_model": _cpu_model()}
 
 
+def kernel_sources_sha256():
+    """identity of the streaming-kernel sources a PMC profile belongs to (scripts/pmc_summary.py stamps the same hash)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gv_mfma.hip", "gv_mfma.h"):
+        with open(os.path.join(ROOT, "gvamp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -98,16 +108,59 @@ def _cpu_model():
     return "unknown"
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with no launcher: start the N per-GPU ranks ourselves, as plain child processes, BEFORE
+    anything in this process touches the GPU (torch.cuda.device_count() does not initialise it on this image), and leave
+    with the first non-zero exit code of a rank.  Rank 0 inherits stdout: the one JSON line is its."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print("bench.py: --gpus %d but this box has %d GPU(s); refusing to report a smaller job under that name"
+              % (a.gpus, have), file=sys.stderr)
+        sys.exit(3)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, set(range(a.gpus))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
+        # never downgrade: a harness that asked for N GPUs must not get another job's number under that name
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
-                  % (a.gpus, world, a.gpus), file=sys.stderr)
-        a.gpus = world
+            print("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d; start it as `python -m torch.distributed.run "
+                  "--nproc-per-node %d ... bench.py --gpus %d`, or bare (it then spawns its own ranks)"
+                  % (a.gpus, world, a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
 
     # torch first: it brings its own ROCm runtime libraries, and libgvamp.so then binds to the same loaded
     # libamdhip64 / librccl (same SONAMEs) -- the other order leaves torch without a device.
@@ -160,6 +213,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    sh.synchronize()
+    tune_s, tune_src = sh.tune_info()       # the first matvec picked the work decompositions (measured, or from the cache)
     sh.set_timing(2)
     sh.counters(reset=True)
     sh.synchronize()
@@ -189,14 +244,19 @@ def main():
     atx_gbps = shard_bytes / (ms_atx * 1e-3) / 1e9 if ms_atx > 0 else 0.0
     kname = "k_mfma_matvec<1, SK> (Ax)" if a.mode == 1 else "k_ax_f64"
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes of this same command (counters cannot be
-    # read from inside the process); the committed summary is quoted when it was taken on the same configuration.
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        if (pm["N"], pm["Mt"], pm["n_gpus"], pm["kernel_mode"]) == (N, Mt, world, a.mode):
-            traffic = pm["ax"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # read from inside the process).  The newest committed summary is quoted ONLY when it was taken on this configuration
+    # AND on these very kernel sources (sha256 of gv_mfma.hip recorded by scripts/pmc_summary.py); otherwise null.
+    traffic, traffic_src = None, None
+    ksha = kernel_sources_sha256()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if (pm["N"], pm["Mt"], pm["n_gpus"], pm["kernel_mode"]) == (N, Mt, world, a.mode) and \
+                    pm.get("kernel_sources_sha256") == ksha:
+                traffic, traffic_src = pm["ax"]["hbm_bytes"], "profiles/" + name
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     out = {
         "metric": "genotype_matvec_GBps", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
@@ -206,9 +266,9 @@ def main():
         "config": {"workload": "N=%d x Mt=%d 2-bit genotype matrix, step = lmmse_mult = Ax + N-vector all-reduce + ATx "
                                "(vamp.cpp:1074-1118)" % (N, Mt),
                    "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
-                   "ingest_s": round(t_ingest, 2)},
+                   "ingest_s": round(t_ingest, 2), "tune_s": round(tune_s, 3), "tune_source": tune_src},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic,
+                     "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4),
                      # context ("also report vs measured copy bandwidth"): what plain streaming kernels reach
                      # on this box, measured now -- a read-only stream over the same resident stripes, and a copy
@@ -217,6 +277,19 @@ def main():
         "kernels": {"ax": {"avg_ms": round(ms_ax, 4), "GBps": round(ax_gbps, 1), "launches": cnt["n_ax_kernel"]},
                     "atx": {"avg_ms": round(ms_atx, 4), "GBps": round(atx_gbps, 1), "launches": cnt["n_atx_kernel"]}},
     }
+    # what each rank ran: shard, picked decompositions, kernel and exchange times of the timed region (HIP events)
+    mine = {"rank": rank, "markers": M, "first_marker": S, "ms_ax_kernel": round(ms_ax, 4), "ms_atx_kernel": round(ms_atx, 4),
+            "ms_allreduce_per_ax": round(cnt["ms_allreduce"] / max(cnt["n_allreduce"], 1), 4), "decomposition": sh.decomp()}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if world > 1 or force_dist:
+        out["multi_gpu"] = {"rccl_nranks": sh.L.gv_comm_size(sh.h), "exchange": "ncclAllReduce(double, sum, %d) per Ax on the "
+                            "context stream (data.cpp:928/:995)" % (4 * ((N + 255) // 256) * 64),
+                            "ms_allreduce_per_ax": max(r["ms_allreduce_per_ax"] for r in per_rank), "per_rank": per_rank}
+    else:
+        out["decomposition"] = mine["decomposition"]
     # ---- second half of the metric: VAMP iterations/s (vamp::infere of the host C++ mirror on the same shard) ----
     if a.vamp_iterations > 0:
         from gvamp_amd import hostapi
@@ -251,6 +324,11 @@ def main():
             }
 
         r, out["vamp"] = vamp_leg(a.fuse_solves)
+        # what a user waits for: shard ingest (synthetic here: generated on the device) + picking the decompositions (0 when an
+        # earlier run on this shape left them in the cache) + every VAMP iteration, the cold first one included
+        out["vamp"]["time_to_solution_s"] = round(t_ingest + tune_s + out["vamp"]["wall_s_all_iterations"], 3)
+        out["vamp"]["time_to_solution_parts"] = {"ingest_s": round(t_ingest, 3), "tune_s": round(tune_s, 3), "tune_source": tune_src,
+                                                 "iterations_s": out["vamp"]["wall_s_all_iterations"]}
         out["vamp"]["config"] = (
             "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, %d iterations; "
             "iters/s over iterations 2.., file output off; n_ax / n_atx = explicit vector products, n_*_pass = passes over "

@@ -21,8 +21,8 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
-    "gv_get_counters", "gv_reset_counters", "gv_copy_bandwidth", "gv_read_bandwidth",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
 
@@ -43,7 +43,14 @@ class Counters(C.Structure):
     _fields_ = [("n_ax", C.c_int64), ("n_atx", C.c_int64), ("ms_ax", C.c_double), ("ms_atx", C.c_double),
                 ("ms_allreduce", C.c_double), ("n_ax_kernel", C.c_int64), ("n_atx_kernel", C.c_int64),
                 ("ms_ax_kernel", C.c_double), ("ms_atx_kernel", C.c_double), ("n_ax_pass", C.c_int64),
-                ("n_atx_pass", C.c_int64)]
+                ("n_atx_pass", C.c_int64), ("n_allreduce", C.c_int64)]
+
+
+class DecompInfo(C.Structure):
+    _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 
 def load():
@@ -115,11 +122,14 @@ def load():
     L.gv_comm_unique_id.argtypes = [C.c_void_p]
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.gv_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
     L.gv_comm_rank.argtypes = [vp]
     L.gv_comm_size.argtypes = [vp]
     L.gv_set_timing.argtypes = [vp, C.c_int]
     L.gv_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.gv_reset_counters.argtypes = [vp]
+    L.gv_get_decomp.argtypes = [vp, C.POINTER(DecompInfo)]
+    L.gv_tune_info.argtypes = [vp, dp, C.POINTER(C.c_int)]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.gv_read_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     _LIB = L
@@ -403,6 +413,20 @@ class Shard:
     def comm_init_local(self, group, nranks, rank):
         self._ck(self.L.gv_comm_init_local(self.h, group, nranks, rank))
 
+    def comm_init_callback(self, nranks, rank, allreduce):
+        """gv_comm_init_callback: `allreduce(a)` sums the float64 numpy array `a` in place over the ranks (e.g.
+        torch.distributed.all_reduce over gloo on torch.from_numpy(a))."""
+        def _cb(_user, buf, n):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+                return 0
+            except Exception:          # no exception may cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb_keep = ALLREDUCE_FN(_cb)          # keep the trampoline alive as long as the context
+        self._ck(self.L.gv_comm_init_callback(self.h, nranks, rank, self._cb_keep, None))
+
     def set_timing(self, on):
         self._ck(self.L.gv_set_timing(self.h, int(on)))
 
@@ -413,7 +437,23 @@ class Shard:
             self._ck(self.L.gv_reset_counters(self.h))
         return dict(n_ax=c.n_ax, n_atx=c.n_atx, ms_ax=c.ms_ax, ms_atx=c.ms_atx, ms_allreduce=c.ms_allreduce,
                     n_ax_kernel=c.n_ax_kernel, n_atx_kernel=c.n_atx_kernel, ms_ax_kernel=c.ms_ax_kernel,
-                    ms_atx_kernel=c.ms_atx_kernel, n_ax_pass=c.n_ax_pass, n_atx_pass=c.n_atx_pass)
+                    ms_atx_kernel=c.ms_atx_kernel, n_ax_pass=c.n_ax_pass, n_atx_pass=c.n_atx_pass,
+                    n_allreduce=c.n_allreduce)
+
+    def tune_info(self):
+        """(seconds spent picking the decompositions, source: 'pending' / 'model' / 'measured' / 'cache' / 'fixed')"""
+        sec, src = C.c_double(), C.c_int()
+        self._ck(self.L.gv_tune_info(self.h, C.byref(sec), C.byref(src)))
+        return sec.value, {-1: "pending", 0: "model", 1: "measured", 2: "cache", 3: "fixed"}[src.value]
+
+    def decomp(self):
+        """work decomposition per streaming-kernel class (gv_get_decomp)"""
+        d = (DecompInfo * 4)()
+        self._ck(self.L.gv_get_decomp(self.h, d))
+        names = ("atx", "atx2", "ax", "ax2")
+        return {n: ({"balanced_cells": int(x.balanced_cells)} if x.balanced_cells > 0 else
+                    {"ks": x.ks, "taper": round(float(x.taper), 2)}) | {"prio": x.prio, "tuned": bool(x.tuned)}
+                for n, x in zip(names, d)}
 
     def synchronize(self):
         self._ck(self.L.gv_synchronize(self.h))

@@ -11,6 +11,10 @@
 #include <mutex>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "gv_internal.h"
 
 namespace gvi {
@@ -75,17 +79,29 @@ int ensure_w2(gv_ctx* c) {
     return 0;
 }
 int ensure_work(gv_ctx* c) {
-    if (!c->w_n) {
-        if (vec_new(c, GV_SPACE_N, &c->w_n)) return 1;
-        (void)hipFree(c->w_n->d);                              // twice the room: w_n2 lives in the second half
-        c->w_n->d = nullptr;
-        HIPCHK(c, hipMalloc(&c->w_n->d, sizeof(double) * 2 * c->npad));
-        HIPCHK(c, hipMemsetAsync(c->w_n->d, 0, sizeof(double) * 2 * c->npad, c->stream));
-        if (vec_new(c, GV_SPACE_M, &c->cg_r)) return 1;
-        if (vec_new(c, GV_SPACE_M, &c->cg_z)) return 1;
-        if (vec_new(c, GV_SPACE_M, &c->cg_p)) return 1;
-        if (vec_new(c, GV_SPACE_M, &c->cg_d)) return 1;
+    if (c->w_n && c->cg_d) return 0;
+    // all or nothing: a half-built set must never be published (the entry points test w_n / cg_d and then use all five)
+    gv_vec* made[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto undo = [&]() {
+        for (gv_vec* v : made) vec_del(c, v);
+        c->w_n = c->cg_r = c->cg_z = c->cg_p = c->cg_d = nullptr;
+        return 1;
+    };
+    if (c->w_n) { vec_del(c, c->w_n); c->w_n = nullptr; }
+    if (vec_new(c, GV_SPACE_N, &made[0])) return undo();
+    double* both = nullptr;                                    // twice the room: w_n2 lives in the second half
+    if (hipMalloc(&both, sizeof(double) * 2 * c->npad) != hipSuccess ||
+        hipMemsetAsync(both, 0, sizeof(double) * 2 * c->npad, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        if (both) (void)hipFree(both);
+        undo();
+        return fail(c, "ensure_work: no room for the N-space scratch vectors (%lld doubles)", (long long)(2 * c->npad));
     }
+    (void)hipFree(made[0]->d);
+    made[0]->d = both;
+    for (int k = 1; k < 5; k++)
+        if (vec_new(c, GV_SPACE_M, &made[k])) return undo();
+    c->w_n = made[0]; c->cg_r = made[1]; c->cg_z = made[2]; c->cg_p = made[3]; c->cg_d = made[4];
     return 0;
 }
 
@@ -163,13 +179,22 @@ struct LocalGroup {
 std::mutex g_groups_mu;
 std::map<int, std::shared_ptr<LocalGroup>> g_groups;
 
-bool is_multi(const gv_ctx* c) { return c->nranks > 1 && (c->comm || c->local); }
+bool is_multi(const gv_ctx* c) { return c->nranks > 1 && (c->comm || c->local || c->cb); }
 
 // SUM all-reduce of n doubles living on the device, on the context's stream
 int comm_allreduce(gv_ctx* c, double* dev, size_t n) {
     if (!is_multi(c)) return 0;
     if (c->comm) {
         NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+        return 0;
+    }
+    if (c->cb) {   // caller's transport (gv_comm_init_callback): host round trip
+        c->local_buf.resize(n);
+        HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->cb(c->cb_user, c->local_buf.data(), n) != 0) return fail(c, "comm_allreduce: the all-reduce callback failed");
+        HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
     LocalGroup* g = static_cast<LocalGroup*>(c->local);
@@ -229,7 +254,8 @@ void ev_resolve(gv_ctx* c) {
         float ms = 0;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             if (r.kind == 0) { c->cnt.ms_ax_kernel += ms; c->cnt.n_ax_kernel++; }
-            else { c->cnt.ms_atx_kernel += ms; c->cnt.n_atx_kernel++; }
+            else if (r.kind == 1) { c->cnt.ms_atx_kernel += ms; c->cnt.n_atx_kernel++; }
+            else { c->cnt.ms_allreduce += ms; c->cnt.n_allreduce++; }
         }
     }
     c->ev_used = 0;
@@ -247,20 +273,121 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
     return r;
 }
 
+// ---- persisted picks ---------------------------------------------------------------------------------------------
+// The decomposition picked for a (device, CU count, N, M) is appended to a small text file under $GV_TUNE_CACHE_DIR, else
+// $XDG_CACHE_HOME/gvamp_amd, else ~/.cache/gvamp_amd (GV_TUNE_CACHE=0: neither read nor written), so that only the first
+// run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
+// O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
+// accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
+constexpr int GV_TUNE_VERSION = 3;   // bump when the streaming kernel or the candidate set changes shape
+static std::string tune_cache_file() {
+    const char* on = getenv("GV_TUNE_CACHE");
+    if (on && atoi(on) == 0) return std::string();
+    std::string dir;
+    if (const char* d = getenv("GV_TUNE_CACHE_DIR")) dir = d;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/gvamp_amd";
+    else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/gvamp_amd";
+    else return std::string();
+    return dir + "/decomp.txt";
+}
+static std::string tune_key(gv_ctx* c) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
+    std::string name = pr.name;
+    for (char& ch : name) if (ch == ' ' || ch == '|') ch = '_';
+    char buf[256];
+    snprintf(buf, sizeof(buf), "v%d|%s|%s|%d|%lld|%lld|", GV_TUNE_VERSION, name.c_str(), pr.gcnArchName, pr.multiProcessorCount,
+             (long long)c->N, (long long)c->M);
+    return buf;
+}
+// is decomposition d admissible for side (0: ATx / stripes_m, 1: Ax / stripes_n) of this context?
+static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
+    const gvm::Plan& pl = c->plan;
+    const int64_t nkb = side ? pl.nkb_n : pl.nkb_m, nrg = side ? pl.nrg_n : pl.nrg_m;
+    const int64_t min_ks = side ? (c->M * 512 + 2147483646LL) / 2147483647LL : 1;
+    int64_t pieces;
+    if (d.skL > 0) {
+        if (d.skL < 8 || (side && min_ks > 1) || nkb < 2) return false;
+        pieces = (nkb + d.skL - 1) / d.skL + 1;
+    } else {
+        if (d.ks < 1 || d.ks > 64 || d.ks > nkb || d.ks < min_ks) return false;
+        pieces = d.ks;
+    }
+    if (!(d.taper >= 0.f && d.taper < 1.f) || (d.prio != 0 && d.prio != 1)) return false;
+    return (size_t)pieces * 4 * nrg * 64 * 8 * 4 <= pl.partial_bytes;
+}
+static bool tune_cache_load(gv_ctx* c) {
+    const std::string path = tune_cache_file(), key = tune_key(c);
+    if (path.empty() || key.empty()) return false;
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[1024];
+    gvm::Decomp got[4];
+    bool have = false;
+    while (fgets(line, sizeof(line), f)) {
+        if (strncmp(line, key.c_str(), key.size()) != 0) continue;
+        gvm::Decomp d[4];
+        long long sk[4];
+        if (sscanf(line + key.size(), "%d %lld %d %f %d %lld %d %f %d %lld %d %f %d %lld %d %f", &d[0].ks, &sk[0], &d[0].prio,
+                   &d[0].taper, &d[1].ks, &sk[1], &d[1].prio, &d[1].taper, &d[2].ks, &sk[2], &d[2].prio, &d[2].taper, &d[3].ks,
+                   &sk[3], &d[3].prio, &d[3].taper) != 16)
+            continue;
+        for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; got[k] = d[k]; }
+        have = true;
+    }
+    fclose(f);
+    if (!have) return false;
+    for (int k = 0; k < 4; k++)
+        if (!decomp_ok(c, got[k], k >> 1)) return false;
+    if (!c->ks_fixed_m) { c->plan.dm[0] = got[0]; c->plan.dm[1] = got[1]; }
+    if (!c->ks_fixed_n) { c->plan.dn[0] = got[2]; c->plan.dn[1] = got[3]; }
+    return true;
+}
+static void tune_cache_store(gv_ctx* c) {
+    const std::string path = tune_cache_file(), key = tune_key(c);
+    if (path.empty() || key.empty() || c->ks_fixed_m || c->ks_fixed_n) return;   // overrides are not picks
+    const size_t slash = path.rfind('/');
+    std::string dir = path.substr(0, slash);
+    for (size_t i = 1; i <= dir.size(); i++)                                      // mkdir -p
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+    const gvm::Decomp* d[4] = {&c->plan.dm[0], &c->plan.dm[1], &c->plan.dn[0], &c->plan.dn[1]};
+    char buf[1024];
+    int n = snprintf(buf, sizeof(buf), "%s", key.c_str());
+    for (int k = 0; k < 4; k++)
+        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %d %.2f ", d[k]->ks, (long long)d[k]->skL, d[k]->prio, d[k]->taper);
+    n += snprintf(buf + n, sizeof(buf) - n, "\n");
+    const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
+    if (fd < 0) return;
+    ssize_t w = write(fd, buf, (size_t)n);
+    (void)w;
+    close(fd);
+}
+
 // The work decomposition of each streaming-kernel class (ATx, two-vector ATx, Ax, two-vector Ax) is picked by measurement
-// among the candidates gv_set_dims lists (uniform K-splits short-listed by the cost model, balanced grids, each with and
-// without progress-based wave priority; then tapered segment lengths for the winner if it is a uniform split): one warm-up and
-// two timed runs of 2 to 16 Ax / ATx pairs each (the shorter the kernels the more), on the resident stripes, with
-// throw-away vectors (no counters, no collectives).  Once per shard, before its first matvec in kernel mode 1.  Results
-// do not depend on the decomposition (exact integer accumulation), so tuning never changes a bit of output.
+// among the candidates gv_set_dims lists, once per shard, before its first matvec in kernel mode 1, on the resident stripes
+// with throw-away vectors (no counters, no collectives) -- unless an earlier run on the same (device, N, M) left its picks in
+// the cache above.  Protocol, sized so that the cold cost stays a fraction of a second at 100 GB:
+//   stage A  the uniform splits short-listed by the cost model and the balanced grids, without / with their natural priority
+//            setting;  stage B  on the winner only: progress-based wave priority (uniform splits), then tapered segment
+//            lengths 0.5 / 0.9 (uniform splits with more than one segment).  At most 8 timed candidates per class.
+//   long kernels (>= 4 ms): ONE run of the product being tuned per candidate -- at that length neither the clocks nor what
+//            ran before move the result; short kernels: one untimed and a batch of timed Ax -> ATx PAIRS as the solvers
+//            issue them, the side not being tuned on its current pick -- a decomposition that won by 2 % back to back with
+//            itself was measured 10 % behind inside the alternating sequence (N = 50k x M = 200k, two-vector Ax).
+// Results do not depend on the decomposition (exact integer accumulation), so tuning never changes a bit of output.
 int autotune_ks(gv_ctx* c) {
     c->ks_tuned = true;
-    if ((c->ks_fixed_m && c->ks_fixed_n) || !c->have_stripes || c->M <= 0 || !c->have_stats) return 0;
+    c->tune_seconds = 0.0;
+    c->tune_source = 0;
+    if ((c->ks_fixed_m && c->ks_fixed_n) || !c->have_stripes || c->M <= 0 || !c->have_stats) { c->tune_source = 3; return 0; }
+    if (tune_cache_load(c)) { c->tune_source = 2; return 0; }
+    const auto wall0 = std::chrono::steady_clock::now();
     gvm::Plan& pl = c->plan;
     double *xm = nullptr, *wm = nullptr, *wm2 = nullptr, *pn = nullptr, *zn = nullptr, *zn2 = nullptr;
     auto done = [&](int rc) {
         for (double* q : {xm, wm, wm2, pn, zn, zn2}) if (q) (void)hipFree(q);
         pl.ev0 = pl.ev1 = nullptr;
+        c->tune_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
         return rc;
     };
     if (hipMalloc(&xm, sizeof(double) * c->M) != hipSuccess || hipMalloc(&wm, sizeof(double) * c->M) != hipSuccess ||
@@ -272,40 +399,28 @@ int autotune_ks(gv_ctx* c) {
     gvk::fill(c->stream, xm, c->M, 1.0);
     gvk::fill(c->stream, pn, c->npad, 1.0);
     pl.ev0 = pl.ev1 = nullptr;
-    // What is timed is the pair the solvers issue -- an Ax-side product followed by an ATx-side product, launched
-    // asynchronously -- not a kernel back to back with itself: a decomposition that wins in isolation by 2 % was measured
-    // 10 % behind inside the alternating sequence (N = 50k x M = 200k, two-vector Ax).  The side that is not being tuned runs
-    // its current pick.
-    auto run_pair = [&](int dual) {
-        if (dual) {
-            gvm::ax2(c->stream, pl, xm, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn, zn2);
-            gvm::atx2(c->stream, pl, pn, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm, wm2, nullptr, nullptr, 1.0, 0.0);
-        } else {
-            gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
-            gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
+    // side: 0 = both products (the pair the solvers issue), 1 = Ax side only, 2 = ATx side only
+    auto run = [&](int dual, int side) {
+        if (side != 2) {
+            if (dual) gvm::ax2(c->stream, pl, xm, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn, zn2);
+            else gvm::ax(c->stream, pl, xm, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, zn);
+        }
+        if (side != 1) {
+            if (dual) gvm::atx2(c->stream, pl, pn, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm, wm2, nullptr, nullptr, 1.0, 0.0);
+            else gvm::atx(c->stream, pl, pn, c->npad, c->mave, c->msig, 1.0, c->red_partial, wm);
         }
     };
-    auto time_pair = [&](int dual) -> double {   // ms per pair; short kernels get more repetitions (>= ~25 ms per candidate)
-        int reps = 1;
-        float best = 1e30f;
-        for (int round = 0; round < 3; round++) {   // round 0 warms up and sizes the repetition count
-            (void)hipEventRecord(c->ev0, c->stream);
-            for (int r = 0; r < reps; r++) run_pair(dual);
-            (void)hipEventRecord(c->ev1, c->stream);
-            if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            if (round == 0) {
-                const int want = (int)(12.5f / (ms > 1e-3f ? ms : 1e-3f)) + 1;
-                reps = want < 2 ? 2 : (want > 16 ? 16 : want);
-            } else if (ms / reps < best) {
-                best = ms / reps;
-            }
-        }
-        return best;
+    auto timed = [&](int dual, int side, int reps) -> double {   // ms per repetition
+        (void)hipEventRecord(c->ev0, c->stream);
+        for (int r = 0; r < reps; r++) run(dual, side);
+        (void)hipEventRecord(c->ev1, c->stream);
+        if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        return ms / reps;
     };
     const bool verbose = getenv("GV_AUTOTUNE_VERBOSE") != nullptr;
-    if (time_pair(0) < 0) { KCHK(c); return done(1); }   // clocks and caches up before anything is compared
+    if (timed(0, 0, 1) < 0) { KCHK(c); return done(1); }        // clocks and caches up before anything is compared
     for (int step = 0; step < 4; step++) {
         const int dual = step >> 1;
         const bool is_ax = (step & 1) == 0;             // Ax side first, then the ATx side against the tuned Ax
@@ -314,35 +429,60 @@ int autotune_ks(gv_ctx* c) {
         const std::vector<gvm::Decomp>& cand = is_ax ? c->dec_cand_n : c->dec_cand_m;
         gvm::Decomp& d = is_ax ? pl.dn[dual] : pl.dm[dual];
         if (cand.empty()) continue;
-        size_t best = 0;
-        double best_t = -1;
-        for (size_t j = 0; j < cand.size(); j++) {
-            d = cand[j];
-            const double t = time_pair(dual);
-            if (t < 0) { d = cand[0]; KCHK(c); return done(1); }
+        d = cand[0];
+        const double t_pair = timed(dual, 0, 1);        // sizes the protocol of this class (and warms it)
+        if (t_pair < 0) { KCHK(c); return done(1); }
+        const bool solo = t_pair >= 8.0;                // both products >= ~4 ms
+        const int side = solo ? (is_ax ? 1 : 2) : 0;
+        int reps = solo ? 1 : (int)(6.0 / (t_pair > 1e-3 ? t_pair : 1e-3)) + 1;
+        if (reps > 8) reps = 8;
+        auto measure = [&](const gvm::Decomp& cd) -> double {
+            d = cd;
+            if (!solo && timed(dual, 0, 1) < 0) return -1.0;   // untimed: the first launch of a new grid shape
+            const double t = timed(dual, side, reps);
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d : %.4f ms / pair\n", cls, d.ks, (long long)d.skL, d.prio, t);
-            if (best_t < 0 || t < best_t * 0.997) { best_t = t; best = j; }   // the list order breaks near-ties
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d taper %.1f : %.4f ms / %s\n", cls, cd.ks,
+                        (long long)cd.skL, cd.prio, cd.taper, t, solo ? "product" : "pair");
+            return t;
+        };
+        gvm::Decomp best = cand[0];
+        double best_t = -1;
+        auto consider = [&](const gvm::Decomp& cd) -> int {
+            const double t = measure(cd);
+            if (t < 0) return 1;
+            if (best_t < 0 || t < best_t * 0.997) { best_t = t; best = cd; }   // the list order breaks near-ties
+            return 0;
+        };
+        // stage A: uniform splits without priority, balanced grids (which carry their priority setting)
+        bool any_plain = false;
+        for (const gvm::Decomp& cd : cand) any_plain |= cd.skL <= 0 && cd.prio == 0;
+        for (const gvm::Decomp& cd : cand) {
+            if (cd.skL <= 0 && cd.prio != 0 && any_plain) continue;
+            if (consider(cd)) { d = cand[0]; KCHK(c); return done(1); }
         }
-        d = cand[best];
-        // second stage, uniform splits with more than one segment: taper the segment lengths so that the workgroups
-        // dispatched last are the shortest (the launch's tail is one workgroup-duration long)
-        if (d.skL <= 0 && d.ks > 1 && d.taper == 0.f) {
-            gvm::Decomp keep = d;
-            for (float tp : {0.5f, 0.9f}) {
-                d = keep; d.taper = tp;
-                const double t = time_pair(dual);
-                if (t < 0) { d = cand[0]; KCHK(c); return done(1); }
-                if (verbose)
-                    fprintf(stderr, "[gvamp autotune] class %d ks %d taper %.1f prio %d : %.4f ms / pair\n", cls, d.ks, tp, d.prio, t);
-                if (t < best_t * 0.997) { best_t = t; keep = d; }
+        // stage B on the winner: priority, then taper
+        if (best.skL <= 0) {
+            bool prio_listed = false;
+            for (const gvm::Decomp& cd : cand) prio_listed |= cd.skL <= 0 && cd.prio == 1 && cd.ks == best.ks;
+            if (best.prio == 0 && prio_listed) {
+                gvm::Decomp t = best; t.prio = 1;
+                if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
             }
-            d = keep;
+            if (best.ks > 1 && best.taper == 0.f) {
+                const gvm::Decomp base = best;
+                for (float tp : {0.5f, 0.9f}) {
+                    gvm::Decomp t = base; t.taper = tp;
+                    if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
+                }
+            }
         }
+        d = best;
         if (verbose)
             fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld prio %d taper %.1f\n", cls, d.ks, (long long)d.skL, d.prio, d.taper);
     }
     KCHK(c);
+    c->tune_source = 1;
+    tune_cache_store(c);
     return done(0);
 }
 
@@ -351,7 +491,10 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
-    if (c->kernel_mode == 1 && c->M > 0) {
+    if (c->M == 0) {   // an empty shard (Mt < ranks) contributes zeros through the same collective as its peers
+        gvk::fill(c->stream, out, c->npad, 0.0);
+        KCHK(c);
+    } else if (c->kernel_mode == 1) {
         NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
         if (!c->ks_tuned && autotune_ks(c)) return 1;
         Timer t(c, &c->cnt.ms_ax);
@@ -377,10 +520,14 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
     c->cnt.n_ax_pass++;
     if (multi) {   // data.cpp:995 MPI_Allreduce, then the 1/sqrt(N) of :998-1005
         Timer t(c, &c->cnt.ms_allreduce);
+        gv_ctx::EvRec* er = ev_next(c, 2);                 // timing == 2: the exchange step of the pass, un-synchronised
+        if (er) (void)hipEventRecord(er->a, c->stream);
         if (comm_allreduce(c, out, c->npad)) return 1;
         gvk::scale_vec(c->stream, out, c->npad, scale);
+        if (er) (void)hipEventRecord(er->b, c->stream);
         KCHK(c);
         t.stop();
+        if (c->timing == 1) c->cnt.n_allreduce++;
     }
     return 0;
 }
@@ -388,7 +535,12 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
 int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, double tau, double gam2) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
-    if (c->kernel_mode == 1 && c->M > 0 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
+    if (c->M == 0) {   // empty shard
+        c->cnt.n_atx++;
+        c->cnt.n_atx_pass++;
+        return 0;
+    }
+    if (c->kernel_mode == 1 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "ATx: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
@@ -413,15 +565,22 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
 
 // two-vector forms: ONE pass over the shard in kernel mode 1, two single passes otherwise
 int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb) {
-    if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
+    // The collective sequence below must not depend on rank-local state (an empty shard, M == 0, enters the same calls
+    // with zeros): it is chosen by the kernel mode -- the same on every rank of a job -- and the output pointers only.
+    if (c->kernel_mode != 1) {
         if (ax_device(c, xa, outa)) return 1;
         return ax_device(c, xb, outb);
     }
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
-    if (!c->ks_tuned && autotune_ks(c)) return 1;
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
-    {
+    if (c->M == 0) {
+        gvk::fill(c->stream, outa, c->npad, 0.0);
+        gvk::fill(c->stream, outb, c->npad, 0.0);
+        KCHK(c);
+    } else {
+        NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+        if (!c->ks_tuned && autotune_ks(c)) return 1;
         Timer t(c, &c->cnt.ms_ax);
         gv_ctx::EvRec* er = ev_next(c, 0);
         c->plan.ev0 = er ? er->a : nullptr;
@@ -434,6 +593,8 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     c->cnt.n_ax_pass += 1;
     if (multi) {
         Timer t(c, &c->cnt.ms_allreduce);
+        gv_ctx::EvRec* er = ev_next(c, 2);
+        if (er) (void)hipEventRecord(er->a, c->stream);
         if (c->w_n && c->w_n2 && outa == c->w_n->d && outb == c->w_n2->d) {   // w_n | w_n2 (one allocation): one message, one scaling pass
             if (comm_allreduce(c, outa, 2 * c->npad)) return 1;
             gvk::scale_vec(c->stream, outa, 2 * c->npad, scale);
@@ -443,14 +604,21 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
             gvk::scale_vec(c->stream, outa, c->npad, scale);
             gvk::scale_vec(c->stream, outb, c->npad, scale);
         }
+        if (er) (void)hipEventRecord(er->b, c->stream);
         KCHK(c);
         t.stop();
+        if (c->timing == 1) c->cnt.n_allreduce++;
     }
     return 0;
 }
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
                 const double* addxb, double tau, double gam2) {
-    if (!(c->kernel_mode == 1 && c->M > 0 && c->have_stripes)) {
+    if (c->M == 0) {   // empty shard: no local markers, no collective in ATx
+        c->cnt.n_atx += 2;
+        c->cnt.n_atx_pass += 1;
+        return 0;
+    }
+    if (!(c->kernel_mode == 1 && c->have_stripes)) {
         if (atx_device(c, pa, outa, addxa, tau, gam2)) return 1;
         return atx_device(c, pb, outb, addxb, tau, gam2);
     }
@@ -951,8 +1119,14 @@ int gv_ax(gv_ctx* c, const double* x, double* out) {
 }
 int gv_atx(gv_ctx* c, const double* p, double* out) {
     if (ensure_work(c)) return 1;
-    // pad slots of w_n beyond 4*mbytes stay 0 (allocated zeroed, Ax writes 0 there)
+    NEED(c, c->mask2, "gv_atx: the phenotype mask must be set first");
     if (to_device(c, c->w_n->d, p, sizeof(double) * 4 * c->mbytes)) return 1;
+    // The kernels (like data::dot_product, data.cpp:728-801, which applies no mask) need p = 0 at NA-phenotype and pad
+    // slots; the reference's callers hand in filter_pheno()'d vectors.  A caller-owned host vector is not trusted to be
+    // filtered -- data::get_phen() carries DBL_MAX at NA individuals (data.cpp:147) -- so the staged copy is masked here:
+    // a no-op for filtered input, a defined result (the NA individuals dropped) otherwise.
+    gvk::mask_copy(c->stream, c->w_n->d, c->w_n->d, c->mask2, c->npad);
+    KCHK(c);
     if (atx_device(c, c->w_n->d, c->cg_d->d)) return 1;
     return to_host(c, out, c->cg_d->d, sizeof(double) * (c->M > 0 ? c->M : 0));
 }
@@ -1103,6 +1277,9 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
     PV_HIP(hipMalloc(&pv_dev, sizeof(double) * Mn));
     PV_HIP(hipMemsetAsync(pv_dev, 0, sizeof(double) * Mn, c->stream));
     gvk::axpby(c->stream, ymod->d, 1.0, y->d, -1.0, z1->d, c->npad);            // y_mod = y - z1 (data.cpp:1117-1119)
+    // the reference masks every term of the regression sums with na_lut[mask4] (data.cpp:1155-1175); the sums here are
+    // matvec-shaped and need zeros at NA / pad slots instead, whatever the caller left there (an unfiltered y holds DBL_MAX)
+    gvk::mask_copy(c->stream, ymod->d, ymod->d, c->mask2, c->npad);
     if (!chrom) {
         PV_TRY(marker_sums_p_p2(c, ymod->d, sq->d, sums_dev));
         // y_mark = y_mod + gen_part * x1_hat[k] (data.cpp:1145-1148): the marker's own column, c = x1_hat[k] / sqrt(N)
@@ -1167,6 +1344,8 @@ int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
     }
     c->local = nullptr;
     c->local_keep.reset();
+    c->cb = nullptr;
+    c->cb_user = nullptr;
     c->rank = rank;
     c->nranks = nranks;
     if (nranks == 1 && !id128) return 0;
@@ -1199,8 +1378,34 @@ int gv_comm_init_local(gv_ctx* c, int group, int nranks, int rank) {
     }
     c->local_keep = g;
     c->local = g.get();
+    c->cb = nullptr;
+    c->cb_user = nullptr;
     c->rank = rank;
     c->nranks = nranks;
+    return 0;
+}
+int gv_comm_init_callback(gv_ctx* c, int nranks, int rank, gv_allreduce_fn fn, void* user) {
+    NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init_callback: bad rank / nranks");
+    NEED(c, fn != nullptr, "gv_comm_init_callback: fn is NULL");
+    if (c->comm) {
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->local = nullptr;
+    c->local_keep.reset();
+    c->cb = fn;
+    c->cb_user = user;
+    c->rank = rank;
+    c->nranks = nranks;
+    // self-test, as for RCCL: every rank must see nranks * (rank-independent value)
+    double probe[4] = {1.0, 2.0, 3.0, 4.0}, back[4];
+    memcpy(back, probe, sizeof(probe));
+    if (nranks > 1) {
+        if (allreduce_scalars(c, back, 4)) return 1;
+        for (int i = 0; i < 4; i++)
+            if (back[i] != probe[i] * nranks)
+                return fail(c, "gv_comm_init_callback: all-reduce self-test failed (%g != %g)", back[i], probe[i] * nranks);
+    }
     return 0;
 }
 int gv_comm_rank(const gv_ctx* c) { return c->rank; }
@@ -1219,6 +1424,23 @@ int gv_get_counters(gv_ctx* c, gv_counters* out) {
 int gv_reset_counters(gv_ctx* c) {
     ev_resolve(c);
     c->cnt = gv_counters{};
+    return 0;
+}
+int gv_tune_info(gv_ctx* c, double* seconds, int* source) {
+    if (seconds) *seconds = c->tune_seconds;
+    if (source) *source = c->ks_tuned ? c->tune_source : -1;
+    return 0;
+}
+int gv_get_decomp(gv_ctx* c, gv_decomp_info* out4) {
+    NEED(c, out4 != nullptr, "gv_get_decomp: out is NULL");
+    const gvm::Decomp* d[4] = {&c->plan.dm[0], &c->plan.dm[1], &c->plan.dn[0], &c->plan.dn[1]};
+    for (int k = 0; k < 4; k++) {
+        out4[k].ks = d[k]->ks;
+        out4[k].balanced_cells = d[k]->skL;
+        out4[k].prio = d[k]->prio;
+        out4[k].taper = d[k]->taper;
+        out4[k].tuned = c->ks_tuned ? 1 : 0;
+    }
     return 0;
 }
 int gv_copy_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {

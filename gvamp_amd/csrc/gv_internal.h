@@ -48,6 +48,8 @@ struct gv_ctx {
     std::vector<gvm::Decomp> dec_cand_m, dec_cand_n;
     bool ks_fixed_m = false, ks_fixed_n = false;   // an override fixed the decomposition: nothing to pick
     bool ks_tuned = false;
+    double tune_seconds = 0.0;      // wall time the pick cost (0 when it came from the cache)
+    int tune_source = 0;            // 0 model's first candidate, 1 measured, 2 cache, 3 fixed by an override / nothing to tune
 
     // workspaces ---------------------------------------------------------------------------------
     double* t3 = nullptr;          // 3*M: per-marker Ax table {(2-mu)c, (1-mu)c, (0-mu)c}
@@ -74,6 +76,8 @@ struct gv_ctx {
     void* local = nullptr;                 // in-process test communicator (gv_comm_init_local)
     std::shared_ptr<void> local_keep;
     std::vector<double> local_buf;
+    gv_allreduce_fn cb = nullptr;          // host-callback communicator (gv_comm_init_callback)
+    void* cb_user = nullptr;
 
     // instrumentation ------------------------------------------------------------------------------
     int timing = 0;

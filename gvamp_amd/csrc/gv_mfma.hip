@@ -177,13 +177,19 @@ __device__ void prep_final(const double* partial, int nblocks, double* scal, dou
         double amax = shm[0];
         scal[0] = amax;
         scal[1] = shs[0];
-        if (amax > 0.0 && amax < 1.7e308) {
+        if (amax > 0.0 && amax <= 1.7976931348623157e308) {
             int e = ilogb(amax) + 1;
             scal[2] = ldexp(1.0, 54 - e);
             scal[3] = ldexp(1.0, e - 54);
-        } else {
+        } else if (amax == 0.0) {
             scal[2] = 0.0;
             scal[3] = 0.0;
+        } else {
+            // a NaN or an infinity among the entries (the prep kernels raise amax to +inf for either): fixed point has no
+            // encoding for it.  Defined behaviour = what fp64 sums over the whole vector give in the reference: every
+            // output entry of this product is NaN (digits are quantised with multiplier 0, the epilogue multiplies by NaN).
+            scal[2] = 0.0;
+            scal[3] = __longlong_as_double(0x7ff8000000000000LL);
         }
     }
 }
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
         double e = (mu - 3.0) * c;
         cv[i] = c;
         ev[i] = e;
-        mx = fmax(mx, fmax(fabs(c), fabs(e)));
+        mx = (isfinite(c) && isfinite(e)) ? fmax(mx, fmax(fabs(c), fabs(e))) : __longlong_as_double(0x7ff0000000000000LL);
         s += mu * c;
     }
     if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* 
     double mx = 0.0, s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double val = p[i];
-        mx = fmax(mx, fabs(val));
+        mx = isfinite(val) ? fmax(mx, fabs(val)) : __longlong_as_double(0x7ff0000000000000LL);   // fmax would drop a NaN
         s += val;
     }
     if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))

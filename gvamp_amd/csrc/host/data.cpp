@@ -50,6 +50,9 @@ void data::open_device(int device, int kernel_mode) {
     ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
     ck(ctx, gv_set_layout(ctx, kernel_mode == 0, kernel_mode != 0), "gv_set_layout");
     ck(ctx, gv_set_kernel_mode(ctx, kernel_mode), "gv_set_kernel_mode");
+    if (kernel_mode == 0 && rank == 0)
+        std::cerr << "WARNING: --kernel-mode 0 selects the fp64 VALU kernels (parity anchor, 4-9 % of the HBM roofline): "
+                     "expect Ax / ATx 10-20x slower than the default --kernel-mode 1" << std::endl;
     const int nranks = gv_env_nranks();
     if (nranks > 1) {
         // one process per GPU: rank 0 publishes the RCCL unique id through a file next to the outputs

@@ -13,6 +13,7 @@
 #include <numeric>
 #include <random>
 #include <stdexcept>
+#include <string>
 
 static int env_int(const char* k, int dflt) {
     const char* v = getenv(k);
@@ -124,8 +125,14 @@ std::vector<double> mpi_read_vec_from_file(const std::string& filename, int M, i
     return vec;
 }
 
+// Host-vector forms of utilities.cpp:190-214.  Every caller of this build passes sync = 0 (replicated N-vectors, covariate
+// rows); the all-reduced products of the reference (sync = 1) run on the device (vamp::dotM -> gv_vec_dots).  A sync = 1
+// call has no communicator to use here, so it fails loudly instead of returning a rank-local sum.
+static void need_local(int sync, const char* who) {
+    if (sync != 0) throw std::invalid_argument(std::string(who) + ": sync = 1 is not available on host vectors (use gv_vec_dots / gv_allreduce_host)");
+}
 double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync) {
-    (void)sync;
+    need_local(sync, "inner_prod");
     double acc = 0;
     for (size_t i = 0; i < u.size(); i++) acc += u[i] * v[i];
     return acc;
@@ -133,7 +140,7 @@ double inner_prod(const std::vector<double>& u, const std::vector<double>& v, in
 double l2_norm2(const std::vector<double>& u, int sync) { return inner_prod(u, u, sync); }
 
 double calc_stdev(const std::vector<double>& vec, int sync) {
-    (void)sync;
+    need_local(sync, "calc_stdev");
     const double sum = std::accumulate(vec.begin(), vec.end(), 0.0);
     const double sq = std::inner_product(vec.begin(), vec.end(), vec.begin(), 0.0);
     const int n = (int)vec.size();

@@ -23,7 +23,7 @@ std::vector<double> read_vec_from_file(const std::string& filename, int M, int S
 void store_vec_to_file(const std::string& filepath, const std::vector<double>& vec);                // utilities.cpp:178-187 (text)
 void mpi_store_vec_to_file(const std::string& filepath_out, const std::vector<double>& vec, int S, int M);   // :293-301 (binary at S*8)
 std::vector<double> mpi_read_vec_from_file(const std::string& filename, int M, int S);       // :303-319
-double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync);   // host vectors, sync ignored
+double inner_prod(const std::vector<double>& u, const std::vector<double>& v, int sync);   // host vectors; sync must be 0 (throws otherwise)
 double l2_norm2(const std::vector<double>& u, int sync);
 double calc_stdev(const std::vector<double>& vec, int sync = 0);
 double normal_cdf(double value);                                                        // utilities.cpp:336-339

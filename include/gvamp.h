@@ -210,6 +210,13 @@ int gv_comm_init(gv_ctx* ctx, int nranks, int rank, const void* id128);
  * `group` behave like nranks ranks; sums are taken in rank order on the host.  Every collective must be entered by
  * all members concurrently (from different threads). */
 int gv_comm_init_local(gv_ctx* ctx, int group, int nranks, int rank);
+/* Communicator over a caller-supplied transport: every collective of the context becomes
+ *   device -> host copy, fn(user, buf, n) [in-place SUM of n host doubles over the nranks ranks; 0 = ok], host -> device copy.
+ * For a host that already owns a communicator -- the reference's MPI_COMM_WORLD (`MPI_Allreduce(MPI_IN_PLACE, buf, n,
+ * MPI_DOUBLE, MPI_SUM, ...)`, data.cpp:928) -- and for tests that run the ranks as processes sharing one GPU
+ * (torch.distributed gloo).  Slower than RCCL (two PCIe hops per message); the sums must be identical on every rank. */
+typedef int (*gv_allreduce_fn)(void* user, double* buf, size_t n);
+int gv_comm_init_callback(gv_ctx* ctx, int nranks, int rank, gv_allreduce_fn fn, void* user);
 int gv_comm_rank(const gv_ctx* ctx);
 int gv_comm_size(const gv_ctx* ctx);
 
@@ -222,6 +229,7 @@ typedef struct {
     double ms_ax_kernel, ms_atx_kernel;  /* ... and their summed HIP-event durations */
     int64_t n_ax_pass, n_atx_pass;       /* passes over the genotype shard (a two-vector product counts 2 in n_ax / n_atx
                                           * and 1 here) */
+    int64_t n_allreduce;                 /* N-vector exchange steps timed into ms_allreduce (timing 1 or 2; sharded jobs) */
 } gv_counters;
 /* timing: 0 off; 1 brackets every whole matvec (prep + kernel + epilogue) with HIP events and synchronises per
  * call (development); 2 records event pairs around the dominant matvec kernel only, WITHOUT synchronising --
@@ -229,6 +237,21 @@ typedef struct {
 int gv_set_timing(gv_ctx* ctx, int timing);
 int gv_get_counters(gv_ctx* ctx, gv_counters* out);
 int gv_reset_counters(gv_ctx* ctx);
+/* The work decomposition of the four streaming-kernel classes (0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax) as
+ * picked by the on-device tuning (or its cache / an override): what a bench line reports per rank. */
+typedef struct {
+    int ks;                  /* uniform K-split: segments per group of four row groups */
+    int64_t balanced_cells;  /* > 0: balanced decomposition, cells per workgroup (ks unused) */
+    int prio;                /* progress-based wave priority on */
+    float taper;             /* uniform split: taper of the segment lengths */
+    int tuned;               /* 1 once the pick has been made (measured or read from the cache) */
+} gv_decomp_info;
+int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
+/* How the picks were made: *source = -1 not yet (the first matvec in kernel mode 1 makes them), 0 the cost model's first
+ * candidate (tuning impossible), 1 measured on the device now (*seconds of wall time), 2 read from the cache an earlier run on
+ * the same (device, N, M) left ($GV_TUNE_CACHE_DIR, $XDG_CACHE_HOME/gvamp_amd or ~/.cache/gvamp_amd; GV_TUNE_CACHE=0
+ * disables it), 3 fixed by an override.  Picks never change results (exact integer accumulation). */
+int gv_tune_info(gv_ctx* ctx, double* seconds, int* source);
 /* device copy bandwidth probe: copies nbytes device->device `reps` times, returns GB/s (read+write bytes) */
 int gv_copy_bandwidth(gv_ctx* ctx, size_t nbytes, int reps, double* gbps);
 /* read-only stream probe with the access shape of the matvec kernels (every wave walks a contiguous run of 4 KiB blocks,

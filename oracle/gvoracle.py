@@ -140,9 +140,17 @@ def ax(bed, N, M, mave, msig, x, mask4=None, nthreads=1):
     return out
 
 
-def atx(bed, N, M, mave, msig, p, nthreads=1):
+def atx(bed, N, M, mave, msig, p, nthreads=1, mask4=None):
+    """data::ATx (data.cpp:810-835).  dot_product (data.cpp:728-801) applies NO mask: the reference's callers hand in
+    filter_pheno()'d vectors (zero at NA individuals).  mask4 != None restates that caller-side step here -- p is filtered
+    with the phenotype mask first -- so that an unfiltered p (DBL_MAX at NA slots, data.cpp:147) has a defined expectation."""
     bed, mave, msig, p = _u8(bed), _f64(mave), _f64(msig), _f64(p)
     assert p.size == 4 * mbytes(N)
+    if mask4 is not None:
+        m4 = _u8(mask4)
+        present = ((m4[np.arange(p.size) >> 2] >> (np.arange(p.size) & 3)) & 1).astype(bool)
+        present &= np.arange(p.size) < N
+        p = np.where(present, p, 0.0)
     out = np.empty(M)
     lib().gvo_atx(_up(bed), N, M, _dp(mave), _dp(msig), _dp(p), nthreads, _dp(out))
     return out

@@ -13,6 +13,17 @@ import sys
 from collections import defaultdict
 
 
+def kernel_sources_sha256():
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("gv_mfma.hip", "gv_mfma.h"):
+        with open(os.path.join(root, "gvamp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def per_kernel(path, counter):
     acc = defaultdict(lambda: [0, 0.0])
     with open(path + "/bench_counter_collection.csv") as f:
@@ -48,6 +59,9 @@ def main():
                 "--no-cpu-baseline --vamp-iterations 2`; hbm_bytes = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950: "
                 "FETCH_SIZE counts wide streaming reads at half, MI355X_MICROARCH.md section HBM)",
         "N": N, "Mt": Mt, "n_gpus": 1, "kernel_mode": 1,
+        # identity of the kernel sources these counters belong to: bench.py quotes `roofline.traffic` from this file only
+        # while its own gv_mfma.hip / gv_mfma.h hash to the same value
+        "kernel_sources_sha256": kernel_sources_sha256(),
     }
     for key, frag in (("ax", "k_mfma_matvec<1,"), ("atx", "k_mfma_matvec<0,"), ("ax2", "k_mfma_matvec<3,"),
                       ("atx2", "k_mfma_matvec<2,")):

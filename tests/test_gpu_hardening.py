@@ -1,0 +1,193 @@
+"""Direct unit tests of entry points round 1 only covered end to end, and defined behaviour at the edges of the contract:
+gv_lmmse_mult and gv_prior_estep against the oracle, unfiltered phenotypes (DBL_MAX at NA individuals, data.cpp:147) through
+gv_atx / the p-value entry points, non-finite vector entries, work-vector allocation, the --kernel-mode 0 warning."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gvamp_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-12
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def make_mask(N, rng, frac_na):
+    present = rng.random(N) >= frac_na
+    m4 = np.zeros((N + 3) // 4, dtype=np.uint8)
+    for n in np.nonzero(present)[0]:
+        m4[n >> 2] |= 1 << (n & 3)
+    return m4, int(present.sum()), present
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("N,M,fna", [(2000, 700, 0.0), (1003, 257, 0.02)])
+def test_lmmse_mult_vs_oracle(oracle, mode, N, M, fna):
+    """vamp::lmmse_mult (vamp.cpp:1074-1118): tau A^T (A v) + gam2 v, the ATx epilogue fused in kernel mode 1."""
+    rng = np.random.default_rng(N + M + mode)
+    bed = synth.synth_bed(N, M, seed=12, miss_ppm=8000)
+    m4, nonas, _ = make_mask(N, rng, fna) if (fna > 0 or N % 4) else (None, N, None)
+    mave, msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas)
+    v = rng.standard_normal(M)
+    tau, gam2 = 1.7, 0.42
+    ref = tau * oracle.atx(bed, N, M, mave, msig, oracle.ax(bed, N, M, mave, msig, v, mask4=m4)) + gam2 * v
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        if m4 is not None:
+            sh.set_mask(m4, nonas)
+        sh.set_kernel_mode(mode)
+        sh.compute_markers_statistics()
+        dv, out = sh.vecM(v), sh.vecM()
+        sh.lmmse_mult(dv, tau, gam2, out)
+        assert rel(out.download(), ref) < TOL
+        assert np.array_equal(dv.download(), v)                       # the operand is borrowed, never written
+        sh.lmmse_mult(sh.vecM(np.zeros(M)), tau, gam2, out)           # the reference's all-zero shortcut (:1079)
+        assert np.all(out.download() == 0)
+
+
+@pytest.mark.parametrize("L", [3, 23])
+def test_prior_estep_vs_oracle_update_prior(oracle, L):
+    """One E-step of vamp::updatePrior (vamp.cpp:953-1013) on the device, M-step restated from SURVEY Appendix A on its sums,
+    against one EM round of the oracle's updatePrior; and the sums themselves against a dense numpy evaluation."""
+    M = 30011
+    rng = np.random.default_rng(L)
+    if L == 3:
+        probs, vars_ = np.array([0.9, 0.07, 0.03]), np.array([0.0, 2.0, 20.0])
+    else:
+        probs = np.concatenate([[0.7], 0.3 * np.full(L - 1, 1.0 / (L - 1))])
+        vars_ = np.concatenate([[0.0], 1e-2 * 10.0 ** (np.arange(L - 1) * 4.0 / (L - 2))])   # ratios > 1.5: no merge
+    comp = rng.choice(L, size=M, p=probs)
+    gam1 = 3.5
+    r1 = rng.standard_normal(M) * np.sqrt(vars_[comp] + 1.0 / gam1)
+    lam = 1.0 - probs[0]
+    omegas = probs.copy()
+    omegas[1:] /= lam
+    with capi.Shard(64, M) as sh:
+        sums = sh.prior_estep(sh.vecM(r1), gam1, lam, omegas, vars_)
+    # dense numpy evaluation of Appendix A
+    nu, vmax = 1.0 / gam1, vars_.max()
+    v = vars_[1:]
+    num = lam * omegas[1:] * np.exp(-0.5 * r1[:, None] ** 2 * (vmax - v) / ((v + nu) * (vmax + nu))) / np.sqrt(v + nu) / np.sqrt(2 * np.pi)
+    S = num.sum(1)
+    beta = num / S[:, None]
+    pin = 1.0 / (1.0 + (1 - lam) / np.sqrt(2 * np.pi * nu) * np.exp(-0.5 * r1 ** 2 * vmax / (nu * (nu + vmax))) / S)
+    gam = gam1 * r1[:, None] / (1.0 / v + gam1)
+    vhat = 1.0 / (1.0 / v + gam1)
+    want = np.empty(1 + 2 * (L - 1))
+    want[0] = pin.sum()
+    want[1::2] = (beta * pin[:, None]).sum(0)
+    want[2::2] = (beta * (gam ** 2 + vhat) * pin[:, None]).sum(0)
+    assert np.allclose(sums, want, rtol=1e-11, atol=0)
+    # M-step (vamp.cpp:1015-1022) on the device sums vs the oracle's one-round updatePrior
+    Pi, R, Gs = sums[0], sums[1::2], sums[2::2]
+    new_vars = np.concatenate([[0.0], Gs / R])
+    new_lam = Pi / M
+    new_probs = np.concatenate([[1 - new_lam], new_lam * R / Pi])
+    o_probs, o_vars = oracle.update_prior(r1, M, gam1, probs, vars_, EM_max_iter=1, EM_err_thr=1e-30, learn_vars=1)
+    assert len(o_probs) == L
+    assert np.allclose(new_probs, o_probs, rtol=1e-10) and np.allclose(new_vars, o_vars, rtol=1e-10)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_atx_of_an_unfiltered_phenotype_drops_the_na_individuals(oracle, mode):
+    """data::get_phen() keeps DBL_MAX at NA individuals (data.cpp:147); data::dot_product applies no mask (data.cpp:728-801).
+    gv_atx masks the staged copy, so ATx(get_phen()) is the ATx of the filtered phenotype instead of overflow garbage."""
+    N, M = 1003, 300
+    rng = np.random.default_rng(3)
+    bed = synth.synth_bed(N, M, seed=4, miss_ppm=10000)
+    m4, nonas, present = make_mask(N, rng, 0.03)
+    p = np.zeros(4 * ((N + 3) // 4))
+    p[:N] = np.where(present, rng.standard_normal(N), np.finfo(np.float64).max)
+    p[N:] = 7.0                                                    # pad slots are not trusted either
+    mave, msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas)
+    want = oracle.atx(bed, N, M, mave, msig, p, mask4=m4)
+    assert np.all(np.isfinite(want))
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_mask(m4, nonas)
+        sh.set_kernel_mode(mode)
+        sh.compute_markers_statistics()
+        assert rel(sh.ATx(p), want) < TOL
+        # p-values with an unfiltered y (DBL_MAX at NA individuals): masked like the reference's na_lut (data.cpp:1155-1175)
+        x1 = rng.standard_normal(M) * (rng.random(M) < 0.05)
+        z1 = sh.vecN()
+        sh.ax_dev(sh.vecM(x1), z1)
+        y = np.zeros(4 * ((N + 3) // 4))
+        y[:N] = np.where(present, rng.standard_normal(N), np.finfo(np.float64).max)
+        pv = sh.pvals_calc(z1, sh.vecN(y), sh.vecM(x1))
+        yf = np.where(np.arange(y.size) < N, y, 0.0) * np.concatenate([present, np.zeros(y.size - N, bool)])
+        opv = oracle.pvals(bed, N, M, z1.download(), yf, x1, mask4=m4, nonas=nonas)
+        assert np.all(np.isfinite(pv)) and np.allclose(pv, opv, rtol=1e-8, atol=1e-300)
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_entries_give_nan_not_garbage(bad):
+    """Fixed point cannot encode NaN / inf.  Defined behaviour of kernel mode 1, both directions: a non-finite entry anywhere
+    in the operand makes EVERY entry of the product NaN (what the reference's fp64 sums over the whole vector give), masked /
+    pad slots of an N-space result stay 0, and the context stays usable.  Kernel mode 0 propagates through fp64 arithmetic."""
+    N, M = 1500, 400
+    rng = np.random.default_rng(1)
+    bed = synth.synth_bed(N, M, seed=9, miss_ppm=5000)
+    m4, nonas, present = make_mask(N, rng, 0.01)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_mask(m4, nonas)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        x = rng.standard_normal(M)
+        good = sh.Ax(x)
+        xb = x.copy()
+        xb[137] = bad
+        z = sh.Ax(xb)
+        assert np.all(np.isnan(z[:N][present])) and np.all(z[:N][~present] == 0) and np.all(z[N:] == 0)
+        p = np.zeros(4 * ((N + 3) // 4))
+        p[:N] = rng.standard_normal(N) * present
+        pb = p.copy()
+        pb[np.nonzero(present)[0][5]] = bad
+        assert np.all(np.isnan(sh.ATx(pb)))
+        xa, xbv, za, zb = sh.vecM(x), sh.vecM(xb), sh.vecN(), sh.vecN()
+        sh.ax2_dev(xa, xbv, za, zb)                                   # two-vector pass: the clean vector is untouched
+        assert np.array_equal(za.download(), good) and np.all(np.isnan(zb.download()[:N][present]))
+        assert np.array_equal(sh.Ax(x), good)                          # nothing sticks
+        sh.set_kernel_mode(0)
+        sh.compute_markers_statistics()
+        z0 = sh.Ax(xb)
+        # fp64 table kernels: the bad entry reaches every individual whose genotype at that marker is not missing (a missing
+        # genotype is skipped, not multiplied by 0 as in the reference) -- ~99 % of them here
+        assert np.mean(~np.isfinite(z0[:N][present])) > 0.95
+
+
+def test_huge_finite_entries_still_work(oracle):
+    """|v| up to DBL_MAX / 4 is finite input: the scale follows it (round 1 switched the kernel off above 1.7e308 / 2)."""
+    N, M = 800, 200
+    rng = np.random.default_rng(2)
+    bed = synth.synth_bed(N, M, seed=6, miss_ppm=0)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        p = np.zeros(N)
+        p[:] = rng.standard_normal(N) * 1e300
+        w = sh.ATx(p)
+        assert np.all(np.isfinite(w)) and rel(w, oracle.atx(bed, N, M, mave, msig, p)) < TOL
+
+
+def test_kernel_mode_0_warns_in_the_drivers(tmp_path):
+    N, M = 400, 300
+    bedp = str(tmp_path / "t.bed")
+    synth.write_bed(bedp, synth.synth_bed(N, M, seed=2))
+    base = [os.path.join(ROOT, "gvamp_amd", "gvamp_sim"), "--bed-file", bedp, "--N", str(N), "--Mt", str(M), "--out-dir",
+            str(tmp_path) + "/", "--out-name", "t", "--iterations", "1", "--probs", "0.9,0.1", "--vars", "0,0.01", "--CV", "10",
+            "--h2", "0.5", "--model", "linear", "--store-pvals", "0"]
+    r0 = subprocess.run(base + ["--kernel-mode", "0"], capture_output=True, text=True, timeout=300)
+    r1 = subprocess.run(base + ["--kernel-mode", "1"], capture_output=True, text=True, timeout=300)
+    assert r0.returncode == 0 and r1.returncode == 0
+    assert "--kernel-mode 0" in r0.stderr and "slower" in r0.stderr and "WARNING" not in r1.stderr

@@ -1,0 +1,240 @@
+"""The N > 1 path of the PRODUCT across process boundaries (data.cpp:928/:995, utilities.cpp:203,:259-291).
+
+* two worker PROCESSES share GPU 0, one marker shard each, joined by gv_comm_init_callback whose transport is
+  torch.distributed gloo: every collective of libgvamp (the N-vector all-reduce inside Ax, the merged two-vector message,
+  the packed CG / EM scalars) crosses a process boundary -- runs on a 1-GPU box;
+* the same two ranks over real RCCL (gv_comm_init + the file rendezvous of host/data.cpp, launched by
+  scripts/run_sharded.py) and bench.py --gpus 2 under torch.distributed.run -- when the box has >= 2 GPUs;
+* bench.py refuses a world size that does not match --gpus, and spawns its own ranks when no launcher did.
+"""
+import json
+import lzma
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "survey_probe")
+TIGHT = 1e-7
+PROBS, VARS = [0.90, 0.07, 0.03], [0, 0.001, 0.01]
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # does not initialise the GPU on this image
+
+
+WORKER = textwrap.dedent("""
+    import lzma, os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import torch, torch.distributed as dist
+    from gvamp_amd import capi, hostapi
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raw = np.frombuffer(lzma.open(%(bed)r).read(), dtype=np.uint8)[3:]
+    N, Mt = 2000, 10000
+    mb = N // 4
+    size, modu = divmod(Mt, world)
+    M = size + 1 if rank < modu else size
+    S = sum(size + 1 if r < modu else size for r in range(rank))
+    calls = [0]
+    def allreduce(a):
+        calls[0] += 1
+        dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
+    beta = np.fromfile(%(beta)r)
+    with capi.Shard(N, M, Mt=Mt, S=S, device=0) as sh:
+        sh.upload_bed(raw[S * mb:(S + M) * mb])
+        sh.set_kernel_mode(%(mode)d)
+        sh.comm_init_callback(world, rank, allreduce)
+        sh.compute_markers_statistics()
+        # y as sim.cpp makes it: A (beta sqrt(N)) + noise -- the Ax inside is already a cross-process collective
+        b, y = hostapi.sim_phen(sh, 0.5, 500, 7, rank=rank)
+        assert np.allclose(b, beta[S:S + M], rtol=1e-13, atol=0)
+        # data::Ax / ATx with the host signatures: the N-vector comes back summed over the ranks
+        x = np.random.default_rng(5).standard_normal(Mt)[S:S + M]
+        z = sh.Ax(x)
+        w = sh.ATx(z)
+        # the merged two-vector message (w_n | w_n2) and the packed scalars
+        r = hostapi.infere_linear(sh, y, %(probs)r, %(vars)r, iterations=3, CG_max_iter=20, rho=0.5, seed=7, gam1=1e-8,
+                                  gamw=2.0, true_signal=beta[S:S + M], rank=rank, fuse_solves=%(fuse)d)
+        np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), S=S, M=M, y=y, z=z, w=w, x1_3=r.x1[2], x2_1=r.x2[0],
+                 x2_3=r.x2[2], r1_3=r.r1[2], gamw=[t["gamw"] for t in r.trace], alpha2=[t["alpha2"] for t in r.trace],
+                 cg=[t["cg_iters"] for t in r.trace], calls=calls[0])
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("mode,fuse", [(1, 2), (1, 0), (0, 1)])
+def test_two_processes_one_gpu_over_gloo_vs_real_reference_np2(tmp_path, oracle, mode, fuse):
+    """Product code, two processes, gloo transport: compared with what the REAL reference wrote at mpirun -np 2 (survey
+    probe) and with the oracle's 2-shard run."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path), "bed": os.path.join(G, "toy.bed.xz"),
+                                "beta": os.path.join(G, "sim_beta_true.bin"), "mode": mode, "fuse": fuse,
+                                "probs": PROBS, "vars": VARS})
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    assert int(res[0]["S"]) == 0 and int(res[1]["S"]) == int(res[0]["M"])
+    assert all(int(r["calls"]) > 10 for r in res)                        # the transport really carried the collectives
+    # replicated quantities are bit-identical on the two ranks
+    for k in ("y", "z", "gamw", "alpha2", "cg"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    cat = lambda k: np.concatenate([r[k] for r in res])                  # noqa: E731
+    pre = os.path.join(G, "sim_np2_")
+    assert rel(cat("x2_1"), np.fromfile(pre + "it_1_x2_hat.bin")) < TIGHT
+    assert rel(cat("x1_3"), np.fromfile(pre + "it_3.bin")) < TIGHT
+    assert rel(cat("x2_3"), np.fromfile(pre + "it_3_x2_hat.bin")) < TIGHT
+    assert rel(cat("r1_3"), np.fromfile(pre + "r1_it_3.bin")) < TIGHT
+    # Ax / ATx of the sharded operator against the oracle's single-shard operator on the whole matrix
+    raw = np.frombuffer(lzma.open(os.path.join(G, "toy.bed.xz")).read(), dtype=np.uint8)[3:]
+    N, Mt = 2000, 10000
+    mave, msig = oracle.marker_stats(raw, N, Mt)
+    x = np.random.default_rng(5).standard_normal(Mt)
+    oz = oracle.ax(raw, N, Mt, mave, msig, x)
+    assert rel(res[0]["z"], oz) < 1e-12
+    assert rel(cat("w"), oracle.atx(raw, N, Mt, mave, msig, oz)) < 1e-12
+
+
+def test_empty_shard_rank_enters_the_same_collectives(tmp_path):
+    """Mt < ranks leaves a rank with M = 0 (divide_work): it must issue the same sequence of collectives as its peers
+    (one merged 2 x npad message per two-vector Ax in kernel mode 1), not a different one -- three in-process ranks, one empty."""
+    import threading
+    from gvamp_amd import capi, synth
+    N, Mt = 400, 2
+    bed = synth.synth_bed(N, Mt, seed=3)
+    mb = (N + 3) // 4
+    out, errors = [None] * 3, []
+
+    def work(rank):
+        try:
+            M, S = (1, rank) if rank < 2 else (0, 2)
+            with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+                sh.set_layout(False, True)
+                sh.set_kernel_mode(1)
+                sh.upload_bed(bed[S * mb:(S + M) * mb])
+                sh.comm_init_local(4242, 3, rank)
+                sh.compute_markers_statistics()
+                xa, xb, za, zb = sh.vecM(np.full(M, 1.0)), sh.vecM(np.full(M, -2.0)), sh.vecN(), sh.vecN()
+                sh.ax2_dev(xa, xb, za, zb)
+                v, d = sh.vecM(np.full(M, 0.5)), sh.vecM()
+                mu_a, mu_b = sh.vecM(), sh.vecM()
+                sh.cg_solve2(v, None, xa, 2.0, 1.0, 5, mu_a, mu_b)          # merged w_n | w_n2 message inside
+                out[rank] = (za.download(), zb.download(), sh.Ax(np.full(M, 1.0)))
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
+    assert not errors, errors
+    for k in range(3):
+        assert np.array_equal(out[0][k], out[1][k]) and np.array_equal(out[0][k], out[2][k])
+    assert np.allclose(out[0][1], -2.0 * out[0][0], rtol=1e-12, atol=1e-15) and np.array_equal(out[0][0], out[0][2])
+
+
+def _toy_bed(tmp_path):
+    p = tmp_path / "toy.bed"
+    p.write_bytes(lzma.open(os.path.join(G, "toy.bed.xz")).read())
+    return str(p)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs (RCCL with nranks > 1)")
+def test_rccl_two_ranks_gvamp_sim_vs_real_reference_np2(tmp_path):
+    """gvamp_sim as `mpirun -np 2`: scripts/run_sharded.py starts one process per GPU, the ranks exchange the RCCL id through
+    the file rendezvous (host/data.cpp), every collective is an ncclAllReduce over xGMI."""
+    bed = _toy_bed(tmp_path)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_sharded.py"), "-n", "2", "--master-port", str(_free_port()), "--",
+           os.path.join(ROOT, "gvamp_amd", "gvamp_sim"), "--bed-file", bed, "--N", "2000", "--Mt", "10000",
+           "--out-dir", out, "--out-name", "toy", "--iterations", "3", "--num-mix-comp", "3", "--probs", "0.90,0.07,0.03",
+           "--vars", "0,0.001,0.01", "--CV", "500", "--h2", "0.5", "--rho", "0.5", "--CG-max-iter", "20", "--model",
+           "linear", "--seed", "7", "--store-pvals", "0", "--kernel-mode", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    for name in ("it_1_x2_hat", "it_3", "it_3_x2_hat", "r1_it_3"):
+        assert rel(np.fromfile(out + "toy_%s.bin" % name), np.fromfile(os.path.join(G, "sim_np2_%s.bin" % name))) < TIGHT, name
+    assert np.allclose(np.loadtxt(out + "toy_gam1s.csv"), np.loadtxt(os.path.join(G, "sim_np2_gam1s.csv")), rtol=1e-5)
+
+
+def _bench_cmd(extra):
+    return [os.path.join(ROOT, "bench.py"), "--N", "20000", "--Mt", "60000", "--steps", "2", "--warmup", "1",
+            "--vamp-iterations", "2", "--no-cpu-baseline"] + extra
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs (RCCL with nranks > 1)")
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_gpus(launcher):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run) and started bare (it spawns its own ranks)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + _bench_cmd(["--gpus", "2"])
+    else:
+        cmd = [sys.executable] + _bench_cmd(["--gpus", "2"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["rccl_nranks"] == 2 and d["multi_gpu"]["ms_allreduce_per_ax"] > 0
+    assert len(d["multi_gpu"]["per_rank"]) == 2 and d["vamp"]["x_hat_rel_l2"] < 1e-9
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """A harness that asks for 8 GPUs must never get a 1-GPU line: under a launcher with another WORLD_SIZE bench.py
+    exits non-zero; started bare with more GPUs than the box has, its self-launch fails loudly too."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable] + _bench_cmd(["--gpus", "8"]), capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+    have = _gpu_count()
+    if have < 8:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        r = subprocess.run([sys.executable] + _bench_cmd(["--gpus", "8"]), capture_output=True, text=True, timeout=300,
+                           cwd=ROOT, env=env)
+        assert r.returncode != 0 and "GPU" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_multi_rank_plumbing_on_one_gpu():
+    """The N > 1 plumbing of bench.py (rendezvous, RCCL id broadcast, communicator, JSON fields) under torch.distributed.run
+    with one process -- what a 1-GPU box can exercise of it."""
+    env = dict(os.environ, GVAMP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + _bench_cmd(["--gpus", "1"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["multi_gpu"]["rccl_nranks"] == 1 and d["multi_gpu"]["per_rank"][0]["markers"] == 60000
