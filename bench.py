@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--cpu-markers", type=int, default=0, help="markers of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--vamp-iterations", type=int, default=5, help="VAMP iterations of the iters/s leg (0 = skip)")
     ap.add_argument("--CG-max-iter", type=int, default=50)
+    ap.add_argument("--ld-block", type=int, default=64, help="second VAMP setting: markers per LD block (0 = skip that leg)")
+    ap.add_argument("--ld-ppm", type=int, default=900000, help="second VAMP setting: within-block copy probability, 1e-6")
+    ap.add_argument("--layout", type=int, default=1, help="resident re-encoding of kernel mode 1: 1 = two stripe sets "
+                    "(2 x M*N/4 bytes), 2 = one tile layout (M*N/4 bytes)")
     ap.add_argument("--fuse-solves", type=int, default=2,
                     help="0 = the reference's sequence of matvecs, 1 = LMMSE and Onsager CG share passes (bit-identical), "
                          "2 = also z1 rides in a free slot and A x2_hat / A^T A invQ u come out of the CG recurrences")
@@ -55,11 +59,13 @@ def alg_bytes(N, M):
 
 
 def cpu_baseline(N, seed, want_markers, device):
-    """Oracle (CPU restatement, OpenMP over all host cores) timed on a bounded sample: the first `m` markers of
-    the same synthetic matrix, one Ax + one ATx."""
+    """Oracle (CPU restatement, OpenMP) timed on a bounded sample: the first `m` markers of the same synthetic matrix, one
+    Ax + one ATx per repetition, at several thread counts (all hardware threads, one per physical core, a quarter): the best is
+    `value`, every setting is listed.  A port, not the reference (unbuildable here): no credit either way is claimed from the
+    GPU / CPU ratio -- the roofline fraction is what measures the kernels."""
     from gvamp_amd import capi
     from oracle import gvoracle as go
-    cores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
     mb = (N + 3) // 4
     m = want_markers or max(256, min(20000, int(2.0e9 // mb)))
     with capi.Shard(N, m, Mt=m, S=0, device=device) as sh:
@@ -67,24 +73,29 @@ def cpu_baseline(N, seed, want_markers, device):
         sh.synth_bed(seed, 5000)
         bed = sh.download_bed()
     rng = np.random.default_rng(0)
-    t0 = time.time()
-    mave, msig = go.marker_stats(bed, N, m, nthreads=cores)
+    mave, msig = go.marker_stats(bed, N, m, nthreads=hw)
     x = rng.standard_normal(m)
-    reps, t_ax, t_atx = 0, 0.0, 0.0
-    while reps < 1 or (t_ax + t_atx < 8.0 and reps < 50):
-        t1 = time.time()
-        z = go.ax(bed, N, m, mave, msig, x, nthreads=cores)
-        t2 = time.time()
-        go.atx(bed, N, m, mave, msig, z, nthreads=cores)
-        t3 = time.time()
-        t_ax += t2 - t1
-        t_atx += t3 - t2
-        reps += 1
-    gbps = 2 * alg_bytes(N, m) * reps / (t_ax + t_atx) / 1e9
-    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port", "sample_markers": m,
-            "ax_s": t_ax / reps, "atx_s": t_atx / reps,
-            "sample": "oracle/ (OpenMP, %d threads) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix, "
-                      "%d repetitions; Ax %.3f s, ATx %.3f s per call" % (cores, m, N, reps, t_ax / reps, t_atx / reps),
+    tried = []
+    for nt in sorted({hw, max(1, hw // 2), max(1, hw // 4)}, reverse=True):
+        reps, t_ax, t_atx = 0, 0.0, 0.0
+        while reps < 1 or (t_ax + t_atx < 5.0 and reps < 30):
+            t1 = time.time()
+            z = go.ax(bed, N, m, mave, msig, x, nthreads=nt)
+            t2 = time.time()
+            go.atx(bed, N, m, mave, msig, z, nthreads=nt)
+            t3 = time.time()
+            t_ax += t2 - t1
+            t_atx += t3 - t2
+            reps += 1
+        tried.append({"threads": nt, "GBps": round(2 * alg_bytes(N, m) * reps / (t_ax + t_atx) / 1e9, 3),
+                      "ax_s": t_ax / reps, "atx_s": t_atx / reps, "reps": reps})
+    best = max(tried, key=lambda t: t["GBps"])
+    return {"value": best["GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "port", "sample_markers": m,
+            "ax_s": best["ax_s"], "atx_s": best["atx_s"], "hardware_threads": hw,
+            "thread_sweep": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()} for t in tried],
+            "sample": "oracle/ (OpenMP) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix; best of %s threads: "
+                      "%d threads, Ax %.3f s, ATx %.3f s per call (untuned scalar port; the reference itself cannot be built "
+                      "here)" % (m, N, "/".join(str(t["threads"]) for t in tried), best["threads"], best["ax_s"], best["atx_s"]),
             "cpu_model": _cpu_model()}
 
 
@@ -190,7 +201,7 @@ def main():
     M, S = divide_work(Mt, world, rank)
     sh = capi.Shard(N, M, Mt=Mt, S=S, device=local_rank)
     if a.mode == 1:
-        sh.set_layout(False, True)     # stripes only: 2 x M*N/4 bytes resident
+        sh.set_layout(False, a.layout)     # no raw rows resident: 2 x M*N/4 bytes (two stripe sets) or M*N/4 (tile layout)
     else:
         sh.set_layout(True, False)
     sh.set_kernel_mode(a.mode)
@@ -266,6 +277,8 @@ def main():
         "config": {"workload": "N=%d x Mt=%d 2-bit genotype matrix, step = lmmse_mult = Ax + N-vector all-reduce + ATx "
                                "(vamp.cpp:1074-1118)" % (N, Mt),
                    "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
+                   "resident_layout": ("fp64 raw rows" if a.mode == 0 else "two stripe sets, 2 x M*N/4 bytes" if a.layout == 1
+                                       else "one tile layout, M*N/4 bytes"),
                    "ingest_s": round(t_ingest, 2), "tune_s": round(tune_s, 3), "tune_source": tune_src},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -346,6 +359,40 @@ def main():
                 dist.all_reduce(tt)
                 num, den = float(tt[0]), float(tt[1])
             out["vamp"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
+    # ---- a harder setting beside it: block-correlated genotypes (LD), where the CG of the LMMSE step runs tens of steps -------
+    if a.vamp_iterations > 0 and a.ld_block > 0:
+        from gvamp_amd import hostapi
+        t1 = time.perf_counter()
+        sh.synth_bed(a.seed + 1, 5000, ld_block=a.ld_block, ld_ppm=a.ld_ppm)      # same shapes, same picks
+        sh.compute_markers_statistics()
+        sh.synchronize()
+        t_ld_ingest = time.perf_counter() - t1
+        CV = max(1, Mt // 100)
+        beta, y = hostapi.sim_phen(sh, 0.5, CV, 1, rank=rank)
+        barrier()
+        t1 = time.perf_counter()
+        r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5, seed=1,
+                                  gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank, fuse_solves=a.fuse_solves)
+        sh.synchronize()
+        t_total = time.perf_counter() - t1
+        its = r.trace
+        tail = its[1:] if len(its) > 1 else its
+        tot = sum(t["seconds"] for t in tail)
+        if world > 1:
+            tt = torch.tensor([tot], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tot = float(tt.item())
+        npass = sum(t["n_ax_pass"] + t["n_atx_pass"] for t in tail)
+        out["vamp_ld"] = {
+            "config": "as `vamp`, on block-correlated genotypes: LD blocks of %d markers, within-block copy probability %.2f "
+                      "(gv_synth_bed_ld; mean within-block genotype correlation ~0.6), so the CG is matvec-bound for tens of "
+                      "steps as on real data" % (a.ld_block, a.ld_ppm / 1e6),
+            "iters_per_s": round(len(tail) / tot, 4) if tot > 0 else None, "fuse_solves": a.fuse_solves,
+            "seconds_per_iter": [round(t["seconds"], 4) for t in its], "wall_s_all_iterations": round(t_total, 3),
+            "cg_iters": [t["cg_iters"] for t in its], "onsager_iters": [t["onsager_iters"] for t in its],
+            "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
+            "pass_GBps": round(npass * alg_bytes(N, Mt) / tot / 1e9, 1) if tot > 0 else None,
+            "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "ingest_s": round(t_ld_ingest, 2)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
         if "vamp" in out and len(out["vamp"]["n_ax"]) > 1:

@@ -16,7 +16,7 @@ SPACE_M, SPACE_N = 0, 1
 
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
-    "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
+    "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_synth_bed_ld", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
@@ -74,6 +74,7 @@ def load():
     L.gv_mbytes.restype = i64
     L.gv_upload_bed.argtypes = [vp, up, C.c_size_t]
     L.gv_synth_bed.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.gv_synth_bed_ld.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.gv_upload_bed_file.argtypes = [vp, C.c_char_p, i64]
     L.gv_download_bed.argtypes = [vp, up, C.c_size_t]
     L.gv_set_mask.argtypes = [vp, up, i64]
@@ -221,8 +222,11 @@ class Shard:
         off = 3 + self.S * self.mbytes if offset is None else offset
         self._ck(self.L.gv_upload_bed_file(self.h, path.encode(), off))
 
-    def synth_bed(self, seed, miss_ppm=5000):
-        self._ck(self.L.gv_synth_bed(self.h, seed, miss_ppm))
+    def synth_bed(self, seed, miss_ppm=5000, ld_block=0, ld_ppm=0):
+        if ld_block:
+            self._ck(self.L.gv_synth_bed_ld(self.h, seed, miss_ppm, ld_block, ld_ppm))
+        else:
+            self._ck(self.L.gv_synth_bed(self.h, seed, miss_ppm))
 
     def download_bed(self):
         out = np.empty(self.M * self.mbytes, dtype=np.uint8)

@@ -296,8 +296,8 @@ static std::string tune_key(gv_ctx* c) {
     std::string name = pr.name;
     for (char& ch : name) if (ch == ' ' || ch == '|') ch = '_';
     char buf[256];
-    snprintf(buf, sizeof(buf), "v%d|%s|%s|%d|%lld|%lld|", GV_TUNE_VERSION, name.c_str(), pr.gcnArchName, pr.multiProcessorCount,
-             (long long)c->N, (long long)c->M);
+    snprintf(buf, sizeof(buf), "v%d|%s|%s|%d|%lld|%lld|L%d|", GV_TUNE_VERSION, name.c_str(), pr.gcnArchName, pr.multiProcessorCount,
+             (long long)c->N, (long long)c->M, c->plan.layout);
     return buf;
 }
 // is decomposition d admissible for side (0: ATx / stripes_m, 1: Ax / stripes_n) of this context?
@@ -314,7 +314,7 @@ static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
         pieces = d.ks;
     }
     if (!(d.taper >= 0.f && d.taper < 1.f) || (d.prio != 0 && d.prio != 1)) return false;
-    return (size_t)pieces * 4 * nrg * 64 * 8 * 4 <= pl.partial_bytes;
+    return (size_t)pieces * 4 * nrg * (side ? pl.rows_n : 64) * 8 * 4 <= pl.partial_bytes;
 }
 static bool tune_cache_load(gv_ctx* c) {
     const std::string path = tune_cache_file(), key = tune_key(c);
@@ -649,9 +649,12 @@ void free_dataset(gv_ctx* c) {
         p = nullptr;
     };
     F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial); F(c->counts);
-    F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
+    F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.tiles); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
     F(c->plan.cv2); F(c->plan.ev2); F(c->plan.counters);
     F(c->plan.scal); F(c->plan.partial);
+    F(c->cgx_state); F(c->cgx_go); F(c->cgx_counters); F(c->cgx_rel);
+    c->cgx_relcap = 0;
+    if (c->cgx_pin) { (void)hipHostFree(c->cgx_pin); c->cgx_pin = nullptr; }
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
     for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p, &c->w_n2,
@@ -666,6 +669,121 @@ void free_dataset(gv_ctx* c) {
 }  // namespace gvi
 
 using namespace gvi;
+
+// Geometry of the streaming kernels for the layout that will be built (c->want_tile) and the candidate work decompositions
+// of each side.  Called by gv_set_dims and again by ingest when gv_set_layout changed the layout in between.
+static int plan_decomps(gv_ctx* c) {
+    const int64_t N = c->N, M = c->M;
+    gvm::Plan& pl = c->plan;
+    pl.M = M; pl.N = N;
+    pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
+    pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
+    pl.layout = c->want_tile ? 1 : 0;
+    pl.rows_n = 64;
+    if (c->want_tile) {   // one layout: the Ax side walks the marker-group-major super-blocks transposed
+        pl.nrg_n = pl.nkb_m;       // row groups of 256 individuals
+        pl.nkb_n = pl.nrg_m;       // K-steps of 64 markers
+        pl.rows_n = 256;
+    }
+    // K-splits.  A launch is W = ceil(nrg / 4) * ks workgroups, each walking nkb / ks K-blocks; 768 are resident at a time
+    // (256 CUs x 3).  Sweeps on MI355X (GV_KS_M / GV_KS_N overrides; N = 50k ... 400k, M = 125k ... 1M) show 2-7 % between
+    // neighbouring splits, from three effects no closed form ranks reliably: a short last round of workgroups running at
+    // their own ceiling (a workgroup keeps 32 KiB in flight, ~450 of them saturate HBM), stragglers of the last round
+    // against an emptying chip, and per-workgroup prologue / epilogue / partial sums (~40 K-blocks' worth).  So a small
+    // cost model only SHORT-LISTS three candidates here
+    //   per = nkb/ks + 40 ;  W <= 768: T = per * max(W, 448) / 768 ;  W > 768: T = per * W / 768 + straggle * per
+    // and the pick among them is MEASURED once per shard on the resident data (autotune_ks, before the first matvec).
+    // Results do not depend on the split (exact integer accumulation), so tuning never changes a bit of output.
+    auto rank_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks, double straggle, int* out3) {
+        const int64_t nq = (nrg + 3) / 4;
+        out3[0] = out3[1] = out3[2] = (int)(min_ks > 1 ? min_ks : 1);
+        if (nq <= 0 || nkb <= 0) return;
+        int64_t hi = nkb / 32 > 1 ? nkb / 32 : 1;                  // never fewer than 32 K-blocks per workgroup
+        if (hi > 64) hi = 64;
+        if (min_ks > hi) hi = min_ks;
+        double cost[3] = {0, 0, 0};
+        int n = 0;
+        for (int64_t ks = min_ks > 1 ? min_ks : 1; ks <= hi && ks <= nkb; ks++) {
+            const double per = (double)nkb / (double)ks + 40.0;
+            const int64_t W = nq * ks;
+            const double t = W <= 768 ? per * (double)(W > 448 ? W : 448) / 768.0 : per * (double)W / 768.0 + straggle * per;
+            int pos = n < 3 ? n : 3;                                // insertion into the three cheapest
+            while (pos > 0 && t < cost[pos - 1]) pos--;
+            if (pos >= 3) continue;
+            for (int j = (n < 3 ? n : 2); j > pos; j--) { cost[j] = cost[j - 1]; out3[j] = out3[j - 1]; }
+            cost[pos] = t;
+            out3[pos] = (int)ks;
+            if (n < 3) n++;
+        }
+        for (int j = n; j < 3; j++) out3[j] = out3[n > 0 ? n - 1 : 0];
+    };
+    const int64_t min_ks_n = (M * 512 + 2147483646LL) / 2147483647LL;
+    int ks3_m[3], ks3_n[3];
+    rank_ks(pl.nrg_m, pl.nkb_m, 1, 0.4, ks3_m);
+    rank_ks(pl.nrg_n, pl.nkb_n, min_ks_n, 0.8, ks3_n);
+    // balanced decomposition (k_mfma_matvec<., true>): cells per workgroup for a grid of G workgroups.  A segment is at most
+    // min(skL, nkb) K-blocks long; on the Ax side it must respect the int32 bound that min_ks_n expresses.
+    auto skL_of = [](int64_t nrg, int64_t nkb, int64_t G) -> int64_t {
+        const int64_t U = ((nrg + 3) / 4) * nkb;
+        if (U <= 0 || G <= 0) return 0;
+        const int64_t L = (U + G - 1) / G;
+        return L < 8 ? 8 : L;
+    };
+    // Candidate list per side, default first: the uniform splits in the model's order without priority, the same with
+    // priority, then balanced grids of one and two workgroups per slot (always with priority: without it the staggered
+    // workgroups of a balanced launch lose ~10 % to the arbiter's oldest-first tail).
+    int prio_only = -1;                                    // GV_PRIO=0/1 (development): restrict to one setting
+    if (const char* e = getenv("GV_PRIO")) prio_only = atoi(e) ? 1 : 0;
+    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, bool balanced_ok, std::vector<gvm::Decomp>& out) {
+        out.clear();
+        for (int prio = 0; prio < 2; prio++) {
+            if (prio_only >= 0 && prio != prio_only) continue;
+            for (int j = 0; j < 3; j++) {
+                if (j > 0 && (ks3[j] == ks3[0] || (j == 2 && ks3[2] == ks3[1]))) continue;
+                gvm::Decomp d; d.ks = ks3[j]; d.skL = 0; d.prio = prio;
+                out.push_back(d);
+            }
+        }
+        if (balanced_ok && prio_only != 0 && nkb >= 2)
+            for (int r = 1; r <= 2; r++) {
+                gvm::Decomp d; d.ks = 1; d.skL = skL_of(nrg, nkb, 768 * r); d.prio = 1;
+                if (d.skL > 0) out.push_back(d);
+            }
+    };
+    build(ks3_m, pl.nrg_m, pl.nkb_m, true, c->dec_cand_m);
+    build(ks3_n, pl.nrg_n, pl.nkb_n, min_ks_n <= 1, c->dec_cand_n);
+    c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
+    // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
+    // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
+    // first candidate
+    auto fix = [&](std::vector<gvm::Decomp>& cand, bool& fixed, gvm::Decomp d) { cand.assign(1, d); fixed = true; };
+    const float taper_env = getenv("GV_TAPER") ? (float)atof(getenv("GV_TAPER")) : 0.f;
+    if (const char* e = getenv("GV_KS_M")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= pl.nkb_m && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_m, c->ks_fixed_m, d); }
+    }
+    if (const char* e = getenv("GV_KS_N")) {
+        int v = atoi(e);
+        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_n, c->ks_fixed_n, d); }
+    }
+    if (const char* e = getenv("GV_SK_M")) {
+        gvm::Decomp d; d.skL = skL_of(pl.nrg_m, pl.nkb_m, atoi(e)); d.prio = prio_only != 0;
+        if (d.skL > 0) fix(c->dec_cand_m, c->ks_fixed_m, d);
+    }
+    if (const char* e = getenv("GV_SK_N")) {
+        gvm::Decomp d; d.skL = min_ks_n > 1 ? 0 : skL_of(pl.nrg_n, pl.nkb_n, atoi(e)); d.prio = prio_only != 0;
+        if (d.skL > 0) fix(c->dec_cand_n, c->ks_fixed_n, d);
+    }
+    if (const char* e = getenv("GV_AUTOTUNE"))
+        if (atoi(e) == 0) c->ks_fixed_m = c->ks_fixed_n = true;
+    if (c->dec_cand_m.empty()) c->dec_cand_m.assign(1, gvm::Decomp());
+    if (c->dec_cand_n.empty()) { gvm::Decomp d; d.ks = (int)(min_ks_n > 1 ? min_ks_n : 1); c->dec_cand_n.assign(1, d); }
+    pl.dm[0] = pl.dm[1] = c->dec_cand_m[0];
+    pl.dn[0] = pl.dn[1] = c->dec_cand_n[0];
+    return 0;
+}
+
+
 
 extern "C" {
 
@@ -765,105 +883,7 @@ int gv_set_dims(gv_ctx* c, int64_t N, int64_t M, int64_t Mt, int64_t S) {
     NEED(c, N * 384 < 2147483647LL, "gv_set_dims: N too large for the int32 accumulators of kernel mode 1");
     // the streaming kernel counts (quad, K-block) cells in 32 bits: M N / 65536 of them (35 TB of genotypes at the limit)
     NEED(c, ((M + 255) / 256 + 1) * ((N + 255) / 256 + 1) < 2147483647LL, "gv_set_dims: shard too large for the 32-bit cell index");
-    gvm::Plan& pl = c->plan;
-    pl.M = M; pl.N = N;
-    pl.nrg_m = (M + 63) / 64;  pl.nkb_m = (N + 255) / 256;
-    pl.nrg_n = (N + 63) / 64;  pl.nkb_n = (M + 255) / 256;
-    // K-splits.  A launch is W = ceil(nrg / 4) * ks workgroups, each walking nkb / ks K-blocks; 768 are resident at a time
-    // (256 CUs x 3).  Sweeps on MI355X (GV_KS_M / GV_KS_N overrides; N = 50k ... 400k, M = 125k ... 1M) show 2-7 % between
-    // neighbouring splits, from three effects no closed form ranks reliably: a short last round of workgroups running at
-    // their own ceiling (a workgroup keeps 32 KiB in flight, ~450 of them saturate HBM), stragglers of the last round
-    // against an emptying chip, and per-workgroup prologue / epilogue / partial sums (~40 K-blocks' worth).  So a small
-    // cost model only SHORT-LISTS three candidates here
-    //   per = nkb/ks + 40 ;  W <= 768: T = per * max(W, 448) / 768 ;  W > 768: T = per * W / 768 + straggle * per
-    // and the pick among them is MEASURED once per shard on the resident data (autotune_ks, before the first matvec).
-    // Results do not depend on the split (exact integer accumulation), so tuning never changes a bit of output.
-    auto rank_ks = [](int64_t nrg, int64_t nkb, int64_t min_ks, double straggle, int* out3) {
-        const int64_t nq = (nrg + 3) / 4;
-        out3[0] = out3[1] = out3[2] = (int)(min_ks > 1 ? min_ks : 1);
-        if (nq <= 0 || nkb <= 0) return;
-        int64_t hi = nkb / 32 > 1 ? nkb / 32 : 1;                  // never fewer than 32 K-blocks per workgroup
-        if (hi > 64) hi = 64;
-        if (min_ks > hi) hi = min_ks;
-        double cost[3] = {0, 0, 0};
-        int n = 0;
-        for (int64_t ks = min_ks > 1 ? min_ks : 1; ks <= hi && ks <= nkb; ks++) {
-            const double per = (double)nkb / (double)ks + 40.0;
-            const int64_t W = nq * ks;
-            const double t = W <= 768 ? per * (double)(W > 448 ? W : 448) / 768.0 : per * (double)W / 768.0 + straggle * per;
-            int pos = n < 3 ? n : 3;                                // insertion into the three cheapest
-            while (pos > 0 && t < cost[pos - 1]) pos--;
-            if (pos >= 3) continue;
-            for (int j = (n < 3 ? n : 2); j > pos; j--) { cost[j] = cost[j - 1]; out3[j] = out3[j - 1]; }
-            cost[pos] = t;
-            out3[pos] = (int)ks;
-            if (n < 3) n++;
-        }
-        for (int j = n; j < 3; j++) out3[j] = out3[n > 0 ? n - 1 : 0];
-    };
-    const int64_t min_ks_n = (M * 512 + 2147483646LL) / 2147483647LL;
-    int ks3_m[3], ks3_n[3];
-    rank_ks(pl.nrg_m, pl.nkb_m, 1, 0.4, ks3_m);
-    rank_ks(pl.nrg_n, pl.nkb_n, min_ks_n, 0.8, ks3_n);
-    // balanced decomposition (k_mfma_matvec<., true>): cells per workgroup for a grid of G workgroups.  A segment is at most
-    // min(skL, nkb) K-blocks long; on the Ax side it must respect the int32 bound that min_ks_n expresses.
-    auto skL_of = [](int64_t nrg, int64_t nkb, int64_t G) -> int64_t {
-        const int64_t U = ((nrg + 3) / 4) * nkb;
-        if (U <= 0 || G <= 0) return 0;
-        const int64_t L = (U + G - 1) / G;
-        return L < 8 ? 8 : L;
-    };
-    // Candidate list per side, default first: the uniform splits in the model's order without priority, the same with
-    // priority, then balanced grids of one and two workgroups per slot (always with priority: without it the staggered
-    // workgroups of a balanced launch lose ~10 % to the arbiter's oldest-first tail).
-    int prio_only = -1;                                    // GV_PRIO=0/1 (development): restrict to one setting
-    if (const char* e = getenv("GV_PRIO")) prio_only = atoi(e) ? 1 : 0;
-    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, bool balanced_ok, std::vector<gvm::Decomp>& out) {
-        out.clear();
-        for (int prio = 0; prio < 2; prio++) {
-            if (prio_only >= 0 && prio != prio_only) continue;
-            for (int j = 0; j < 3; j++) {
-                if (j > 0 && (ks3[j] == ks3[0] || (j == 2 && ks3[2] == ks3[1]))) continue;
-                gvm::Decomp d; d.ks = ks3[j]; d.skL = 0; d.prio = prio;
-                out.push_back(d);
-            }
-        }
-        if (balanced_ok && prio_only != 0 && nkb >= 2)
-            for (int r = 1; r <= 2; r++) {
-                gvm::Decomp d; d.ks = 1; d.skL = skL_of(nrg, nkb, 768 * r); d.prio = 1;
-                if (d.skL > 0) out.push_back(d);
-            }
-    };
-    build(ks3_m, pl.nrg_m, pl.nkb_m, true, c->dec_cand_m);
-    build(ks3_n, pl.nrg_n, pl.nkb_n, min_ks_n <= 1, c->dec_cand_n);
-    c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
-    // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
-    // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
-    // first candidate
-    auto fix = [&](std::vector<gvm::Decomp>& cand, bool& fixed, gvm::Decomp d) { cand.assign(1, d); fixed = true; };
-    const float taper_env = getenv("GV_TAPER") ? (float)atof(getenv("GV_TAPER")) : 0.f;
-    if (const char* e = getenv("GV_KS_M")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= pl.nkb_m && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_m, c->ks_fixed_m, d); }
-    }
-    if (const char* e = getenv("GV_KS_N")) {
-        int v = atoi(e);
-        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_n, c->ks_fixed_n, d); }
-    }
-    if (const char* e = getenv("GV_SK_M")) {
-        gvm::Decomp d; d.skL = skL_of(pl.nrg_m, pl.nkb_m, atoi(e)); d.prio = prio_only != 0;
-        if (d.skL > 0) fix(c->dec_cand_m, c->ks_fixed_m, d);
-    }
-    if (const char* e = getenv("GV_SK_N")) {
-        gvm::Decomp d; d.skL = min_ks_n > 1 ? 0 : skL_of(pl.nrg_n, pl.nkb_n, atoi(e)); d.prio = prio_only != 0;
-        if (d.skL > 0) fix(c->dec_cand_n, c->ks_fixed_n, d);
-    }
-    if (const char* e = getenv("GV_AUTOTUNE"))
-        if (atoi(e) == 0) c->ks_fixed_m = c->ks_fixed_n = true;
-    if (c->dec_cand_m.empty()) c->dec_cand_m.assign(1, gvm::Decomp());
-    if (c->dec_cand_n.empty()) { gvm::Decomp d; d.ks = (int)(min_ks_n > 1 ? min_ks_n : 1); c->dec_cand_n.assign(1, d); }
-    pl.dm[0] = pl.dm[1] = c->dec_cand_m[0];
-    pl.dn[0] = pl.dn[1] = c->dec_cand_n[0];
+    if (plan_decomps(c)) return 1;
     return gv_set_mask(c, nullptr, N);
 }
 
@@ -871,7 +891,8 @@ int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 
 // Ingest: fills the resident layouts chunk by chunk (markers [m0, m0+mc), m0 % 256 == 0) so that the raw rows never
 // have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
-static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr, FILE* file = nullptr) {
+static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr, FILE* file = nullptr,
+                  uint32_t ld_block = 0, uint32_t ld_thr = 0) {
     NEED(c, c->N > 0, "ingest: gv_set_dims must be called first");
     NEED(c, c->want_raw || c->want_stripes, "ingest: gv_set_layout disabled both layouts");
     HIPCHK(c, hipSetDevice(c->device));
@@ -880,10 +901,20 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     c->have_raw = c->have_stripes = c->have_stats = false;
     if (c->want_raw && !c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(M > 0 ? M : 1) * P));
     if (!c->want_raw && c->bed) { (void)hipFree(c->bed); c->bed = nullptr; }
-    if (c->want_stripes && !pl.stripes_m) {
+    const int want_layout = c->want_tile ? 1 : 0;
+    if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
+        // (re)build the geometry and the buffers of the MFMA family for the layout asked for
+        for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
+                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.counters, (void**)&pl.scal, (void**)&pl.partial})
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+        if (plan_decomps(c)) return 1;
         const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
-        HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
-        HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
+        if (want_layout) {
+            HIPCHK(c, hipMalloc(&pl.tiles, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
+        } else {
+            HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
+            HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
+        }
         HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
@@ -902,42 +933,65 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             return k;
         };
         const int km = pieces(c->dec_cand_m, pl.nkb_m), kn = pieces(c->dec_cand_n, pl.nkb_n);
-        size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * 64 * 8 * 4;
+        size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * pl.rows_n * 8 * 4;
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
-    const int64_t CH = file ? 8192 : 32768;   // file source: the pinned staging buffer is CH * mbytes bytes
+    const int64_t CH = file ? 8192 : 32768;   // file source: each pinned staging buffer is CH * mbytes bytes
     uint8_t* tmp = nullptr;
-    uint8_t* stage = nullptr;
-    if (file) HIPCHK(c, hipHostMalloc(&stage, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * c->mbytes));
+    uint8_t* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+    // File source: two pinned staging buffers, so that reading chunk k + 1 from the file system overlaps the PCIe copy and the
+    // re-encoding kernels of chunk k (the stream serialises the device side; an event per buffer says when its copy has left)
+    for (int b = 0; b < 2 && file; b++) {
+        HIPCHK(c, hipHostMalloc(&stage[b], (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * c->mbytes));
+        HIPCHK(c, hipEventCreateWithFlags(&stage_free[b], hipEventDisableTiming));
+    }
     if (!c->want_raw) HIPCHK(c, hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P));
     int rc = 0;
-    for (int64_t m0 = 0; m0 < M && !rc; m0 += CH) {
+    int64_t chunk = 0;
+    for (int64_t m0 = 0; m0 < M && !rc; m0 += CH, chunk++) {
         const int64_t mc = M - m0 < CH ? M - m0 : CH;
         uint8_t* rawp = c->want_raw ? c->bed + m0 * P : tmp;
         hipError_t e = hipSuccess;
+        const int sb = (int)(chunk & 1);
         if (synth) {
-            gvk::synth_bed(c->stream, rawp, mc, c->S + m0, c->N, P, seed, miss_thr);
+            gvk::synth_bed(c->stream, rawp, mc, c->S + m0, c->N, P, seed, miss_thr, ld_block, ld_thr);
         } else {
-            const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage;
-            if (file && fread(stage, 1, (size_t)mc * c->mbytes, file) != (size_t)mc * c->mbytes) {
-                rc = fail(c, "ingest: short read on the .bed file at marker %lld", (long long)(c->S + m0));
-                break;
+            const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage[sb];
+            if (file) {
+                if (chunk >= 2) e = hipEventSynchronize(stage_free[sb]);      // the copy of chunk - 2 has left this buffer
+                if (e == hipSuccess && fread(stage[sb], 1, (size_t)mc * c->mbytes, file) != (size_t)mc * c->mbytes) {
+                    rc = fail(c, "ingest: short read on the .bed file at marker %lld", (long long)(c->S + m0));
+                    break;
+                }
             }
-            e = hipMemsetAsync(rawp, 0, (size_t)mc * P, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(rawp, 0, (size_t)mc * P, c->stream);
             if (e == hipSuccess)
                 e = hipMemcpy2DAsync(rawp, P, src, c->mbytes, c->mbytes, mc, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess && file) e = hipEventRecord(stage_free[sb], c->stream);
         }
-        if (e == hipSuccess && c->want_stripes) {
+        if (e == hipSuccess && c->want_stripes && pl.layout == 1)
+            gvm::tile_chunk(c->stream, rawp, P, mc, c->N, pl.tiles, m0 / 64, pl.nkb_m);
+        else if (e == hipSuccess && c->want_stripes) {
             gvm::stripes_m_chunk(c->stream, rawp, P, mc, c->N, pl.stripes_m, m0 / 64, pl.nkb_m);
             gvm::stripes_n_chunk(c->stream, rawp, P, mc, c->N, pl.stripes_n, m0 / 256, pl.nkb_n, pl.nrg_n);
         }
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        // a caller-owned pageable host buffer (gv_upload_bed) and the synthetic source have nothing to overlap: keep the
+        // launch queue short; the file source runs ahead by one chunk
+        if (e == hipSuccess && !file) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(c, "ingest chunk at marker %lld failed: %s", (long long)m0, hipGetErrorString(e));
     }
+    {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && !rc) rc = fail(c, "ingest failed: %s", hipGetErrorString(e));
+    }
+    for (int b = 0; b < 2; b++) {
+        if (stage[b]) (void)hipHostFree(stage[b]);
+        if (stage_free[b]) (void)hipEventDestroy(stage_free[b]);
+    }
     if (tmp) (void)hipFree(tmp);
-    if (stage) (void)hipHostFree(stage);
     if (rc) return rc;
     c->have_raw = c->want_raw;
     c->have_stripes = c->want_stripes;
@@ -946,8 +1000,10 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
 
 int gv_set_layout(gv_ctx* c, int raw_rows, int stripes) {
     NEED(c, raw_rows || stripes, "gv_set_layout: at least one layout is required");
+    NEED(c, stripes >= 0 && stripes <= 2, "gv_set_layout: stripes is 0 (none), 1 (two stripe sets) or 2 (one tile layout)");
     c->want_raw = raw_rows != 0;
     c->want_stripes = stripes != 0;
+    c->want_tile = stripes == 2;
     return 0;
 }
 
@@ -974,6 +1030,14 @@ int gv_synth_bed(gv_ctx* c, uint64_t seed, uint32_t miss_ppm) {
     NEED(c, c->N > 0, "gv_synth_bed: gv_set_dims must be called first");
     uint32_t thr = (uint32_t)(((uint64_t)miss_ppm << 32) / 1000000ull);
     return ingest(c, nullptr, true, seed, thr);
+}
+
+int gv_synth_bed_ld(gv_ctx* c, uint64_t seed, uint32_t miss_ppm, uint32_t ld_block, uint32_t ld_ppm) {
+    NEED(c, c->N > 0, "gv_synth_bed_ld: gv_set_dims must be called first");
+    NEED(c, ld_ppm <= 1000000, "gv_synth_bed_ld: ld_ppm is a probability in 1e-6");
+    const uint32_t thr = (uint32_t)(((uint64_t)miss_ppm << 32) / 1000000ull);
+    const uint64_t lt = ((uint64_t)ld_ppm << 32) / 1000000ull;
+    return ingest(c, nullptr, true, seed, thr, nullptr, ld_block, (uint32_t)(lt > 0xFFFFFFFFull ? 0xFFFFFFFFull : lt));
 }
 
 int gv_download_bed(gv_ctx* c, uint8_t* bed, size_t nbytes) {
@@ -1003,7 +1067,10 @@ int gv_set_mask(gv_ctx* c, const uint8_t* mask4, int64_t nonas) {
 
 int gv_marker_stats(gv_ctx* c, double alpha_scale) {
     NEED(c, (c->have_raw || c->have_stripes) && c->mask2, "gv_marker_stats: bed and mask must be set first");
-    if (c->have_stripes && (c->kernel_mode == 1 || !c->have_raw))
+    if (c->have_stripes && c->plan.layout == 1 && (c->kernel_mode == 1 || !c->have_raw))
+        gvm::stats_from_tiles(c->stream, c->plan.tiles, c->mask2, c->M, c->plan.nrg_m, c->plan.nkb_m, c->pitch / 4,
+                              (double)c->nonas, alpha_scale, c->mave, c->msig, c->counts);
+    else if (c->have_stripes && (c->kernel_mode == 1 || !c->have_raw))
         gvm::stats_from_stripes(c->stream, c->plan.stripes_m, c->mask2, c->M, c->plan.nkb_m, c->pitch / 4,
                                 (double)c->nonas, alpha_scale, c->mave, c->msig, c->counts);
     else
@@ -1468,8 +1535,8 @@ int gv_read_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {
     void* buf = nullptr;
     bool own = false;
     size_t have = 0;
-    if (c->have_stripes && c->plan.stripes_m) {
-        buf = c->plan.stripes_m;
+    if (c->have_stripes && (c->plan.stripes_m || c->plan.tiles)) {
+        buf = c->plan.layout == 1 ? c->plan.tiles : c->plan.stripes_m;
         have = (size_t)c->plan.nrg_m * c->plan.nkb_m * 4096;
     }
     if (have < (size_t)64 << 20) {

@@ -41,6 +41,7 @@ struct gv_ctx {
     bool have_stats = false;
     int kernel_mode = 0;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
     bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
+    bool want_tile = false;                      // the MFMA family's layout: false = two stripe sets, true = one tile layout
     bool have_raw = false, have_stripes = false;
     gvm::Plan plan;
     // candidate work decompositions of the ATx-side / Ax-side streaming kernels (default first) and whether the on-device
@@ -64,6 +65,14 @@ struct gv_ctx {
     unsigned long long mbox_seq = 0;
     bool use_mbox = false;
     void* xfer_pin = nullptr;      // 4 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
+    // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` flag, 4 ticket counters,
+    // residual traces (2 x cgx_relcap doubles), a pinned staging block for the initial states
+    double* cgx_state = nullptr;
+    int* cgx_go = nullptr;
+    unsigned int* cgx_counters = nullptr;
+    double* cgx_rel = nullptr;
+    int cgx_relcap = 0;
+    double* cgx_pin = nullptr;
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
     gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
     gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
@@ -101,7 +110,7 @@ struct gv_prior {
 // ---- kernel launchers (gv_kernels.hip) -----------------------------------------------------------
 namespace gvk {
 void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
-               uint32_t miss_thr);
+               uint32_t miss_thr, uint32_t ld_block = 0, uint32_t ld_thr = 0);
 void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
                   double alpha_scale, double* mave, double* msig, uint32_t* counts);
 void marker_sums2_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p1, const double* p2,
@@ -132,6 +141,13 @@ void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mas
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
 void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
           double* out);
+// device-resident CG step (gv_solvers.hip: cg_run_device)
+void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
+            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
+            double* const* red, double diag, int64_t n, unsigned int* counters);
+void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
+void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,
                double* partial, double* out);                 // mu += alpha p ; out[0] = <v, mu>
 void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double diag, double* z, const double* mu,
@@ -167,6 +183,7 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
                 const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
 int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out);
+int autotune_ks(gv_ctx* c);     // picks the work decompositions of the streaming kernels (once per shard)
 
 struct Timer {
     gv_ctx* c;

@@ -41,8 +41,12 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // ---- synthetic shard (SURVEY 8d recipe, integer-only so the host generator matches bit for bit) ---------
 // marker g (global index): maf = (3277 + h % 29491) / 65536 in [0.05, 0.5); genotype ~ Binomial(2, maf);
 // missing with probability miss_thr / 2^32.  Codes: 2 -> 00, 1 -> 10, 0 -> 11, missing -> 01.
+// Linkage disequilibrium (ld_block > 0): the markers of a block of ld_block consecutive markers share, per individual, one
+// latent uniform; each genotype takes it with probability ld_thr / 2^32 instead of its own draw and pushes it through the
+// marker's own allele-frequency thresholds -- co-monotone genotypes inside a block, independent blocks (block-correlated
+// columns: what makes the CG of the LMMSE step run tens of iterations on real genotypes).
 __global__ void k_synth_bed(uint32_t* bed, int64_t M, int64_t S, int64_t N, int64_t P4, uint64_t seed,
-                            uint32_t miss_thr) {
+                            uint32_t miss_thr, uint32_t ld_block, uint32_t ld_thr) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * P4) return;
     int64_t m = idx / P4, j = idx % P4;
@@ -53,12 +57,17 @@ __global__ void k_synth_bed(uint32_t* bed, int64_t M, int64_t S, int64_t N, int6
     uint32_t p0 = qv * qv;              // P(geno 0) * 2^32  (qv <= 62259 -> fits)
     uint32_t p1 = 2u * maf * qv;        // P(geno 1) * 2^32
     uint64_t base = splitmix64(hm + 0x632BE59BD9B4E019ull);
+    const uint64_t lbase = ld_block ? splitmix64(seed ^ ((g / ld_block) * 0xA24BAED4963EE407ull) ^ 0x5851F42D4C957F2Dull) : 0;
     uint32_t w = 0;
     for (int q = 0; q < 16; q++) {
         int64_t n = 16 * j + q;
         if (n >= N) break;
         uint64_t r = splitmix64(base + (uint64_t)n);
         uint32_t u = (uint32_t)(r >> 32), um = (uint32_t)r;
+        if (ld_block) {
+            const uint64_t rs = splitmix64(r ^ 0x9FB21C651E98DF25ull);
+            if ((uint32_t)(rs >> 32) < ld_thr) u = (uint32_t)(splitmix64(lbase + (uint64_t)n) >> 32);
+        }
         uint32_t code;
         if (um < miss_thr) code = 1u;
         else if (u < p0) code = 3u;
@@ -496,6 +505,139 @@ __global__ __launch_bounds__(256) void k_cg_b(double* __restrict__ r, const doub
     }
 }
 
+// ---- device-resident CG step (gv_solvers.hip: cg_run_device) ------------------------------------------------------------
+// One launch for every still-active system (blockIdx.y): alpha = <r,z> / <d,p> from the system's state block and the reduced
+// <d,p> the ATx epilogue left, then k_cg_a and k_cg_b in one sweep -- mu += alpha p, r -= alpha d, z = r / diag -- with the
+// block partials of <v,mu>, <r,z>, <r,r>; the block that takes the last ticket adds them up in the fixed order of k_finalize
+// (red[v][0..2]).  (The reference leaves r one step behind on an Onsager-rule exit, vamp.cpp:1176-1193; here r is always
+// current, which is what the by-products of gv_cg_solve2x want and nobody else reads.)
+struct CgxAB {
+    double* st[2]; double* mu[2]; const double* p[2]; const double* v[2]; double* r[2]; const double* d[2]; double* z[2];
+    const double* dp[2]; double* part[2]; double* red[2];
+};
+__global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n, unsigned int* __restrict__ counters) {
+    __shared__ double sh[256];
+    __shared__ bool is_last;
+    const int v = blockIdx.y;
+    double* st = a.st[v];
+    if (st[gvm::ST_ACTIVE] == 0.0) return;
+    const double alpha = st[gvm::ST_RZ] / a.dp[v][0];                    // vamp.cpp:1167
+    double* __restrict__ mu = a.mu[v];
+    const double* __restrict__ p = a.p[v];
+    const double* __restrict__ vv = a.v[v];
+    double* __restrict__ r = a.r[v];
+    const double* __restrict__ d = a.d[v];
+    double* __restrict__ z = a.z[v];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double s_vmu = 0, s_rz = 0, s_rr = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        double palpha = alpha * p[i];
+        double m = mu[i] + palpha;
+        mu[i] = m;
+        s_vmu += vv[i] * m;
+        double ri = r[i];
+        ri -= d[i] * alpha;
+        double zi = ri / diag;
+        r[i] = ri;
+        z[i] = zi;
+        s_rz += ri * zi;
+        s_rr += ri * ri;
+    }
+    s_vmu = block_sum_256(s_vmu, sh);
+    s_rz = block_sum_256(s_rz, sh);
+    s_rr = block_sum_256(s_rr, sh);
+    if (threadIdx.x == 0) {
+        double* o = a.part[v] + (int64_t)blockIdx.x * 3;
+        o[0] = s_vmu; o[1] = s_rz; o[2] = s_rr;
+        __threadfence();
+        const unsigned int t = atomicAdd(counters + v, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) counters[v] = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x == 0) st[gvm::ST_ALPHA] = alpha;                      // for A mu += alpha A p (k_axpy_st)
+    for (int k = 0; k < 3; k++) {
+        double acc = 0.0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+            acc += __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(a.part[v] + (int64_t)b * 3 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.red[v][k] = sh[0];
+    }
+}
+// y += st[ST_ALPHA] * x while the system is active (A mu accumulated from the A p_k, gv_cg_extras.a_mu_a)
+__global__ void k_axpy_st(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ st, int64_t n) {
+    if (st[gvm::ST_ACTIVE] == 0.0) return;
+    const double alpha = st[gvm::ST_ALPHA];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+// The scalar part of a CG step (vamp.cpp:1174-1223) for every system, on the device: iteration count, Onsager rule, beta,
+// <r,z>, relative residual and its trace, stopping rules; then *go = some system is still running, and the status of every
+// system goes to the host mailbox (slot = seq & 1: the host reads status s while the device may already write s + 1).
+struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; };
+constexpr int CGX_STATUS = 8;   // doubles per system in the mailbox: active, iters, converged, rel_err, onsager, n_relres, stepped
+__global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
+                             unsigned long long* flag, unsigned long long seq) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const int v = threadIdx.x;
+    if (v < a.nsys) {
+        double* st = a.st[v];
+        if (st[gvm::ST_ACTIVE] != 0.0) {
+            const double* q = a.red[v];                 // <v,mu>, <r,z>, <r,r>
+            const int iters = (int)st[gvm::ST_ITERS] + 1;
+            st[gvm::ST_ITERS] = (double)iters;
+            bool stepping = true;
+            if (st[gvm::ST_DENOISER] == 0.0) {          // :1174-1193
+                const double ons = gam2 * q[0], prev = st[gvm::ST_PREV_ONS];
+                const double oerr = (ons != 0) ? fabs((ons - prev) / ons) : 1.0;
+                st[gvm::ST_ONS] = ons;
+                if (oerr < 1e-8) {
+                    st[gvm::ST_CONV] = 1.0;
+                    st[gvm::ST_ACTIVE] = 0.0;
+                    stepping = false;
+                }
+                st[gvm::ST_PREV_ONS] = ons;
+            }
+            if (stepping) {
+                st[gvm::ST_BETA] = q[1] / st[gvm::ST_RZ];   // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
+                st[gvm::ST_RZ] = q[1];
+                const double rel = sqrt(q[2]) / st[gvm::ST_NORMV];   // :1215
+                st[gvm::ST_RELERR] = rel;
+                if (a.relres[v]) a.relres[v][iters - 1] = rel;
+                st[gvm::ST_NRELRES] = (double)iters;
+                if (rel < 1e-5) {                       // :1217,:1222
+                    st[gvm::ST_CONV] = 1.0;
+                    st[gvm::ST_ACTIVE] = 0.0;
+                } else if (iters >= max_iter)
+                    st[gvm::ST_ACTIVE] = 0.0;
+            }
+            st[gvm::ST_STEPPED] = stepping ? 1.0 : 0.0;
+        } else
+            st[gvm::ST_STEPPED] = 0.0;
+        if (st[gvm::ST_ACTIVE] != 0.0) atomicOr(&any, 1);
+        double* mb = mailbox + (seq & 1ull) * (2 * CGX_STATUS) + v * CGX_STATUS;
+        mb[0] = st[gvm::ST_ACTIVE]; mb[1] = st[gvm::ST_ITERS]; mb[2] = st[gvm::ST_CONV]; mb[3] = st[gvm::ST_RELERR];
+        mb[4] = st[gvm::ST_ONS]; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *go = any;
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // vamp::g1 / g1d (vamp.cpp:805-869), same operation order per element
 __device__ __forceinline__ void g1_g1d(double y, double gam1, const gv_prior& pr, double eta_max, double& g1,
                                        double& g1d) {
@@ -690,11 +832,11 @@ inline int red_blocks(int64_t n, int bs) {
 namespace gvk {
 
 void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
-               uint32_t miss_thr) {
+               uint32_t miss_thr, uint32_t ld_block, uint32_t ld_thr) {
     int64_t P4 = pitch / 4, tot = M * P4;
     if (tot == 0) return;
     hipLaunchKernelGGL(k_synth_bed, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (uint32_t*)bed, M, S, N, P4,
-                       seed, miss_thr);
+                       seed, miss_thr, ld_block, ld_thr);
 }
 
 void marker_stats(hipStream_t s, const uint8_t* bed, const uint32_t* mask2, int64_t M, int64_t pitch, double nonas,
@@ -807,6 +949,27 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_dots, dim3(nb), dim3(256), 0, s, a, K, n, partial);
     hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
+}
+
+void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
+            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
+            double* const* red, double diag, int64_t n, unsigned int* counters) {
+    CgxAB a{};
+    for (int k = 0; k < nsys; k++) {
+        a.st[k] = st[k]; a.mu[k] = mu[k]; a.p[k] = p[k]; a.v[k] = v[k]; a.r[k] = r[k]; a.d[k] = d[k]; a.z[k] = z[k];
+        a.dp[k] = dp[k]; a.part[k] = part[k]; a.red[k] = red[k];
+    }
+    hipLaunchKernelGGL(k_cgx_ab, dim3(red_blocks(n, 256), nsys), dim3(256), 0, s, a, diag, n, counters);
+}
+void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n) {
+    hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
+}
+void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq) {
+    CgxDecide a{};
+    a.nsys = nsys;
+    for (int k = 0; k < nsys; k++) { a.st[k] = st[k]; a.red[k] = red[k]; a.relres[k] = relres[k]; }
+    hipLaunchKernelGGL(k_cgx_decide, dim3(1), dim3(64), 0, s, a, gam2, max_iter, go, mailbox, flag, seq);
 }
 
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n, double* partial,

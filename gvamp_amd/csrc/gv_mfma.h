@@ -13,6 +13,24 @@ struct Decomp {
                          // workgroups dispatched last (the last segment) are the shortest and the launch's tail is short
 };
 
+// ---- device-resident CG (gv_solvers.hip, cg_run_device) ------------------------------------------------------------
+// State block of one CG system in device memory (doubles).  The kernels of a CG step read alpha / beta / the activity
+// flags from it, so a step is enqueued without the host knowing the scalars of the previous one.
+enum { ST_RZ = 0, ST_ALPHA, ST_BETA, ST_NORMV, ST_PREV_ONS, ST_ONS, ST_RELERR, ST_ACTIVE, ST_ITERS, ST_CONV, ST_NRELRES,
+       ST_DENOISER, ST_STEPPED, ST_SIZE = 16 };
+// What a pass over the shard needs to know when it is one half of a CG step.  Slot v = vector v of the pass.
+struct CgHook {
+    const int* go = nullptr;                 // the pass kernels return at once when *go == 0 (every system has finished)
+    const double* state[2] = {nullptr, nullptr};   // slot v is CG system state[v]; NULL: not a CG system (a rider)
+    // Ax side (k_prep_ax): the search direction is advanced on the way in, p <- z + beta p, when the system stepped
+    double* p[2] = {nullptr, nullptr};
+    const double* z[2] = {nullptr, nullptr};
+    // ATx side (k_fin_atx_dot): <out, addx> = <Q p, p>, block partials + ordered finish by the last block -> dot_out[v][0]
+    double* dot_part[2] = {nullptr, nullptr};
+    double* dot_out[2] = {nullptr, nullptr};
+    unsigned int* dot_counters = nullptr;    // 2 ticket counters, zero between launches
+};
+
 struct Plan {
     int64_t M = 0, N = 0;
     int64_t nrg_m = 0, nkb_m = 0;   // stripes_m: row groups of 64 markers x K-blocks of 256 individuals
@@ -22,6 +40,12 @@ struct Plan {
     Decomp dm[2], dn[2];
     void* stripes_m = nullptr;
     void* stripes_n = nullptr;
+    // layout 1 ("tile", gv_set_layout(.., 2)): ONE resident re-encoding, 64 markers x 256 individuals per 4 KiB super-block,
+    // serves both products (gv_mfma.hip).  Then nrg_m / nkb_m describe it (marker groups x individual blocks) and the Ax
+    // side walks it transposed: nrg_n = nkb_m row groups of rows_n = 256 individuals, nkb_n = nrg_m K-steps of 64 markers.
+    void* tiles = nullptr;
+    int layout = 0;
+    int rows_n = 64;                // rows per row group on the Ax side
     void* dig0 = nullptr;           // digit buffers, max(nkb_m, nkb_n) * 2048 bytes each
     void* dig1 = nullptr;
     double* cv = nullptr;           // M doubles: c = msig * x
@@ -39,6 +63,9 @@ void stripes_m_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t m
                      int64_t rg0, int64_t nkb);
 void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* stripes,
                      int64_t kb0, int64_t nkb, int64_t nrg_n);
+void tile_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* tiles, int64_t rg0, int64_t nkb);
+void stats_from_tiles(hipStream_t s, const void* tiles, const uint32_t* mask2, int64_t M, int64_t nrg, int64_t nkb, int64_t P4,
+                      double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts);
 // counts (may be NULL): 3 per marker = present individuals with a = 2, 1, 0
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
                         int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts);
@@ -49,18 +76,20 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
 // addx != NULL: out = tau * ATx(p) + gam2 * addx, the whole of vamp::lmmse_mult's epilogue (vamp.cpp:1112-1116)
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
          double inv_sqrt_n, double* red_partial, double* out, const double* addx = nullptr, double tau = 1.0,
-         double gam2 = 0.0);
+         double gam2 = 0.0, const CgHook* cg = nullptr);
 // out[npad] = mask * (A~ x) * post   (post = 1/sqrt(N), or 1 when a cross-rank all-reduce follows)
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
-        int64_t npad, double post, double* red_partial, double* out);
+        int64_t npad, double post, double* red_partial, double* out, const CgHook* cg = nullptr);
 
 // two vectors per pass (the LMMSE and the Onsager CG of one VAMP iteration share the operator, vamp.cpp:593-596,:884)
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb,
-          const double* addxa = nullptr, const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
+          const double* addxa = nullptr, const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0,
+          const CgHook* cg = nullptr);
 void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, const double* msig, const uint32_t* mask2,
                int64_t npad, double* red_partial, double* out);
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
-         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb);
+         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb,
+         const CgHook* cg = nullptr);
 
 }  // namespace gvm

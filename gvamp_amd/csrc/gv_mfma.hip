@@ -216,18 +216,30 @@ constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per v
 
 // Ax operands: c = msig*x, e = (mave-3)*c  (out = sum r' c + sum miss e - K0, K0 = sum mave*c).  blockIdx.y = vector.
 // block partials: [0] = max(|c|,|e|), [1] = sum mave*c
-struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; };
+// CG hook (device-resident CG): x is the search direction p of system st; when that system took a step and is still
+// running, p <- z + beta p (vamp.cpp:1209-1210) happens here, on the way into the operands, instead of in a launch of its own.
+struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2]; };
 __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
                                                  int64_t M, double* __restrict__ partial, double* __restrict__ scal,
                                                  unsigned int* __restrict__ counters) {
     __shared__ double shm[256], shs[256];
     const int v = blockIdx.y;
-    const double* __restrict__ x = a.x[v];
+    const double* x = a.x[v];
     double* __restrict__ cv = a.cv[v];
     double* __restrict__ ev = a.ev[v];
+    const double* st = a.st[v];
+    const bool upd = st && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;
+    const double beta = upd ? st[gvm::ST_BETA] : 0.0;
+    const double* zz = a.z[v];
+    double* pw = a.pw[v];
     double mx = 0.0, s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
-        double c = msig[i] * x[i], mu = mave[i];
+        double xi = x[i];
+        if (upd) {
+            xi = zz[i] + beta * xi;
+            pw[i] = xi;
+        }
+        double c = msig[i] * xi, mu = mave[i];
         double e = (mu - 3.0) * c;
         cv[i] = c;
         ev[i] = e;
@@ -409,9 +421,9 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg; P = 2 (MODE 0: sum r' p, sum miss p),
 // 4 (MODE 2: planes 2v, 2v+1 belong to vector v), 1 (MODE 1, 4: the two products already added) or 2 (MODE 3: plane v = vector v); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
 // workgroups that touch a quad are consecutive).  pieces_of() below is the count the epilogue kernels sum over.
-__device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL) {
+__device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL, int qshift = 8) {
     if (skL <= 0) return ksplit;
-    const int64_t q = row >> 8;
+    const int64_t q = row >> qshift;   // rows per quad of row groups: 256 (64-row groups) or 1024 (tile layout, Ax side)
     return (int)(((q + 1) * nkb - 1) / skL - (q * nkb) / skL + 1);
 }
 
@@ -425,7 +437,10 @@ struct KBounds { uint32_t b[GV_MAX_KS + 1]; };
 template <int MODE, bool SK>
 __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                  const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
-                                                 int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial) {
+                                                 int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial,
+                                                 const int* __restrict__ go) {
+    // device-resident CG: a step enqueued before the host knew that every system had converged is dropped here
+    if (go && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
     constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
     __shared__ u32x4 sB[2][SS];
@@ -638,6 +653,385 @@ extern "C" int gv_debug_wgtime(unsigned long long* out, int n) {
 namespace {
 #endif
 
+// =====================================================================================================================
+// ONE resident layout for both products ("tile" layout, kernel mode 2): M N / 4 bytes instead of 2 x M N / 4.
+//
+// The MFMA contracts over the bytes a lane holds, so a layout serves a product only if, after the 2-bit -> byte expansion,
+// the bytes of an operand register run along that product's K.  The expansion (w >> 2s) & 0x03030303 turns bit pair s of
+// every byte into a byte: bytes keep their meaning, bit pairs become the register index.  Pack a dword as a 4 x 4 block
+//     D(q, j) : byte t <-> marker 4q + t,  bit pair s <-> individual 4j + s
+// and  * Ax  (K = markers)     is native: (D >> 2s) & mask = 4 consecutive markers (bytes = K) of individual 4j + s;
+//      * ATx (K = individuals) needs bytes along individuals: a 4 x 4 BYTE transpose of the four dwords D(q, 4J..4J+3) a lane
+//        holds (8 v_perm_b32) gives T[t] = marker 4q + t, byte d <-> individuals 16J + 4d + (bit pair), which is exactly the
+//        1 x 16 packing the two-layout kernel expands.  +2 VALU per dword (13 instead of 11), nothing else.
+// Memory: super-block SB(RG, KB) = 64 markers x 256 individuals = 4 KiB at ((RG nkb + KB) 4 KiB): 16 marker quads
+// (q_local) x 16 individual groups of 16 (J_local), as four 1 KiB blocks JB = J_local >> 2, each ordered
+// [q_local][J_local & 3] in 16-byte pieces P(q, J) = D(q, 4J .. 4J+3).
+//   ATx wave, load i = block JB = i: lane (r, g) takes P(q_local = r, J_local = 4i + g)      -- the whole KiB, lanes permuted
+//   Ax  wave, load i: lane (rho, gam) takes P(q_local = 4i + gam, J_local = rho)            -- 256 contiguous bytes of each block
+// so both directions consume a super-block with four wave-wide 16-byte loads that touch only whole 128-byte lines.
+// ATx: 4 row tiles t (marker 4 q + t) x K = 64 individuals per load, digits in the order of k_quant (element g*64 + i*16 + c).
+// Ax: 16 row tiles (d, s) (individual 16 rho + 4 d + s) x K = 64 markers per super-block; operand register i comes from
+// load i; the r' plane multiplies dig0 = [c_a | c_b], the missing plane dig1 = [e_a | e_b], both into ONE accumulator per
+// tile (64 accumulator registers); digits in the order of k_quant_t.  A one-vector Ax is the two-vector pass with nv = 1.
+// All sums are the same integers as in the two-layout kernels: results are bit-identical.
+struct ABufT { u32x4 t[4]; };
+
+template <int DIR>   // 0: ATx side (rows = markers), 1: Ax side (rows = individuals)
+__device__ __forceinline__ void load_t(ABufT& a, const u32x4* __restrict__ sb, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int off = (DIR == 0) ? i * 64 + r * 4 + g : (r >> 2) * 64 + (4 * i + g) * 4 + (r & 3);
+        a.t[i] = __builtin_nontemporal_load(sb + off);
+    }
+}
+
+// ATx side, one K-block (256 individuals): per load i a byte transpose, then 4 tiles x (r' plane, missing plane)
+template <int MODE>   // 0: one vector (8 digit columns, lanes c >= 8 alias), 2: two vectors
+__device__ __forceinline__ void compute_atx_t(const ABufT& a, const u32x4* sb, int lane, v4i (&accX)[4], v4i (&accY)[4]) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32x4 bq = (MODE == 0) ? sb[g * 32 + i * 8 + (c & 7)] : sb[g * 64 + i * 16 + c];
+        const v4i B = {(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w};
+        const uint32_t L0 = a.t[i].x, L1 = a.t[i].y, L2 = a.t[i].z, L3 = a.t[i].w;
+        const uint32_t a0 = __builtin_amdgcn_perm(L1, L0, 0x05010400u), a1 = __builtin_amdgcn_perm(L1, L0, 0x07030602u);
+        const uint32_t b0 = __builtin_amdgcn_perm(L3, L2, 0x05010400u), b1 = __builtin_amdgcn_perm(L3, L2, 0x07030602u);
+        const uint32_t T[4] = {__builtin_amdgcn_perm(b0, a0, 0x05040100u), __builtin_amdgcn_perm(b0, a0, 0x07060302u),
+                               __builtin_amdgcn_perm(b1, a1, 0x05040100u), __builtin_amdgcn_perm(b1, a1, 0x07060302u)};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t w = T[t];
+            const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
+                           e3 = (w >> 6) & 0x03030303u;
+            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            accX[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B, accX[t], 0, 0, 0);
+            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            accY[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B, accY[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Ax side, one K-step (64 markers): 16 tiles (d, s), operand register i from load i
+template <bool SQUARE>   // SQUARE: the first plane is a^2 (compute_people_statistics), else r'
+__device__ __forceinline__ void compute_ax_t(const ABufT& a, const u32x4* sb, int lane, v4i (&acc)[16]) {
+    const u32x4 q0 = sb[lane], q1 = sb[64 + lane];
+    const v4i B0 = {(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w};
+    const v4i B1 = {(int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+            const uint32_t e0 = (a.t[0][d] >> (2 * s2)) & 0x03030303u, e1 = (a.t[1][d] >> (2 * s2)) & 0x03030303u,
+                           e2 = (a.t[2][d] >> (2 * s2)) & 0x03030303u, e3 = (a.t[3][d] >> (2 * s2)) & 0x03030303u;
+            const v4i X = SQUARE ? (v4i){(int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e0),
+                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e1),
+                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e2),
+                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e3)}
+                                 : (v4i){(int)e0, (int)e1, (int)e2, (int)e3};
+            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
+                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            acc[d * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B0, acc[d * 4 + s2], 0, 0, 0);
+            acc[d * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B1, acc[d * 4 + s2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The streaming kernel on the tile layout.  Same skeleton as k_mfma_matvec: a workgroup = 4 waves = 4 consecutive row
+// groups over the same K range (digits once per workgroup through a two-stage LDS ring, one bare s_barrier per step), three
+// super-block register buffers rotating by name, uniform / tapered K-split or balanced decomposition, progress-based wave
+// priority.  DIR 0 (ATx): row group = 64 markers (nrg = ceil(M/64)), K-step = 256 individuals (nkb = ceil(N/256)), digit
+// block 128 (MODE 0) or 256 (MODE 2) pieces.  DIR 1 (Ax): row group = 256 individuals (nrg = ceil(N/256)), K-step = 64
+// markers (nkb = ceil(M/64)), digit block = 64 pieces of dig0 + 64 of dig1.  Super-block of (row group rg, K-step kb):
+// DIR 0: (rg nkb + kb), DIR 1: (kb nrg + rg) -- the layout is stored marker-group-major.
+// partial layout as k_mfma_matvec: [(piece * P + plane) * rows_p + row] * 8 + digit; DIR 0: rows_p = 64 nrg, P = 2 (MODE 0)
+// or 4 (MODE 2); DIR 1: rows_p = 256 nrg, P = nv.
+template <int DIR, int MODE, bool SK>
+__global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
+                                                      const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
+                                                      int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial, int nv,
+                                                      const int* __restrict__ go) {
+    if (go && __builtin_nontemporal_load(go) == 0) return;
+    constexpr int KBS = (DIR == 1) ? 64 : ((MODE == 0) ? 128 : 256);   // u32x4 per K-step of one digit buffer
+    constexpr int SS = (DIR == 1) ? 128 : 256;                         // u32x4 per LDS stage
+    constexpr int ROWS = (DIR == 1) ? 256 : 64;                        // rows per row group
+    __shared__ u32x4 sB[2][SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t nq = (nrg + 3) >> 2;
+    const int c = lane & 15, g = lane >> 4;
+    // the digit copy: DIR 0: thread -> piece (MODE 0: pieces 0..127, threads 128..255 copy them again into the unused half);
+    // DIR 1: threads 0..63 -> dig0, 64..127 -> dig1, 128..255 repeat (no divergent branch in the loop body)
+    const int dofs = (DIR == 1) ? (tid & 63) : ((MODE == 0) ? (tid & 127) : tid);
+    const u32x4* digsel = (DIR == 1 && (tid & 64)) ? dig1 : dig0;
+    const int sofs = (DIR == 1) ? (tid & 127) : tid;
+    uint32_t u, uend;
+    const uint32_t nkb32 = (uint32_t)nkb, skL32 = (uint32_t)skL;
+    if (SK) {
+        const uint32_t U = (uint32_t)nq * nkb32;
+        u = blockIdx.x * skL32;
+        uend = u + skL32 < U ? u + skL32 : U;
+    } else {
+        const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
+        u = q0 * nkb32 + kbnd.b[ks0];
+        uend = q0 * nkb32 + kbnd.b[ks0 + 1];
+    }
+    const uint32_t p_quarter = (uend - u + 3) / 4;
+    uint32_t p_thr = prio ? u + p_quarter : 0xffffffffu, p_lvl = 3;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    ABufT a0, a1, a2;
+    u32x4 r0;
+    bool primed = false;
+    uint32_t par = 0;
+    if (u >= uend) return;
+    // super-block (row group rg_, K-step kb_) in u32x4 units
+    const int64_t kstride = (DIR == 1) ? nrg * 256 : 256;   // from one K-step to the next
+#pragma unroll 1
+  do {
+    const uint32_t q32 = __builtin_amdgcn_readfirstlane(u / nkb32);
+    const int64_t q = q32, kb0 = u - q32 * nkb32;
+    const uint32_t seg = nkb32 - (uint32_t)kb0 < uend - u ? nkb32 - (uint32_t)kb0 : uend - u;
+    const int64_t nsteps = seg;
+    const int ks = SK ? (int)__builtin_amdgcn_readfirstlane(blockIdx.x - (q32 * nkb32) / skL32)
+                      : (int)(blockIdx.x / (uint32_t)nq);
+    const uint32_t useg0 = u;
+    u += seg;
+    int64_t rg = q * 4 + (tid >> 6);
+    const bool live = rg < nrg;
+    if (!live) rg = nrg - 1;
+
+    v4i accX[(DIR == 1) ? 16 : 4], accY[(DIR == 1) ? 1 : 4];
+#pragma unroll
+    for (int i = 0; i < ((DIR == 1) ? 16 : 4); i++) accX[i] = (v4i){0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < ((DIR == 1) ? 1 : 4); i++) accY[i] = (v4i){0, 0, 0, 0};
+    const int64_t last = nsteps - 1;
+    const u32x4* ap = stripes + ((DIR == 1) ? (kb0 * nrg + rg) * 256 : (rg * nkb + kb0) * 256);
+    const u32x4* g0 = digsel + kb0 * KBS + dofs;
+    const bool has_next = SK && u < uend && nkb32 >= 2;
+    int64_t rgn = (q + 1) * 4 + (tid >> 6);
+    if (rgn >= nrg) rgn = nrg - 1;
+    const u32x4* apn = has_next ? stripes + ((DIR == 1) ? rgn * 256 : rgn * nkb * 256) : ap + last * kstride;
+    const u32x4* g0n = has_next ? digsel + dofs : g0 + last * KBS;
+    const int64_t nlastn = has_next ? (int64_t)(uend - u < nkb32 ? uend - u : nkb32) - 1 : 0;
+#define GV_A_AT(I) ((I) <= last ? ap + (I) * kstride : apn + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * kstride)
+#define GV_D_AT(I) ((I) <= last ? g0 + (I) * KBS : g0n + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * KBS)
+
+    if (!primed) {
+        r0 = g0[0];
+        load_t<DIR>(a0, ap, lane);
+        load_t<DIR>(a1, GV_A_AT((int64_t)1), lane);
+        sB[par][sofs] = r0;
+        wg_barrier_lds();
+    }
+#define GV_T_STEP(CUR, NXT, S)                                                         \
+    {                                                                                  \
+        const int64_t sv = (S);                                                        \
+        const int64_t n2 = sv + 2, n1 = sv + 1;                                        \
+        r0 = *GV_D_AT(n1);                                                             \
+        load_t<DIR>(NXT, GV_A_AT(n2), lane);                                           \
+        if constexpr (DIR == 1)                                                        \
+            compute_ax_t<MODE == 4>(CUR, sB[(sv + par) & 1], lane, accX);              \
+        else                                                                           \
+            compute_atx_t<MODE>(CUR, sB[(sv + par) & 1], lane, accX, accY);            \
+        sB[(sv + 1 + par) & 1][sofs] = r0;                                             \
+        wg_barrier_lds();                                                              \
+    }
+    int64_t st = 0;
+    const int64_t rem = nsteps % 3;
+#pragma unroll 1
+    for (; st < rem; st++) {
+        GV_T_STEP(a0, a2, st)
+        a0 = a1;
+        a1 = a2;
+    }
+#pragma unroll 1
+    for (; st < nsteps; st += 3) {
+        if (useg0 + (uint32_t)st >= p_thr) {
+            p_thr += p_quarter;
+            p_lvl = p_lvl > 0 ? p_lvl - 1 : 0;
+            if (p_lvl == 2) __builtin_amdgcn_s_setprio(2);
+            else if (p_lvl == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        GV_T_STEP(a0, a2, st)
+        GV_T_STEP(a1, a0, st + 1)
+        GV_T_STEP(a2, a1, st + 2)
+    }
+#undef GV_T_STEP
+#undef GV_A_AT
+#undef GV_D_AT
+    par = (par + (uint32_t)nsteps) & 1u;
+    primed = has_next;
+    if (!live) continue;
+    const int64_t rows_p = nrg * ROWS;
+    const int cd = c & 7;
+    if constexpr (DIR == 1) {
+        // tile (d, s2): D[row 4g + reg][col c] <-> individual 256 rg + 16 (4g + reg) + 4d + s2; vector c >> 3, digit c & 7
+        const int pv = c >> 3;
+        if (pv < nv) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int64_t row = rg * 256 + 16 * (4 * g + reg) + t;   // t = 4 d + s2
+                    partial[(((int64_t)ks * nv + pv) * rows_p + row) * 8 + cd] = accX[t][reg];
+                }
+            }
+        }
+    } else if constexpr (MODE == 2) {
+    // DIR 0: tile t, D[row 4g + reg][col c] <-> marker 64 rg + 4 (4g + reg) + t
+        const int pv = (c >> 3) * 2;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int64_t row = rg * 64 + 4 * (4 * g + reg) + t;
+                partial[(((int64_t)ks * 4 + pv + 0) * rows_p + row) * 8 + cd] = accX[t][reg];
+                partial[(((int64_t)ks * 4 + pv + 1) * rows_p + row) * 8 + cd] = accY[t][reg];
+            }
+        }
+    } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int64_t row = rg * 64 + 4 * (4 * g + reg) + t;
+            if (c < 8) {
+                partial[(((int64_t)ks * 2 + 0) * rows_p + row) * 8 + cd] = accX[t][reg];
+                partial[(((int64_t)ks * 2 + 1) * rows_p + row) * 8 + cd] = accY[t][reg];
+            }
+        }
+    }
+    }
+  } while (SK && u < uend);
+}
+
+// ---- tile layout from a raw chunk: markers [m0, m0 + mc) of the shard, m0 % 64 == 0.  block = super-block (rg_local, kb);
+// thread tau writes piece tau = JB * 64 + q_local * 4 + (J_local & 3): four 16-entry words (one per marker of the quad),
+// recoded, then byte-transposed into the four dwords D(q, 4J + d).
+__device__ __forceinline__ void transpose4x4_bytes(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&o)[4]) {
+    const uint32_t a0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), a1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+    const uint32_t b0 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), b1 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+}
+__global__ __launch_bounds__(256) void k_tile_build(const uint8_t* __restrict__ raw, int64_t pitch, int64_t mc, int64_t N,
+                                                    uint4* __restrict__ tiles, int64_t rg0, int64_t nkb) {
+    const int tau = threadIdx.x, JB = tau >> 6, ql = (tau >> 2) & 15, Jl = JB * 4 + (tau & 3);
+    const int64_t kb = blockIdx.x, rgl = blockIdx.y;
+    const int64_t J = kb * 16 + Jl;                 // group of 16 individuals = one 32-bit word of a raw row
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (J * 4 < pitch) {
+        const int nvalid = (int)min((int64_t)16, max((int64_t)0, N - J * 16));
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int64_t m = rgl * 64 + 4 * ql + t;
+            if (m < mc) w[t] = keep_lo(recode(*reinterpret_cast<const uint32_t*>(raw + m * pitch + J * 4)), nvalid);
+        }
+    }
+    uint32_t o[4];
+    transpose4x4_bytes(w[0], w[1], w[2], w[3], o);   // o[d] byte t = w[t] byte d
+    tiles[((rg0 + rgl) * nkb + kb) * 256 + tau] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// compute_markers_statistics (data.cpp:451-484) from the tile layout: block = 4 waves = 4 marker groups; lane (r, g) walks the
+// pieces P(q_local = r, J_local = 4i + g) of its group, transposes them back to one word per marker and counts as k_stats_stripes
+__global__ __launch_bounds__(256) void k_stats_tile(const uint4* __restrict__ tiles, const uint32_t* __restrict__ mask2,
+                                                    int64_t M, int64_t nrg, int64_t nkb, int64_t P4, double nonas,
+                                                    double alpha_scale, double* __restrict__ mave, double* __restrict__ msig,
+                                                    uint32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rg >= nrg) return;
+    uint32_t n2[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n0[4] = {0, 0, 0, 0};
+    for (int64_t kb = 0; kb < nkb; kb++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = tiles[(rg * nkb + kb) * 256 + i * 64 + r * 4 + g];
+            const int64_t J = kb * 16 + 4 * i + g;
+            const uint32_t pm = (J < P4) ? (mask2[J] & 0x55555555u) : 0u;
+            uint32_t T[4];
+            transpose4x4_bytes(v.x, v.y, v.z, v.w, T);   // T[t] = marker 4q + t, 16 individuals of group J
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t lo = T[t] & 0x55555555u, hi = (T[t] >> 1) & 0x55555555u;
+                n2[t] += __popc(hi & ~lo & pm);
+                n1[t] += __popc(~hi & lo & pm);
+                n0[t] += __popc(~hi & ~lo & pm);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        n2[t] += __shfl_xor(n2[t], 16, 64); n2[t] += __shfl_xor(n2[t], 32, 64);
+        n1[t] += __shfl_xor(n1[t], 16, 64); n1[t] += __shfl_xor(n1[t], 32, 64);
+        n0[t] += __shfl_xor(n0[t], 16, 64); n0[t] += __shfl_xor(n0[t], 32, 64);
+    }
+    if (g != 0) return;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t m = rg * 64 + 4 * r + t;
+        if (m >= M) continue;
+        double suma = 2.0 * n2[t] + 1.0 * n1[t], sumb = (double)n0[t] + (double)n1[t] + (double)n2[t];
+        double mu = (sumb != 0) ? suma / sumb : 0.0;
+        double sumsqr = n2[t] * ((2.0 - mu) * (2.0 - mu)) + n1[t] * ((1.0 - mu) * (1.0 - mu)) + n0[t] * (mu * mu);
+        double sg;
+        if (sumsqr != 0) {
+            if (alpha_scale == 1.0) sg = 1.0 / sqrt(sumsqr / (nonas - 1.0));
+            else sg = 1.0 / pow(sqrt(sumsqr / (nonas - 1.0)), alpha_scale);
+        } else
+            sg = 1.0;
+        mave[m] = mu;
+        msig[m] = sg;
+        if (counts) {
+            counts[3 * m] = n2[t];
+            counts[3 * m + 1] = n1[t];
+            counts[3 * m + 2] = n0[t];
+        }
+    }
+}
+
+// digits of an M-vector in the B-operand order of the tile layout's Ax side: K-step = 64 markers; entry
+// k = 64 kstep + 16 i + 4 gam + t is byte t of dword i of the 16-byte element (kstep, gam, column): dword index
+// kstep * 256 + (gam * 16 + col0 + c) * 4 + i.  Thread = (kstep, i, gam): four consecutive entries.
+__global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t nsteps) {
+    const double* __restrict__ v = a.v[blockIdx.y];
+    const double* __restrict__ scal = a.scal[blockIdx.y];
+    uint32_t* __restrict__ out = a.out[blockIdx.y];
+    const int col0 = a.col0[blockIdx.y];
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nsteps * 16) return;
+    const int gam = tid & 3, i = (tid >> 2) & 3;
+    const int64_t kstep = tid >> 4;
+    const double mult = scal[2];
+    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t k = 4 * tid + t;                       // = 64 kstep + 16 i + 4 gam + t
+        double val = (k < n) ? v[k] : 0.0;
+        long long q = (long long)rint(val * mult);
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            long long dg = (long long)(signed char)(q & 0xFF);
+            q = (q - dg) >> 8;
+            dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
+        }
+    }
+    uint32_t* o = out + kstep * 256 + (gam * 16 + col0) * 4 + i;
+#pragma unroll
+    for (int c = 0; c < 8; c++) o[c * 4] = dig[c];
+}
+
 __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
 
 // Raw per-marker sums of TWO N-vectors from one pass over stripes_m (MODE 2):
@@ -714,12 +1108,77 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     out[m] = a.addx[v] ? tau * r + gam2 * a.addx[v][m] : r;
 }
 
+// The same epilogue as one half of a device-resident CG step: out = d = tau ATx + gam2 p (addx = p is the search direction)
+// and, in the same sweep, the block partials of <d, p> in the summation order of gvk::dots (grid-stride, block tree); the
+// block that takes the last ticket adds them up in the fixed order of k_finalize and leaves <d, p> in dot_out[v][0].
+// A slot whose system has finished is skipped (its d is not needed and its scalars must not move).
+struct FinAtxDot { double* out[2]; const double* addx[2]; const double* st[2]; double* part[2]; double* dot_out[2]; int pv[2]; };
+__global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
+                                                     const double* __restrict__ scal_base, const double* __restrict__ mave,
+                                                     const double* __restrict__ msig, double inv_sqrt_n, FinAtxDot a, double tau,
+                                                     double gam2, int ppk, int64_t nkb, int64_t skL,
+                                                     unsigned int* __restrict__ counters) {
+    __shared__ double sh[256];
+    __shared__ bool is_last;
+    const int v = blockIdx.y, p0 = 2 * a.pv[v];
+    const double* st = a.st[v];
+    if (st && st[gvm::ST_ACTIVE] == 0.0) return;
+    const double* __restrict__ scal = scal_base + 4 * a.pv[v];
+    double* __restrict__ out = a.out[v];
+    const double* __restrict__ addx = a.addx[v];
+    const double scale = scal[3], P = scal[1];
+    double s = 0.0;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
+        const int np = pieces_of(m, ksplit, nkb, skL);
+        for (int ks = 0; ks < np; ks++) {
+            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
+            const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
+            int4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
+            sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+            sy[0] += y0.x; sy[1] += y0.y; sy[2] += y0.z; sy[3] += y0.w; sy[4] += y1.x; sy[5] += y1.y; sy[6] += y1.z;
+        }
+        long long xh, xl, yh, yl;
+        combine(sx, xh, xl);
+        combine(sy, yh, yl);
+        const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
+        const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
+        const double r = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
+        const double pm = addx[m];
+        const double d = tau * r + gam2 * pm;
+        out[m] = d;
+        s += d * pm;
+    }
+    s = wave_sum_d(s);   // the butterfly of gvk::dots (bit-identical sums)
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        __threadfence();
+        const unsigned int t = atomicAdd(counters + v, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) counters[v] = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) acc += ld_l2(a.part[v] + b);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.dot_out[v][0] = sh[0];
+}
+
 // data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
 struct FinAx { double* out[2]; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
-                                                int64_t nkb, int64_t skL) {
+                                                int64_t nkb, int64_t skL, int qshift) {
     // the streaming kernel has already added the r'.c and miss.e products: one plane per vector and piece, ppk = number of
     // vectors of the pass (1: MODE 1, 4; 2: MODE 3)
     const int v = blockIdx.y;
@@ -733,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
         return;
     }
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
-    ksplit = pieces_of(n, ksplit, nkb, skL);
+    ksplit = pieces_of(n, ksplit, nkb, skL, qshift);
     for (int ks = 0; ks < ksplit; ks++) {
         const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
         int4 x0 = px[0], x1 = px[1];
@@ -748,9 +1207,52 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 // launch of the streaming kernel of one matvec (HIP events around it when the roofline timing is on)
+static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb);
+// the streaming kernel on the tile layout (DIR 0: ATx side, MODE 0 / 2; DIR 1: Ax side, MODE 3 / 4, nv vectors)
+template <int DIR, int MODE>
+void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const void* dig1, int64_t nrg, int64_t nkb,
+                 const gvm::Decomp& d, int nv, const int* go) {
+    if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
+    const int64_t nq = (nrg + 3) / 4;
+    const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    const KBounds kb = make_bounds(d, nkb);
+    if (d.skL > 0)
+        hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go);
+    else
+        hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go);
+    if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
+}
+static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb) {
+    KBounds kb{};
+    if (d.skL <= 0) {
+        const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
+        double acc = 0.0;
+        kb.b[0] = 0;
+        for (int j = 0; j < ks; j++) {
+            const double w = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
+            acc += w;
+            int64_t e = (int64_t)((double)nkb * acc / (double)ks + 0.5);
+            const int64_t lo = (int64_t)kb.b[j] + 1, hi = nkb - (ks - 1 - j);
+            e = e < lo ? lo : (e > hi ? hi : e);
+            kb.b[j + 1] = (uint32_t)e;
+        }
+        kb.b[ks] = (uint32_t)nkb;
+    }
+    return kb;
+}
+
 template <int MODE>
 void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, const void* dig0, const void* dig1, int64_t nrg,
-                   int64_t nkb, const gvm::Decomp& d) {
+                   int64_t nkb, const gvm::Decomp& d, const int* go = nullptr) {
+    if (pl.layout == 1) {   // one resident layout: the same products on the tile kernels
+        if (MODE == 0) return launch_tile<0, 0>(s, pl, dig0, dig1, nrg, nkb, d, 1, go);
+        if (MODE == 2) return launch_tile<0, 2>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
+        if (MODE == 1) return launch_tile<1, 3>(s, pl, dig0, dig1, nrg, nkb, d, 1, go);
+        if (MODE == 3) return launch_tile<1, 3>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
+        return launch_tile<1, 4>(s, pl, dig0, dig1, nrg, nkb, d, 1, go);
+    }
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
@@ -771,10 +1273,10 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     }
     if (d.skL > 0)
         hipLaunchKernelGGL((k_mfma_matvec<MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go);
     else
         hipLaunchKernelGGL((k_mfma_matvec<MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 
@@ -820,10 +1322,33 @@ static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, cons
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), nv), dim3(256), 0, s, q, npad, pl.nkb_m, nv == 2 ? 16 : 8);
 }
 
+// red_blocks of gvk::dots: the block partials of the fused <d, p> are taken in the same order
+static int dot_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
+static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, const double* mave, const double* msig,
+                       double inv_sqrt_n, double* const* out, const double* const* addx, double tau, double gam2,
+                       const CgHook& cg) {
+    FinAtxDot f{};
+    for (int v = 0; v < nv; v++) {
+        f.out[v] = out[v]; f.addx[v] = addx[v]; f.st[v] = cg.state[v]; f.part[v] = cg.dot_part[v]; f.dot_out[v] = cg.dot_out[v];
+        f.pv[v] = v;
+    }
+    hipLaunchKernelGGL(k_fin_atx_dot, dim3(dot_blocks(pl.M), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL, cg.dot_counters);
+}
+
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
-         double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2) {
+         double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2, const CgHook* cg) {
     prep_quant_atx(s, pl, p, nullptr, npad, red_partial);
-    launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[0]);
+    launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[0], cg ? cg->go : nullptr);
+    if (cg && cg->dot_out[0]) {
+        double* o[2] = {out, nullptr};
+        const double* ax_[2] = {addx, nullptr};
+        fin_atx_cg(s, pl, pl.dm[0], 1, mave, msig, inv_sqrt_n, o, ax_, tau, gam2, *cg);
+        return;
+    }
     FinAtx f{{out, nullptr}, {addx, nullptr}};
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 1), dim3(256), 0, s, pl.partial, pl.dm[0].ks, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2, pl.nkb_m, pl.dm[0].skL);
@@ -832,9 +1357,15 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
 // data::ATx of TWO N-vectors in one pass over stripes_m
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb, const double* addxa,
-          const double* addxb, double tau, double gam2) {
+          const double* addxb, double tau, double gam2, const CgHook* cg) {
     prep_quant_atx(s, pl, pa, pb, npad, red_partial);
-    launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
+    launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1], cg ? cg->go : nullptr);
+    if (cg && (cg->dot_out[0] || cg->dot_out[1])) {
+        double* o[2] = {outa, outb};
+        const double* ax_[2] = {addxa, addxb};
+        fin_atx_cg(s, pl, pl.dm[1], 2, mave, msig, inv_sqrt_n, o, ax_, tau, gam2, *cg);
+        return;
+    }
     FinAtx f{{outa, outb}, {addxa, addxb}};
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 2), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4, pl.nkb_m, pl.dm[1].skL);
@@ -853,56 +1384,80 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
                        pl.scal, pl.scal + 4, out4, pl.nkb_m, pl.dm[1].skL);
 }
 
-void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
-        int64_t npad, double post, double* red_partial, double* out) {
-    const int nb = prep_blocks(pl.M);
-    PrepAx pa{{x, nullptr}, {pl.cv, nullptr}, {pl.ev, nullptr}};
-    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 1), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
-    QuantArgs q{};   // dig0 = [c | e]
+// operands cv / ev (and cv2 / ev2) -> digit buffers of the Ax side.  Two stripe sets: one vector dig0 = [c | e], two vectors
+// dig0 = [c_a | c_b], dig1 = [e_a | e_b].  Tile layout: always the second form (a one-vector pass leaves columns 8..15 unused).
+static void quant_ax(hipStream_t s, const Plan& pl, int nv) {
+    QuantArgs q{};
+    if (pl.layout == 1 || nv == 2) {
+        q.v[0] = pl.cv;  q.scal[0] = pl.scal;     q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
+        q.v[1] = pl.ev;  q.scal[1] = pl.scal;     q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;
+        q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
+        q.v[3] = pl.ev2; q.scal[3] = pl.scal + 4; q.out[3] = (uint32_t*)pl.dig1; q.col0[3] = 8;
+        if (pl.layout == 1)
+            hipLaunchKernelGGL(k_quant_t, dim3(nblk(pl.nkb_n * 16, 256), 2 * nv), dim3(256), 0, s, q, pl.M, pl.nkb_n);
+        else
+            hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+        return;
+    }
     q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
     q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
-    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
-    FinAx f{{out, nullptr}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 1, pl.nkb_n, pl.dn[0].skL);
+}
+static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64_t npad, const uint32_t* mask2, double post,
+                   double* outa, double* outb) {
+    FinAx f{{outa, outb}};
+    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad,
+                       pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8);
 }
 
-// one of the three per-individual sums of compute_people_statistics from stripes_n (k_prep_people): out[n] = mask * sum
+void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
+        int64_t npad, double post, double* red_partial, double* out, const CgHook* cg) {
+    const int nb = prep_blocks(pl.M);
+    PrepAx pa{{x, nullptr}, {pl.cv, nullptr}, {pl.ev, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (cg) { pa.st[0] = cg->state[0]; pa.pw[0] = cg->p[0]; pa.z[0] = cg->z[0]; }
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 1), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
+    quant_ax(s, pl, 1);
+    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[0], cg ? cg->go : nullptr);
+    fin_ax(s, pl, pl.dn[0], 1, npad, mask2, post, out, nullptr);
+}
+
+// one of the three per-individual sums of compute_people_statistics from the Ax-side layout (k_prep_people): out[n] = mask * sum
 void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, const double* msig, const uint32_t* mask2,
                int64_t npad, double* red_partial, double* out) {
     const int nb = prep_blocks(pl.M);
     hipLaunchKernelGGL(k_prep_people, dim3(nb), dim3(256), 0, s, kind, mave, msig, pl.M, pl.cv, pl.ev, red_partial, pl.scal,
                        pl.counters);
-    QuantArgs q{};
-    q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
-    q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+    quant_ax(s, pl, 1);
     gvm::Plan pq = pl;      // no roofline events around the statistics passes
     pq.ev0 = pq.ev1 = nullptr;
-    if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
-    else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, nullptr, pl.nrg_n, pl.nkb_n, pl.dn[0]);
-    FinAx f{{out, nullptr}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 1), dim3(256), 0, s, pl.partial, pl.dn[0].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, 1.0, f, 1, pl.nkb_n, pl.dn[0].skL);
+    if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[0]);
+    else           launch_stream<1>(s, pq, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[0]);
+    fin_ax(s, pl, pl.dn[0], 1, npad, mask2, 1.0, out, nullptr);
 }
 
-// data::Ax of TWO M-vectors in one pass over stripes_n: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
+// data::Ax of TWO M-vectors in one pass: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
-         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb) {
+         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, const CgHook* cg) {
     const int nb = prep_blocks(pl.M);
-    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}};
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (cg)
+        for (int v = 0; v < 2; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
     hipLaunchKernelGGL(k_prep_ax, dim3(nb, 2), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
-    QuantArgs q{};
-    q.v[0] = pl.cv;  q.scal[0] = pl.scal;     q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
-    q.v[1] = pl.ev;  q.scal[1] = pl.scal;     q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;
-    q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
-    q.v[3] = pl.ev2; q.scal[3] = pl.scal + 4; q.out[3] = (uint32_t*)pl.dig1; q.col0[3] = 8;
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
-    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[1]);
-    FinAx f{{outa, outb}};
-    hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), 2), dim3(256), 0, s, pl.partial, pl.dn[1].ks, pl.nrg_n * 64, npad,
-                       pl.scal, mask2, post, f, 2, pl.nkb_n, pl.dn[1].skL);
+    quant_ax(s, pl, 2);
+    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[1], cg ? cg->go : nullptr);
+    fin_ax(s, pl, pl.dn[1], 2, npad, mask2, post, outa, outb);
+}
+
+void tile_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* tiles, int64_t rg0, int64_t nkb) {
+    if (mc <= 0) return;
+    hipLaunchKernelGGL(k_tile_build, dim3((unsigned)nkb, (unsigned)((mc + 63) / 64)), dim3(256), 0, s, raw, pitch, mc, N,
+                       (uint4*)tiles, rg0, nkb);
+}
+void stats_from_tiles(hipStream_t s, const void* tiles, const uint32_t* mask2, int64_t M, int64_t nrg, int64_t nkb, int64_t P4,
+                      double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(k_stats_tile, dim3(nblk(nrg, 4)), dim3(256), 0, s, (const uint4*)tiles, mask2, M, nrg, nkb, P4, nonas,
+                       alpha_scale, mave, msig, counts);
 }
 
 }  // namespace gvm

@@ -170,6 +170,231 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
     return atx2_device(c, c->w_n->d, c->w_n2->d, outa, outb, xa, xb, tau, gam2);
 }
 
+// ---- the steady state of cg_run with every scalar on the device (kernel mode 1) ------------------------------------------
+// A CG step of the host-driven loop above costs three scalar round trips (alpha, the Onsager rule, beta / the residual
+// rule): the host waits for a reduction, computes one division and launches the next small kernel, ~20 launches and ~60 us
+// of idle GPU per step -- 3 % of a step at N=400k x M=1M, 10-17 % on a 2.5-12.5 GB shard (profiles/r2_*_gaps.txt).  Here the
+// state of each system (gvm::ST_*) lives in HBM; the step is
+//   Ax pass   [k_prep_ax: p <- z + beta p on the way in | k_quant | stream | k_fin_ax | all-reduce]
+//   ATx pass  [k_prep_atx | k_quant | stream | k_fin_atx_dot: d = tau A^T A p + gam2 p and <d,p>, finished by the last block]
+//   k_cgx_ab  [alpha = <r,z>/<d,p>; mu += alpha p; r -= alpha d; z = r/diag; <v,mu>, <r,z>, <r,r>]
+//   k_cgx_decide [Onsager rule, beta, residual rule, trace; go flag; status -> host mailbox]
+// and the host only ENQUEUES: it reads the status of step s - 1 after it has enqueued step s, so the device always has
+// a step queued.  A step enqueued after every system had finished is dropped on the device (the stream kernels return on
+// *go == 0, the update kernels on the system's ACTIVE flag): one step of empty launches, ~50 us.  Sharded jobs: the
+// reductions are all-reduced in-stream on the device buffer (RCCL), still without the host.  Per system the arithmetic is
+// that of the host-driven loop -- the same reductions in the same order, the same IEEE divisions and square roots.
+struct CgxStatus { double active, iters, conv, rel, ons, nrel, stepped; };
+
+static int cgx_alloc(gv_ctx* c, int max_iter) {
+    if (!c->cgx_state) {
+        HIPCHK(c, hipMalloc(&c->cgx_state, sizeof(double) * 2 * gvm::ST_SIZE));
+        HIPCHK(c, hipMalloc(&c->cgx_go, sizeof(int) * 4));
+        HIPCHK(c, hipMalloc(&c->cgx_counters, sizeof(unsigned int) * 4));
+        HIPCHK(c, hipMemsetAsync(c->cgx_counters, 0, sizeof(unsigned int) * 4, c->stream));
+        HIPCHK(c, hipHostMalloc(&c->cgx_pin, sizeof(double) * (2 * gvm::ST_SIZE + 2)));
+    }
+    if (max_iter > c->cgx_relcap) {
+        if (c->cgx_rel) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->cgx_rel); c->cgx_rel = nullptr; }
+        const int cap = max_iter < 64 ? 64 : max_iter;
+        HIPCHK(c, hipMalloc(&c->cgx_rel, sizeof(double) * 2 * cap));
+        c->cgx_relcap = cap;
+    }
+    return 0;
+}
+
+// waits until the device has published status number `seq` (or a later one); copies the slot of `seq`
+static int cgx_wait(gv_ctx* c, unsigned long long seq, CgxStatus* out2) {
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->mbox + RED_MAXK);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) {
+        if ((++spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));       // a kernel may have faulted: let the runtime say so
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq) break;
+            return fail(c, "cg_run_device: the device never published the status of a CG step");
+        }
+    }
+    const double* mb = c->mbox + (seq & 1ull) * 16;
+    for (int v = 0; v < 2; v++) {
+        const double* q = mb + 8 * v;
+        out2[v] = CgxStatus{q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
+    }
+    return 0;
+}
+
+// sys[k] (k < nsys <= 2) are initialised (phase 1: r, z, p = z, rz, norm_v set; req = p, res = d).  Runs them to their
+// stopping rules.  *ride_done tells whether the rider's product was taken along.
+static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x,
+                         double* ride_out, bool* ride_done) {
+    const int64_t M = c->M, npad = c->npad;
+    hipStream_t st = c->stream;
+    const bool multi = is_multi(c);
+    const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
+    const double scale = 1.0 / sqrt((double)c->N);
+    if (cgx_alloc(c, max_iter)) return 1;
+    if (ensure_work(c) || ensure_w2(c)) return 1;
+    if (M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
+    c->plan.ev0 = c->plan.ev1 = nullptr;       // no per-launch events inside the loop
+    // ---- initial states -> device
+    double* pin = c->cgx_pin;
+    int go0 = 0;
+    for (int k = 0; k < 2; k++) {
+        double* q = pin + k * gvm::ST_SIZE;
+        for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+        if (k >= nsys) continue;
+        const CgSys& s = sys[k];
+        q[gvm::ST_RZ] = s.rz; q[gvm::ST_NORMV] = s.norm_v; q[gvm::ST_PREV_ONS] = s.prev_onsager; q[gvm::ST_ONS] = s.onsager;
+        q[gvm::ST_RELERR] = s.rel_err; q[gvm::ST_ACTIVE] = s.active ? 1.0 : 0.0; q[gvm::ST_ITERS] = s.iters;
+        q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
+        go0 |= s.active ? 1 : 0;
+    }
+    int* pin_go = reinterpret_cast<int*>(pin + 2 * gvm::ST_SIZE);
+    pin_go[0] = go0;
+    HIPCHK(c, hipMemcpyAsync(c->cgx_state, pin, sizeof(double) * 2 * gvm::ST_SIZE, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->cgx_go, pin_go, sizeof(int), hipMemcpyHostToDevice, st));
+    double* dst[2] = {c->cgx_state, c->cgx_state + gvm::ST_SIZE};
+    double* drel[2] = {c->cgx_rel, c->cgx_rel + c->cgx_relcap};
+    unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
+    bool host_active[2] = {nsys > 0 && sys[0].active, nsys > 1 && sys[1].active};
+    int done_iters[2] = {nsys > 0 ? sys[0].iters : 0, nsys > 1 ? sys[1].iters : 0};
+    CgxStatus last[2] = {};
+    bool have_last = false;
+    // bookkeeping per enqueued step: which systems it carried, whether the rider rode
+    struct Step { unsigned long long seq; bool ride; };
+    std::vector<Step> steps;
+    int executed = 0;                       // steps that ran with *go == 1
+    bool ride_pending = ride_x != nullptr, rode = false;
+    auto apply_status = [&](const CgxStatus* s2) {
+        for (int k = 0; k < nsys; k++) host_active[k] = s2[k].active != 0.0;
+        last[0] = s2[0]; last[1] = s2[1];
+        have_last = true;
+    };
+    for (;;) {
+        int act[2], na = 0;
+        for (int k = 0; k < nsys; k++) if (host_active[k]) act[na++] = k;
+        if (na == 0) break;
+        // ---- enqueue one step for the systems the host believes active
+        gvm::CgHook hk;
+        hk.go = c->cgx_go;
+        hk.dot_counters = c->cgx_counters;
+        const bool ride_now = na == 1 && ride_pending;
+        for (int j = 0; j < na; j++) {
+            CgSys& s = sys[act[j]];
+            hk.state[j] = dst[act[j]];
+            hk.p[j] = s.p;
+            hk.z[j] = s.z;
+            hk.dot_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8;
+            hk.dot_out[j] = c->red_out + 8 * act[j];
+        }
+        double* wn[2] = {c->w_n->d, c->w_n2->d};
+        if (na == 2 || ride_now) {
+            const double* xb = na == 2 ? sys[act[1]].p : ride_x;
+            double* ob = na == 2 ? wn[1] : ride_out;
+            if (M == 0) {          // empty shard: zeros into the same collectives (the search directions are empty vectors)
+                gvk::fill(st, wn[0], npad, 0.0);
+                gvk::fill(st, ob, npad, 0.0);
+            } else
+                gvm::ax2(st, c->plan, sys[act[0]].p, xb, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], ob, &hk);
+            KCHK(c);
+            if (multi) {
+                if (na == 2) {
+                    if (comm_allreduce(c, wn[0], 2 * npad)) return 1;      // w_n | w_n2: one message
+                    gvk::scale_vec(st, wn[0], 2 * npad, scale);
+                } else {
+                    if (comm_allreduce(c, wn[0], npad)) return 1;
+                    if (comm_allreduce(c, ob, npad)) return 1;
+                    gvk::scale_vec(st, wn[0], npad, scale);
+                    gvk::scale_vec(st, ob, npad, scale);
+                }
+            }
+        } else {
+            if (M == 0) gvk::fill(st, wn[0], npad, 0.0);
+            else gvm::ax(st, c->plan, sys[act[0]].p, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], &hk);
+            KCHK(c);
+            if (multi) {
+                if (comm_allreduce(c, wn[0], npad)) return 1;
+                gvk::scale_vec(st, wn[0], npad, scale);
+            }
+        }
+        if (na == 2)
+            gvm::atx2(st, c->plan, wn[0], wn[1], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[1]].d,
+                      sys[act[0]].p, sys[act[1]].p, tau, gam2, &hk);
+        else
+            gvm::atx(st, c->plan, wn[0], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[0]].p, tau, gam2, &hk);
+        KCHK(c);
+        const int K = 8 * (act[na - 1] + 1);
+        if (multi && comm_allreduce(c, c->red_out, K)) return 1;               // <d,p>
+        {
+            double *a_st[2], *a_mu[2], *a_r[2], *a_z[2], *a_part[2], *a_red[2];
+            const double *a_p[2], *a_v[2], *a_d[2], *a_dp[2];
+            for (int j = 0; j < na; j++) {
+                CgSys& s = sys[act[j]];
+                a_st[j] = dst[act[j]]; a_mu[j] = s.mu; a_p[j] = s.p; a_v[j] = s.v; a_r[j] = s.r; a_d[j] = s.d; a_z[j] = s.z;
+                a_dp[j] = c->red_out + 8 * act[j];
+                a_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8;
+                a_red[j] = c->red_out + 8 * act[j];
+            }
+            gvk::cgx_ab(st, na, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M, c->cgx_counters + 2);
+            for (int j = 0; j < na; j++)
+                if (sys[act[j]].az) gvk::axpy_st(st, sys[act[j]].az, wn[j], dst[act[j]], npad);   // A mu += alpha A p
+            KCHK(c);
+            if (multi && comm_allreduce(c, c->red_out, K)) return 1;           // <v,mu>, <r,z>, <r,r>
+            const double* c_red[2] = {c->red_out, c->red_out + 8};
+            double* c_rel[2] = {sys[0].relres ? drel[0] : nullptr, (nsys > 1 && sys[1].relres) ? drel[1] : nullptr};
+            const unsigned long long seq = ++c->mbox_seq;
+            gvk::cgx_decide(st, nsys, dst, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq);
+            KCHK(c);
+            steps.push_back(Step{seq, ride_now});
+        }
+        if (ride_now) ride_pending = false;
+        // ---- the status of the step BEFORE the one just enqueued
+        if (steps.size() >= 2) {
+            CgxStatus s2[2];
+            if (cgx_wait(c, steps[steps.size() - 2].seq, s2)) return 1;
+            apply_status(s2);
+        }
+    }
+    // ---- drain: the last enqueued step's status is the final one (a dropped step republishes the unchanged state)
+    if (!steps.empty()) {
+        CgxStatus s2[2];
+        if (cgx_wait(c, steps.back().seq, s2)) return 1;
+        apply_status(s2);
+    }
+    // executed steps = the largest iteration count reached inside this loop; a rider rode if its step was executed
+    if (have_last) {
+        int most = 0;
+        for (int k = 0; k < nsys; k++) {
+            const int it = (int)last[k].iters - done_iters[k];
+            if (it > most) most = it;
+            c->cnt.n_ax += it;
+            c->cnt.n_atx += it;
+        }
+        executed = most;
+        for (size_t i = 0; i < steps.size(); i++)
+            if (steps[i].ride && (int)i < executed) rode = true;
+        if (rode) c->cnt.n_ax += 1;
+        c->cnt.n_ax_pass += executed;
+        c->cnt.n_atx_pass += executed;
+        for (int k = 0; k < nsys; k++) {
+            CgSys& s = sys[k];
+            s.active = false;
+            s.iters = (int)last[k].iters;
+            s.converged = (int)last[k].conv;
+            s.rel_err = last[k].rel;
+            s.onsager = last[k].ons;
+            s.n_relres = (int)last[k].nrel;
+            // the device trace is indexed by the iteration number of the solve; entries below done_iters[k] were written by
+            // the host-driven rounds before the hand-over
+            if (s.relres && s.n_relres > done_iters[k])
+                if (to_host(c, s.relres + done_iters[k], drel[k] + done_iters[k], sizeof(double) * (size_t)(s.n_relres - done_iters[k])))
+                    return 1;
+        }
+    }
+    if (ride_done) *ride_done = rode;
+    return 0;
+}
+
 // ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
 // one system is still active (a two-vector pass costs what a one-vector pass costs), else by a pass of its own.
 static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x = nullptr,
@@ -192,12 +417,26 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
         }
         if (max_iter <= 0 && s.phase == 1) s.active = false;
     }
+    const char* cgdev = getenv("GV_CG_DEVICE");
+    // (chosen by nothing rank-local: an empty shard, M == 0, must enter the same sequence of collectives as its peers)
+    const bool device_loop = c->kernel_mode == 1 && c->have_stripes && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
     for (;;) {
         CgSys* act[2];
         int na = 0;
+        bool all_stepping = true;
         for (int k = 0; k < nsys; k++)
-            if (sys[k].active) act[na++] = &sys[k];
+            if (sys[k].active) {
+                act[na++] = &sys[k];
+                all_stepping &= sys[k].phase == 1;
+            }
         if (na == 0) break;
+        if (device_loop && all_stepping) {
+            // every active system is past its initial residual: hand the steady state to the device-resident loop
+            bool rode = false;
+            if (cg_run_device(c, sys, nsys, tau, gam2, max_iter, ride_x, ride_out, &rode)) return 1;
+            if (rode) ride_x = nullptr;
+            break;
+        }
         if (na == 2) {
             if (lmmse2_device(c, act[0]->req, act[1]->req, tau, gam2, act[0]->res, act[1]->res)) return 1;
             act[0]->wslot = c->w_n->d;

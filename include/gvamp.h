@@ -51,6 +51,10 @@ int gv_upload_bed_file(gv_ctx* ctx, const char* path, int64_t offset);
 /* Synthetic shard generated on the device (bench / tests; SURVEY 8d recipe with an integer hash so that
  * gvamp_amd.synth.synth_bed() reproduces it bit for bit on the host).  miss_ppm: missing rate in 1e-6. */
 int gv_synth_bed(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm);
+/* The same with linkage disequilibrium: inside every block of ld_block consecutive (global) markers a genotype copies, with
+ * probability ld_ppm / 1e6, the block's per-individual latent draw instead of its own -- block-correlated columns, as real
+ * genotypes have them (the LMMSE CG then needs tens of steps instead of 4-5).  ld_block = 0: gv_synth_bed. */
+int gv_synth_bed_ld(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm, uint32_t ld_block, uint32_t ld_ppm);
 int gv_download_bed(gv_ctx* ctx, uint8_t* bed, size_t nbytes);
 /* mask4: mbytes nibbles (data.hpp:36; bit k of mask4[j] = individual 4j+k has a phenotype and 4j+k < N);
  * NULL = every individual present (vector-phenotype ctor, data.cpp:86-100).  nonas: data.cpp:100/:150. */
@@ -66,9 +70,11 @@ int gv_ax(gv_ctx* ctx, const double* x, double* out);
 int gv_atx(gv_ctx* ctx, const double* p, double* out);
 
 /* Resident HBM layouts built at the next gv_upload_bed / gv_synth_bed: raw_rows = the PLINK rows (pitch-padded;
- * needed by kernel mode 0 and gv_download_bed), stripes = the two re-encoded 2-bit stripe sets of kernel mode 1
- * (marker-major for ATx, individual-major for Ax).  Default: both.  With raw_rows = 0 the rows stream through a
- * chunk buffer and only the stripes stay resident (2 x M*N/4 bytes). */
+ * needed by kernel mode 0 and gv_download_bed); stripes selects the re-encoded 2-bit layout of kernel mode 1:
+ *   0 none, 1 two stripe sets (marker-major for ATx, individual-major for Ax: 2 x M*N/4 bytes resident),
+ *   2 ONE tile layout that serves both products (M*N/4 bytes resident; bit-identical results).
+ * Default: raw rows + two stripe sets.  With raw_rows = 0 the rows stream through a chunk buffer and only the re-encoded
+ * layout stays resident. */
 int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
 /* kernel family for Ax/ATx: 0 = fp64 VALU kernels (parity anchor), 1 = i8 MFMA fixed-point kernels. */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);

@@ -132,7 +132,7 @@ def sharded_case(rng, idx):
         except Exception as e:   # noqa: BLE001
             errs.append((rank, repr(e)))
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(nshards)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nshards)]
     for t in th:
         t.start()
     for t in th:

@@ -1,0 +1,63 @@
+"""Real .bed ingest at BASELINE config-2 size (N=100k x M=500k = 12.5 GB): file -> resident layout GB/s (data.cpp:201-234's
+read_genotype_data replaced by gv_upload_bed_file).  The file is written on the box first, from the seeded on-device
+generator (chunks through the raw-row layout), so it comes out of the page cache: what is measured is fread + the pinned
+staging copy + PCIe + the re-encoding kernels, double-buffered (gv_capi.hip: ingest), not the disk.
+
+  python scripts/ingest_rate.py [N] [M] [dir]      -> one JSON line
+"""
+import json
+import os
+import shutil
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from gvamp_amd import capi
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
+mb = (N + 3) // 4
+need = M * mb + (1 << 20)
+cands = [sys.argv[3]] if len(sys.argv) > 3 else ["/dev/shm", os.environ.get("TMPDIR", "/tmp"), "/tmp"]
+where = next((d for d in cands if os.path.isdir(d) and shutil.disk_usage(d).free > 1.2 * need), None)
+if where is None:
+    sys.exit("no directory with %.1f GB free among %s" % (need / 1e9, cands))
+path = os.path.join(where, "gvamp_ingest_%d_%d.bed" % (N, M))
+t0 = time.perf_counter()
+CH = 32768
+with open(path, "wb") as f:
+    f.write(bytes([0x6C, 0x1B, 0x01]))
+    for m0 in range(0, M, CH):
+        mc = min(CH, M - m0)
+        with capi.Shard(N, mc, Mt=M, S=m0) as sh:
+            sh.set_layout(True, 0)
+            sh.synth_bed(4242, 5000)
+            f.write(sh.download_bed().tobytes())
+t_write = time.perf_counter() - t0
+out = {"N": N, "M": M, "file_bytes": os.path.getsize(path), "dir": where, "write_file_s": round(t_write, 2), "source": "page cache"}
+try:
+    for name, stripes in (("two_stripe_sets", 1), ("tile_layout", 2)):
+        best = None
+        for rep in range(2):
+            with capi.Shard(N, M) as sh:
+                sh.set_layout(False, stripes)
+                sh.set_kernel_mode(1)
+                t = time.perf_counter()
+                sh.upload_bed_file(path)
+                sh.synchronize()
+                dt = time.perf_counter() - t
+                t = time.perf_counter()
+                sh.compute_markers_statistics()
+                sh.synchronize()
+                ts = time.perf_counter() - t
+                if rep == 0:
+                    x = np.random.default_rng(0).standard_normal(M)
+                    chk = float(np.linalg.norm(sh.Ax(x)))
+            best = dt if best is None or dt < best else best
+        out[name] = {"ingest_s": round(best, 3), "GBps": round(M * mb / best / 1e9, 2), "stats_s": round(ts, 4), "norm_Ax": chk}
+    assert out["two_stripe_sets"]["norm_Ax"] == out["tile_layout"]["norm_Ax"]      # the same matrix, bit for bit
+finally:
+    os.remove(path)
+print(json.dumps(out))

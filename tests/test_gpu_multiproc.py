@@ -152,7 +152,7 @@ def test_empty_shard_rank_enters_the_same_collectives(tmp_path):
         except Exception as e:   # noqa: BLE001
             errors.append((rank, repr(e)))
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(3)]
     for t in th:
         t.start()
     for t in th:

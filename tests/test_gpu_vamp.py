@@ -188,7 +188,7 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode, fuse
         except Exception as e:   # noqa: BLE001
             errors.append((rank, repr(e)))
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(nshards)]
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nshards)]
     for t in th:
         t.start()
     for t in th:
