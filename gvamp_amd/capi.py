@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -124,6 +124,7 @@ def load():
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.gv_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    L.gv_set_overlap.argtypes = [vp, C.c_int]
     L.gv_comm_rank.argtypes = [vp]
     L.gv_comm_size.argtypes = [vp]
     L.gv_set_timing.argtypes = [vp, C.c_int]
@@ -430,6 +431,9 @@ class Shard:
                 return 1
         self._cb_keep = ALLREDUCE_FN(_cb)          # keep the trampoline alive as long as the context
         self._ck(self.L.gv_comm_init_callback(self.h, nranks, rank, self._cb_keep, None))
+
+    def set_overlap(self, tiles):
+        self._ck(self.L.gv_set_overlap(self.h, tiles))
 
     def set_timing(self, on):
         self._ck(self.L.gv_set_timing(self.h, int(on)))

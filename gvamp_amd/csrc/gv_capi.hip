@@ -109,12 +109,24 @@ int ensure_work(gv_ctx* c) {
 // them into mapped coherent host memory and then a sequence number; the host spins on that number -- no copy engine,
 // no interrupt-driven stream synchronisation (measured: ~55 us of GPU idle per read-back with hipMemcpyAsync +
 // hipStreamSynchronize, a CG step has three).  When the flag arrives every earlier kernel of the stream has finished.
+void arm_scalars(gv_ctx* c) {
+    if (!c->use_mbox || !c->pub_counter) return;
+    c->pub_seq = ++c->mbox_seq;
+    c->pub_armed = true;
+    gvk::arm_publish(c->mbox_dev, reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), c->pub_seq, c->pub_counter);
+}
 int read_scalars(gv_ctx* c, int K, double* out) {
     if (c->use_mbox && K <= RED_MAXK) {
         unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->mbox + RED_MAXK);
         unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
-        const unsigned long long seq = ++c->mbox_seq;
-        gvk::publish(c->stream, c->red_out, K, c->mbox_dev, flag_dev, seq);
+        unsigned long long seq;
+        if (c->pub_armed) {            // the reduction's own finalisation publishes (arm_scalars)
+            c->pub_armed = false;
+            seq = c->pub_seq;
+        } else {
+            seq = ++c->mbox_seq;
+            gvk::publish(c->stream, c->red_out, K, c->mbox_dev, flag_dev, seq);
+        }
         KCHK(c);
         const auto t0 = std::chrono::steady_clock::now();
         unsigned long spins = 0;
@@ -130,6 +142,8 @@ int read_scalars(gv_ctx* c, int K, double* out) {
         memcpy(out, c->mbox, sizeof(double) * K);
         return 0;
     }
+    c->pub_armed = false;
+    gvk::disarm_publish();
     HIPCHK(c, hipMemcpyAsync(c->host_pin, c->red_out, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(out, c->host_pin, sizeof(double) * K);
@@ -138,6 +152,7 @@ int read_scalars(gv_ctx* c, int K, double* out) {
 
 bool is_multi(const gv_ctx* c);
 int comm_allreduce(gv_ctx* c, double* dev, size_t n);
+int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream);
 
 // K scalars a reduction launcher left in red_out, summed over the ranks (utilities.cpp:203) and read back: the all-reduce
 // runs on the device buffer itself, so a CG scalar costs one stream synchronisation whether or not the job is sharded
@@ -182,25 +197,26 @@ std::map<int, std::shared_ptr<LocalGroup>> g_groups;
 bool is_multi(const gv_ctx* c) { return c->nranks > 1 && (c->comm || c->local || c->cb); }
 
 // SUM all-reduce of n doubles living on the device, on the context's stream
-int comm_allreduce(gv_ctx* c, double* dev, size_t n) {
+int comm_allreduce(gv_ctx* c, double* dev, size_t n) { return comm_allreduce_on(c, dev, n, c->stream); }
+int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream) {
     if (!is_multi(c)) return 0;
     if (c->comm) {
-        NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+        NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, stream));
         return 0;
     }
     if (c->cb) {   // caller's transport (gv_comm_init_callback): host round trip
         c->local_buf.resize(n);
-        HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
         if (c->cb(c->cb_user, c->local_buf.data(), n) != 0) return fail(c, "comm_allreduce: the all-reduce callback failed");
-        HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, stream));
+        HIPCHK(c, hipStreamSynchronize(stream));
         return 0;
     }
     LocalGroup* g = static_cast<LocalGroup*>(c->local);
     c->local_buf.resize(n);
-    HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->local_buf.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
     g->slots[c->rank] = c->local_buf.data();
     g->barrier();
     std::vector<double> sum(n, 0.0);
@@ -210,8 +226,8 @@ int comm_allreduce(gv_ctx* c, double* dev, size_t n) {
     }
     g->barrier();
     c->local_buf.swap(sum);
-    HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(dev, c->local_buf.data(), sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -486,12 +502,70 @@ int autotune_ks(gv_ctx* c) {
     return done(0);
 }
 
+// ---- the exchange step of data::Ax (data.cpp:928/:995) overlapped with the decode (north_star; GV_OVERLAP=T or gv_set_overlap)
+// The product is cut into T chunks of individuals (whole quads of row groups).  Chunk t is decoded on the context's stream;
+// its slice of the N-vector is all-reduced and scaled on a side stream while chunk t + 1 decodes; the context's stream joins
+// the side stream at the end.  Every chunk is the same exact integer arithmetic as the undivided pass and the all-reduce
+// of a slice adds the same numbers in the same rank order: results are bit-identical to the one-message form.  What it
+// buys is (T - 1)/T of the exchange time at the price of T - 1 more kernel tails: a knob to measure
+// on an 8-GPU node, off by default.
+int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double* outa, double* outb,
+                  const gvm::CgHook* cg) {
+    const double scale = 1.0 / sqrt((double)c->N);
+    gvm::Plan& pl = c->plan;
+    if (!c->comm_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+    }
+    const int64_t nq = (pl.nrg_n + 3) / 4;
+    int T = c->overlap_tiles;
+    if (T > nq) T = (int)nq;
+    const bool empty = c->M == 0;      // an empty shard sends zeros through the same sequence of slice messages
+    if (empty) {
+        gvk::fill(c->stream, outa, c->npad, 0.0);
+        if (nv == 2) gvk::fill(c->stream, outb, c->npad, 0.0);
+    } else
+        gvm::ax_prep(c->stream, pl, xa, nv == 2 ? xb : nullptr, c->mave, c->msig, c->red_partial, cg);
+    for (int t = 0; t < T; t++) {
+        const int64_t rg0 = 4 * (nq * t / T), rg1 = t == T - 1 ? pl.nrg_n : 4 * (nq * (t + 1) / T);
+        if (!empty) gvm::ax_rows(c->stream, pl, nv, rg0, rg1, c->mask2, c->npad, 1.0, outa, nv == 2 ? outb : nullptr, cg);
+        KCHK(c);
+        const int64_t n0 = rg0 * pl.rows_n;
+        int64_t cnt = (rg1 - rg0) * pl.rows_n;
+        if (n0 + cnt > c->npad) cnt = c->npad - n0;
+        if (cnt <= 0) continue;
+        HIPCHK(c, hipEventRecord(c->ev_chunk, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_chunk, 0));
+        if (comm_allreduce_on(c, outa + n0, (size_t)cnt, c->comm_stream)) return 1;
+        gvk::scale_vec(c->comm_stream, outa + n0, cnt, scale);
+        if (nv == 2) {
+            if (comm_allreduce_on(c, outb + n0, (size_t)cnt, c->comm_stream)) return 1;
+            gvk::scale_vec(c->comm_stream, outb + n0, cnt, scale);
+        }
+        KCHK(c);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_comm, c->comm_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    return 0;
+}
+bool use_overlap(const gv_ctx* c) {   // nothing rank-local in here: every rank of a job must cut the same slices
+    return c->overlap_tiles > 1 && is_multi(c) && c->kernel_mode == 1 && c->have_stripes;
+}
+
 // data::Ax on device pointers.  x: M doubles, out: npad doubles.
 int ax_device(gv_ctx* c, const double* x, double* out) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
-    if (c->M == 0) {   // an empty shard (Mt < ranks) contributes zeros through the same collective as its peers
+    if (c->kernel_mode == 1 && use_overlap(c)) {
+        if (c->M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
+        c->plan.ev0 = c->plan.ev1 = nullptr;
+        if (ax_overlapped(c, 1, x, nullptr, out, nullptr, nullptr)) return 1;
+        c->cnt.n_ax++;
+        c->cnt.n_ax_pass++;
+        return 0;
+    } else if (c->M == 0) {   // an empty shard (Mt < ranks) contributes zeros through the same collective as its peers
         gvk::fill(c->stream, out, c->npad, 0.0);
         KCHK(c);
     } else if (c->kernel_mode == 1) {
@@ -574,7 +648,14 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
-    if (c->M == 0) {
+    if (use_overlap(c)) {
+        if (c->M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
+        c->plan.ev0 = c->plan.ev1 = nullptr;
+        if (ax_overlapped(c, 2, xa, xb, outa, outb, nullptr)) return 1;
+        c->cnt.n_ax += 2;
+        c->cnt.n_ax_pass += 1;
+        return 0;
+    } else if (c->M == 0) {
         gvk::fill(c->stream, outa, c->npad, 0.0);
         gvk::fill(c->stream, outb, c->npad, 0.0);
         KCHK(c);
@@ -823,11 +904,17 @@ int gv_create(int device, gv_ctx** out) {
             c->mbox = static_cast<double*>(hp);
             c->mbox_dev = static_cast<double*>(dp);
             c->use_mbox = true;
+            if (hipMalloc(&c->pub_counter, sizeof(unsigned int)) != hipSuccess ||
+                hipMemset(c->pub_counter, 0, sizeof(unsigned int)) != hipSuccess) {
+                (void)hipGetLastError();
+                c->pub_counter = nullptr;          // read_scalars then keeps its own publish launch
+            }
         } else {
             (void)hipGetLastError();
             if (hp) (void)hipHostFree(hp);
         }
     }
+    if (const char* ov = getenv("GV_OVERLAP")) c->overlap_tiles = atoi(ov) > 64 ? 64 : (atoi(ov) < 0 ? 0 : atoi(ov));
     *out = c;
     return 0;
 }
@@ -843,10 +930,14 @@ void gv_destroy(gv_ctx* c) {
     if (c->red_out) (void)hipFree(c->red_out);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
     if (c->mbox) (void)hipHostFree(c->mbox);
+    if (c->pub_counter) (void)hipFree(c->pub_counter);
     if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1147,6 +1238,7 @@ int gv_vec_dots(gv_ctx* c, int n, const gv_vec* const* x, const gv_vec* const* y
         xs[k] = x[k]->d;
         ys[k] = y[k]->d;
     }
+    if (!(sync && is_multi(c))) arm_scalars(c);
     gvk::dots(c->stream, n, xs, ys, x[0]->len, c->red_partial, c->red_out);
     KCHK(c);
     if (sync && comm_allreduce(c, c->red_out, n)) return 1;
@@ -1226,6 +1318,7 @@ int gv_denoise(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, co
     NEED(c, r1->space == GV_SPACE_M && x1_out->space == GV_SPACE_M, "gv_denoise: M-space vectors required");
     gv_prior pr;
     if (fill_prior(c, pr, probs, vars, L)) return 1;
+    arm_scalars(c);
     gvk::denoise(c->stream, r1->d, c->M, gam1, pr, x1_out->d, d_out ? d_out->d : nullptr, c->red_partial, c->red_out);
     KCHK(c);
     return read_scalars(c, 2, sums2);
@@ -1237,6 +1330,7 @@ int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, cons
     NEED(c, L >= 2, "gv_prior_estep: L >= 2");
     gv_prior pr;
     if (fill_prior(c, pr, omegas, vars, L)) return 1;
+    arm_scalars(c);
     gvk::prior_estep(c->stream, r1->d, c->M, gam1, lambda, pr, c->red_partial, c->red_out);
     KCHK(c);
     return read_scalars(c, 1 + 2 * (L - 1), sums);
@@ -1248,6 +1342,7 @@ int gv_probit_denoise_cov(gv_ctx* c, const gv_vec* p1, const gv_vec* y, const gv
     NEED(c, p1->space == GV_SPACE_N && y->space == GV_SPACE_N && z1_out->space == GV_SPACE_N &&
                 (!m_cov || m_cov->space == GV_SPACE_N),
          "gv_probit_denoise: N-space vectors required");
+    arm_scalars(c);
     gvk::probit_denoise(c->stream, p1->d, y->d, m_cov ? m_cov->d : nullptr, c->N, c->npad, tau1, probit_var, z1_out->d,
                         c->red_partial, c->red_out);
     KCHK(c);
@@ -1473,6 +1568,11 @@ int gv_comm_init_callback(gv_ctx* c, int nranks, int rank, gv_allreduce_fn fn, v
             if (back[i] != probe[i] * nranks)
                 return fail(c, "gv_comm_init_callback: all-reduce self-test failed (%g != %g)", back[i], probe[i] * nranks);
     }
+    return 0;
+}
+int gv_set_overlap(gv_ctx* c, int tiles) {
+    NEED(c, tiles >= 0 && tiles <= 64, "gv_set_overlap: 0 <= tiles <= 64");
+    c->overlap_tiles = tiles;
     return 0;
 }
 int gv_comm_rank(const gv_ctx* c) { return c->rank; }

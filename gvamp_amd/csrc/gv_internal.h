@@ -64,6 +64,10 @@ struct gv_ctx {
     double* mbox_dev = nullptr;    // the same memory as the device sees it
     unsigned long long mbox_seq = 0;
     bool use_mbox = false;
+    // a reduction whose finalisation publishes to the mailbox itself (arm_scalars -> gvk::arm_publish -> k_finalize_pub)
+    unsigned int* pub_counter = nullptr;
+    bool pub_armed = false;
+    unsigned long long pub_seq = 0;
     void* xfer_pin = nullptr;      // 4 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
     // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` flag, 4 ticket counters,
     // residual traces (2 x cgx_relcap doubles), a pinned staging block for the initial states
@@ -85,6 +89,9 @@ struct gv_ctx {
     void* local = nullptr;                 // in-process test communicator (gv_comm_init_local)
     std::shared_ptr<void> local_keep;
     std::vector<double> local_buf;
+    int overlap_tiles = 0;                 // > 1: data::Ax in that many individual chunks, exchange on comm_stream (GV_OVERLAP)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_chunk = nullptr, ev_comm = nullptr;
     gv_allreduce_fn cb = nullptr;          // host-callback communicator (gv_comm_init_callback)
     void* cb_user = nullptr;
 
@@ -136,8 +143,12 @@ void atx_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const 
              const double* msig, double scale, double* out);
 void fill(hipStream_t s, double* v, int64_t n, double a);
 void publish(hipStream_t s, const double* src, int K, double* mailbox, unsigned long long* flag, unsigned long long seq);
+// the finalisation of the NEXT reduction launched from this thread also publishes its scalars (no k_publish launch)
+void arm_publish(double* mailbox, unsigned long long* flag, unsigned long long seq, unsigned int* counter);
+void disarm_publish();
 void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n);
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad);
+void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n);     // p = fma(beta, p, z)
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
 void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
           double* out);
@@ -170,10 +181,14 @@ void vec_del(gv_ctx* c, gv_vec* v);
 int ensure_w2(gv_ctx* c);       // the second N-space scratch vector (behind w_n in one allocation)
 int ensure_work(gv_ctx* c);     // scratch vectors of the matvecs and the CG
 int read_scalars(gv_ctx* c, int K, double* out);                            // red_out[0..K) -> host (mailbox or copy)
+// Call right before launching a reduction (gvk::dots, cg_step_*, denoise, ...) whose red_out[0..K) the very next
+// read_scalars(c, K, .) fetches, with nothing all-reduced in between: saves the k_publish launch of that read-back.
+void arm_scalars(gv_ctx* c);
 int read_scalars_global(gv_ctx* c, int K, double* out, bool multi);         // the same, summed over the ranks first
 int allreduce_scalars(gv_ctx* c, double* buf, int K);                       // MPI_Allreduce(SUM) of K host scalars
 bool is_multi(const gv_ctx* c);
 int comm_allreduce(gv_ctx* c, double* dev, size_t n);
+int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream);
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes);
 int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes);
 // data::Ax / data::ATx (and their two-vector forms) on device pointers, in the kernel family of the context
@@ -183,6 +198,8 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
                 const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
 int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out);
+bool use_overlap(const gv_ctx* c);    // data::Ax cut into chunks whose exchange runs on the side stream (GV_OVERLAP)
+int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double* outa, double* outb, const gvm::CgHook* cg);
 int autotune_ks(gv_ctx* c);     // picks the work decompositions of the streaming kernels (once per shard)
 
 struct Timer {

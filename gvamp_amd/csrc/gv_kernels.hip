@@ -373,6 +373,11 @@ __global__ void k_axpby(double* out, double a, const double* x, double b, const 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (y ? a * x[i] + b * y[i] : a * x[i]);
 }
+// p = z + beta p (vamp.cpp:1209-1210), one rounding -- the same fma as the device-resident CG (k_prep_ax)
+__global__ void k_p_update(double* p, const double* z, double beta, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = fma(beta, p[i], z[i]);
+}
 __global__ void k_mask_copy(double* out, const double* in, const uint32_t* mask2, int64_t npad) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= npad) return;
@@ -443,6 +448,33 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     if (threadIdx.x == 0) out[k] = sh[0];
 }
 
+// k_finalize that also publishes (read_scalars without a launch of its own): scalar k goes to out[k] AND to the host mailbox;
+// the block that takes the last ticket releases the sequence number the host spins on.
+__global__ __launch_bounds__(256) void k_finalize_pub(const double* __restrict__ partial, int nblocks, int K,
+                                                      double* __restrict__ out, double* mailbox, unsigned long long* flag,
+                                                      unsigned long long seq, unsigned int* __restrict__ counter) {
+    __shared__ double sh[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * K + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[k] = sh[0];
+        mailbox[k] = sh[0];
+        __threadfence_system();
+        if (atomicAdd(counter, 1u) == (unsigned int)K - 1) {
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 struct DotArgs {
     const double* x[8];
     const double* y[8];
@@ -453,7 +485,8 @@ __global__ __launch_bounds__(256) void k_dots(DotArgs a, int K, int64_t n, doubl
     for (int k = 0; k < K; k++) {
         const double *x = a.x[k], *y = a.y[k];
         double s = 0.0;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s = fma(x[i], y[i], s);   // (explicit:
+        // the fused <d,p> of k_fin_atx_dot must add the same roundings)
         s = block_sum_256(s, sh);
         if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * K + k] = s;
     }
@@ -467,10 +500,9 @@ __global__ __launch_bounds__(256) void k_cg_a(double* __restrict__ mu, const dou
     int64_t stride = (int64_t)gridDim.x * 256;
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        double palpha = alpha * p[i];
-        double m = mu[i] + palpha;
-        mu[i] = m;
-        s += v[i] * m;
+        double m = fma(alpha, p[i], mu[i]);        // explicit fma / mul in k_cg_a, k_cg_b and k_cgx_ab: the host-driven and
+        mu[i] = m;                                 // the device-resident CG step must round identically
+        s = fma(v[i], m, s);
     }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -485,15 +517,15 @@ __global__ __launch_bounds__(256) void k_cg_b(double* __restrict__ r, const doub
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         double ri = r[i];
-        if (alpha != 0.0) ri -= d[i] * alpha;   // alpha == 0: initialisation pass (z = r/diag, norms), d unread
+        if (alpha != 0.0) ri = fma(-d[i], alpha, ri);   // alpha == 0: initialisation pass (z = r/diag, norms), d unread
         double zi = ri / diag;
         r[i] = ri;
         z[i] = zi;
         double m = mu[i];
-        s0 += ri * zi;
-        s1 += zi * zi;
-        s2 += ri * ri;
-        s3 += m * m;
+        s0 = fma(ri, zi, s0);
+        s1 = fma(zi, zi, s1);
+        s2 = fma(ri, ri, s2);
+        s3 = fma(m, m, s3);
     }
     s0 = block_sum_256(s0, sh);
     s1 = block_sum_256(s1, sh);
@@ -531,17 +563,15 @@ __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n,
     const int64_t stride = (int64_t)gridDim.x * 256;
     double s_vmu = 0, s_rz = 0, s_rr = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        double palpha = alpha * p[i];
-        double m = mu[i] + palpha;
+        double m = fma(alpha, p[i], mu[i]);
         mu[i] = m;
-        s_vmu += vv[i] * m;
-        double ri = r[i];
-        ri -= d[i] * alpha;
+        s_vmu = fma(vv[i], m, s_vmu);
+        double ri = fma(-d[i], alpha, r[i]);
         double zi = ri / diag;
         r[i] = ri;
         z[i] = zi;
-        s_rz += ri * zi;
-        s_rr += ri * ri;
+        s_rz = fma(ri, zi, s_rz);
+        s_rr = fma(ri, ri, s_rr);
     }
     s_vmu = block_sum_256(s_vmu, sh);
     s_rz = block_sum_256(s_rz, sh);
@@ -829,7 +859,26 @@ inline int red_blocks(int64_t n, int bs) {
 
 }  // namespace
 
+namespace {
+// armed by the caller that is about to read the scalars of the NEXT reduction back (gvk::arm_publish): its finalisation
+// publishes to the host mailbox itself
+thread_local struct { double* mailbox; unsigned long long* flag; unsigned long long seq; unsigned int* counter; bool on; } t_arm = {};
+void launch_finalize(hipStream_t s, const double* partial, int nb, int K, double* out) {
+    if (t_arm.on) {
+        t_arm.on = false;
+        hipLaunchKernelGGL(k_finalize_pub, dim3(K), dim3(256), 0, s, partial, nb, K, out, t_arm.mailbox, t_arm.flag, t_arm.seq,
+                           t_arm.counter);
+    } else
+        hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
+}
+}  // namespace
+
 namespace gvk {
+
+void arm_publish(double* mailbox, unsigned long long* flag, unsigned long long seq, unsigned int* counter) {
+    t_arm.mailbox = mailbox; t_arm.flag = flag; t_arm.seq = seq; t_arm.counter = counter; t_arm.on = true;
+}
+void disarm_publish() { t_arm.on = false; }
 
 void synth_bed(hipStream_t s, uint8_t* bed, int64_t M, int64_t S, int64_t N, int64_t pitch, uint64_t seed,
                uint32_t miss_thr, uint32_t ld_block, uint32_t ld_thr) {
@@ -869,14 +918,14 @@ void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, con
                     double* partial, double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cg_b_diag, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, n, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, out);
+    launch_finalize(s, partial, nb, 2, out);
 }
 
 void probit_denoise(hipStream_t s, const double* p1, const double* y, const double* m_cov, int64_t N, int64_t npad,
                     double tau1, double probit_var, double* z1, double* partial, double* out) {
     int nb = red_blocks(npad, 256);
     hipLaunchKernelGGL(k_probit_denoise, dim3(nb), dim3(256), 0, s, p1, y, m_cov, N, npad, tau1, probit_var, z1, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, out);
+    launch_finalize(s, partial, nb, 2, out);
 }
 
 void mul(hipStream_t s, double* out, const double* x, const double* y, int64_t n) {
@@ -935,6 +984,9 @@ void axpby(hipStream_t s, double* out, double a, const double* x, double b, cons
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s, out, a, x, b, y, n);
 }
 
+void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n) {
+    hipLaunchKernelGGL(k_p_update, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, beta, n);
+}
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad) {
     hipLaunchKernelGGL(k_mask_copy, dim3(nblk(npad, 256)), dim3(256), 0, s, out, in, mask2, npad);
 }
@@ -948,7 +1000,7 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
     }
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_dots, dim3(nb), dim3(256), 0, s, a, K, n, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
+    launch_finalize(s, partial, nb, K, out);
 }
 
 void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
@@ -976,21 +1028,21 @@ void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const d
                double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cg_a, dim3(nb), dim3(256), 0, s, mu, p, alpha, v, n, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, out);
+    launch_finalize(s, partial, nb, 1, out);
 }
 
 void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double diag, double* z, const double* mu,
                int64_t n, double* partial, double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cg_b, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, mu, n, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(4), dim3(256), 0, s, partial, nb, 4, out);
+    launch_finalize(s, partial, nb, 4, out);
 }
 
 void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_prior& pr, double* x1, double* dd,
              double* partial, double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_denoise, dim3(nb), dim3(256), 0, s, r1, n, gam1, pr, x1, dd, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, out);
+    launch_finalize(s, partial, nb, 2, out);
 }
 
 void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& pr,
@@ -998,7 +1050,7 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
     int nb = red_blocks(n, 64);
     int K = 1 + 2 * (pr.L - 1);
     hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
+    launch_finalize(s, partial, nb, K, out);
 }
 
 void pvals_test(hipStream_t s, const uint32_t* cnt, const double* mave, const double* msig, const double* sums4,

@@ -46,6 +46,7 @@ struct Plan {
     void* tiles = nullptr;
     int layout = 0;
     int rows_n = 64;                // rows per row group on the Ax side
+    int64_t rstride_n = 0;          // tile layout, Ax side: row groups per K-step in memory when a launch covers a sub-range (0: nrg_n)
     void* dig0 = nullptr;           // digit buffers, max(nkb_m, nkb_n) * 2048 bytes each
     void* dig1 = nullptr;
     double* cv = nullptr;           // M doubles: c = msig * x
@@ -80,6 +81,12 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
 // out[npad] = mask * (A~ x) * post   (post = 1/sqrt(N), or 1 when a cross-rank all-reduce follows)
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
         int64_t npad, double post, double* red_partial, double* out, const CgHook* cg = nullptr);
+
+// the two stages of ax / ax2, for callers that cut the product into individual-range chunks (row groups [rg0, rg1) of pl.rows_n)
+void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
+             double* red_partial, const CgHook* cg = nullptr);
+void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
+             double* outa, double* outb, const CgHook* cg = nullptr);
 
 // two vectors per pass (the LMMSE and the Onsager CG of one VAMP iteration share the operator, vamp.cpp:593-596,:884)
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,

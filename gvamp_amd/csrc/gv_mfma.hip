@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
         double xi = x[i];
         if (upd) {
-            xi = zz[i] + beta * xi;
+            xi = fma(beta, xi, zz[i]);      // = gvk::p_update of the host-driven loop, bit for bit
             pw[i] = xi;
         }
         double c = msig[i] * xi, mu = mave[i];
@@ -758,7 +758,8 @@ template <int DIR, int MODE, bool SK>
 __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                       const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                       int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial, int nv,
-                                                      const int* __restrict__ go) {
+                                                      const int* __restrict__ go, int64_t rstride) {
+    // rstride (DIR 1): row groups per K-step in memory -- nrg, or more when this launch covers a sub-range of the row groups
     if (go && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (DIR == 1) ? 64 : ((MODE == 0) ? 128 : 256);   // u32x4 per K-step of one digit buffer
     constexpr int SS = (DIR == 1) ? 128 : 256;                         // u32x4 per LDS stage
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     uint32_t par = 0;
     if (u >= uend) return;
     // super-block (row group rg_, K-step kb_) in u32x4 units
-    const int64_t kstride = (DIR == 1) ? nrg * 256 : 256;   // from one K-step to the next
+    const int64_t kstride = (DIR == 1) ? rstride * 256 : 256;   // from one K-step to the next
 #pragma unroll 1
   do {
     const uint32_t q32 = __builtin_amdgcn_readfirstlane(u / nkb32);
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
 #pragma unroll
     for (int i = 0; i < ((DIR == 1) ? 1 : 4); i++) accY[i] = (v4i){0, 0, 0, 0};
     const int64_t last = nsteps - 1;
-    const u32x4* ap = stripes + ((DIR == 1) ? (kb0 * nrg + rg) * 256 : (rg * nkb + kb0) * 256);
+    const u32x4* ap = stripes + ((DIR == 1) ? (kb0 * rstride + rg) * 256 : (rg * nkb + kb0) * 256);
     const u32x4* g0 = digsel + kb0 * KBS + dofs;
     const bool has_next = SK && u < uend && nkb32 >= 2;
     int64_t rgn = (q + 1) * 4 + (tid >> 6);
@@ -1104,8 +1105,8 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     const double scale = scal[3], P = scal[1];
     const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
     const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
-    const double r = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
-    out[m] = a.addx[v] ? tau * r + gam2 * a.addx[v][m] : r;
+    const double r = msig[m] * fma(-mave[m], P - sm, sa) * inv_sqrt_n;
+    out[m] = a.addx[v] ? fma(tau, r, gam2 * a.addx[v][m]) : r;   // (explicit: k_fin_atx_dot rounds the same way)
 }
 
 // The same epilogue as one half of a device-resident CG step: out = d = tau ATx + gam2 p (addx = p is the search direction)
@@ -1143,11 +1144,11 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
         combine(sy, yh, yl);
         const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
         const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
-        const double r = msig[m] * (sa - mave[m] * (P - sm)) * inv_sqrt_n;
+        const double r = msig[m] * fma(-mave[m], P - sm, sa) * inv_sqrt_n;
         const double pm = addx[m];
-        const double d = tau * r + gam2 * pm;
+        const double d = fma(tau, r, gam2 * pm);
         out[m] = d;
-        s += d * pm;
+        s = fma(d, pm, s);
     }
     s = wave_sum_d(s);   // the butterfly of gvk::dots (bit-identical sums)
     __syncthreads();
@@ -1215,13 +1216,15 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
+    const int64_t rstride = pl.rstride_n > 0 ? pl.rstride_n : nrg;
     if (d.skL > 0)
         hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride);
     else
         hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go);
+                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride);
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb) {
@@ -1256,6 +1259,7 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     KBounds kb{};
     if (d.skL <= 0) {
         const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
@@ -1410,15 +1414,42 @@ static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64
                        pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8);
 }
 
+// ---- data::Ax in two stages: the operands of the whole vector (ax_prep), then the product for a range of row groups
+// (ax_rows: stream kernel + epilogue) -- the whole range in one go, or individual-range chunks whose cross-rank all-reduce
+// can run behind the next chunk (GV_OVERLAP, gv_capi.hip).  A chunk is a smaller problem of the same shape: the layouts are
+// row-group-major on this side (tile layout: with the row stride of the whole shard), so it only takes pointer offsets.
+void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
+             double* red_partial, const CgHook* cg) {
+    const int nv = xb ? 2 : 1, nb = prep_blocks(pl.M);
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (cg)
+        for (int v = 0; v < nv; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb, nv), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
+    quant_ax(s, pl, nv);
+}
+void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
+             double* outa, double* outb, const CgHook* cg) {
+    if (rg1 <= rg0) return;
+    Plan q = pl;
+    const int64_t n0 = rg0 * pl.rows_n;
+    int64_t nrows = (rg1 - rg0) * pl.rows_n;
+    if (n0 + nrows > npad) nrows = npad - n0;
+    q.nrg_n = rg1 - rg0;
+    if (pl.layout == 1) {
+        q.tiles = (char*)pl.tiles + (size_t)rg0 * 4096;
+        q.rstride_n = pl.rstride_n > 0 ? pl.rstride_n : pl.nrg_n;
+    } else
+        q.stripes_n = (char*)pl.stripes_n + (size_t)rg0 * pl.nkb_n * 4096;
+    const Decomp& d = nv == 2 ? pl.dn[1] : pl.dn[0];
+    if (nv == 2) launch_stream<3>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
+    else         launch_stream<1>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
+    fin_ax(s, q, d, nv, nrows, mask2 + n0 / 16, post, outa + n0, outb ? outb + n0 : nullptr);
+}
+
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
         int64_t npad, double post, double* red_partial, double* out, const CgHook* cg) {
-    const int nb = prep_blocks(pl.M);
-    PrepAx pa{{x, nullptr}, {pl.cv, nullptr}, {pl.ev, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    if (cg) { pa.st[0] = cg->state[0]; pa.pw[0] = cg->p[0]; pa.z[0] = cg->z[0]; }
-    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 1), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
-    quant_ax(s, pl, 1);
-    launch_stream<1>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[0], cg ? cg->go : nullptr);
-    fin_ax(s, pl, pl.dn[0], 1, npad, mask2, post, out, nullptr);
+    ax_prep(s, pl, x, nullptr, mave, msig, red_partial, cg);
+    ax_rows(s, pl, 1, 0, pl.nrg_n, mask2, npad, post, out, nullptr, cg);
 }
 
 // one of the three per-individual sums of compute_people_statistics from the Ax-side layout (k_prep_people): out[n] = mask * sum
@@ -1438,14 +1469,8 @@ void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, cons
 // data::Ax of TWO M-vectors in one pass: dig0 = [c_a | c_b] (r' plane), dig1 = [e_a | e_b] (miss plane)
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, const CgHook* cg) {
-    const int nb = prep_blocks(pl.M);
-    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    if (cg)
-        for (int v = 0; v < 2; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
-    hipLaunchKernelGGL(k_prep_ax, dim3(nb, 2), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
-    quant_ax(s, pl, 2);
-    launch_stream<3>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[1], cg ? cg->go : nullptr);
-    fin_ax(s, pl, pl.dn[1], 2, npad, mask2, post, outa, outb);
+    ax_prep(s, pl, xa, xb, mave, msig, red_partial, cg);
+    ax_rows(s, pl, 2, 0, pl.nrg_n, mask2, npad, post, outa, outb, cg);
 }
 
 void tile_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* tiles, int64_t rg0, int64_t nkb) {

@@ -48,10 +48,12 @@ static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
     // z = r / diag (:1152), <r,z>, ||v||^2 ; p = z (:1154)
     const int64_t M = c->M;
     double sc[4];
+    arm_scalars(c);
     gvk::cg_step_b(c->stream, s.r, s.d, 0.0, diag, s.z, s.mu, M, c->red_partial, c->red_out);
     KCHK(c);
     if (read_scalars(c, 4, sc)) return 1;
     const double* vv[1] = {s.v};
+    arm_scalars(c);
     gvk::dots(c->stream, 1, vv, vv, M, c->red_partial, c->red_out);
     KCHK(c);
     double vn2;
@@ -95,10 +97,13 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
     double sc[16], alpha[2] = {0, 0};
     auto part = [&](int j) { return c->red_partial + (size_t)slot[j] * RED_BLOCKS * 8; };
     auto outp = [&](int j) { return c->red_out + 8 * slot[j]; };
+    // (one system in slot 0 of an unsharded job: each reduction's finalisation publishes its scalars itself)
+    const bool solo = ns == 1 && slot[0] == 0 && !multi;
     // <d, p>
     for (int j = 0; j < ns; j++) {
         const double* xs[1] = {stp[j]->d};
         const double* ys[1] = {stp[j]->p};
+        if (solo) arm_scalars(c);
         gvk::dots(st, 1, xs, ys, M, part(j), outp(j));
     }
     KCHK(c);
@@ -107,6 +112,7 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
     for (int j = 0; j < ns; j++) {
         CgSys& s = *stp[j];
         alpha[j] = s.rz / sc[8 * slot[j]];                                // :1167
+        if (solo && s.denoiser == 0) arm_scalars(c);                      // read back only under the Onsager rule
         gvk::cg_step_a(st, s.mu, s.p, alpha[j], s.v, M, part(j), outp(j));   // mu += alpha p (:1169-1172)
         if (s.az) gvk::axpby(st, s.az, 1.0, s.az, alpha[j], s.wslot, c->npad);   // A mu += alpha A p
         any_onsager |= s.denoiser == 0;
@@ -135,6 +141,7 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
     for (int j = 0; j < ns; j++) {
         if (!stepping[j]) continue;
         CgSys& s = *stp[j];
+        if (solo) arm_scalars(c);
         gvk::cg_step_b(st, s.r, s.d, alpha[j], diag, s.z, s.mu, M, part(j), outp(j));   // :1195-1216
         any = true;
     }
@@ -147,7 +154,7 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
         const double* q = sc + 8 * slot[j];
         const double beta = q[0] / s.rz;                                  // (1/<r,z>_old) * <r,z>_new (:1198,:1207)
         s.rz = q[0];
-        gvk::axpby(st, s.p, 1.0, s.z, beta, s.p, M);                      // p = z + beta p (:1209-1210)
+        gvk::p_update(st, s.p, s.z, beta, M);                             // p = z + beta p (:1209-1210)
         s.rel_err = sqrt(q[2]) / s.norm_v;                                // :1215
         if (s.relres) s.relres[s.iters - 1] = s.rel_err;
         s.n_relres = s.iters;
@@ -232,6 +239,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     const bool multi = is_multi(c);
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
     const double scale = 1.0 / sqrt((double)c->N);
+    const bool ovl = use_overlap(c);
     if (cgx_alloc(c, max_iter)) return 1;
     if (ensure_work(c) || ensure_w2(c)) return 1;
     if (M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
@@ -291,13 +299,15 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         if (na == 2 || ride_now) {
             const double* xb = na == 2 ? sys[act[1]].p : ride_x;
             double* ob = na == 2 ? wn[1] : ride_out;
-            if (M == 0) {          // empty shard: zeros into the same collectives (the search directions are empty vectors)
+            if (ovl) {             // chunks of individuals, each slice exchanged on the side stream behind the next chunk
+                if (ax_overlapped(c, 2, sys[act[0]].p, xb, wn[0], ob, &hk)) return 1;
+            } else if (M == 0) {   // empty shard: zeros into the same collectives (the search directions are empty vectors)
                 gvk::fill(st, wn[0], npad, 0.0);
                 gvk::fill(st, ob, npad, 0.0);
             } else
                 gvm::ax2(st, c->plan, sys[act[0]].p, xb, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], ob, &hk);
             KCHK(c);
-            if (multi) {
+            if (multi && !ovl) {
                 if (na == 2) {
                     if (comm_allreduce(c, wn[0], 2 * npad)) return 1;      // w_n | w_n2: one message
                     gvk::scale_vec(st, wn[0], 2 * npad, scale);
@@ -309,15 +319,19 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
                 }
             }
         } else {
-            if (M == 0) gvk::fill(st, wn[0], npad, 0.0);
+            if (ovl) {
+                if (ax_overlapped(c, 1, sys[act[0]].p, nullptr, wn[0], nullptr, &hk)) return 1;
+            } else if (M == 0) gvk::fill(st, wn[0], npad, 0.0);
             else gvm::ax(st, c->plan, sys[act[0]].p, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], &hk);
             KCHK(c);
-            if (multi) {
+            if (multi && !ovl) {
                 if (comm_allreduce(c, wn[0], npad)) return 1;
                 gvk::scale_vec(st, wn[0], npad, scale);
             }
         }
-        if (na == 2)
+        if (M == 0)            // empty shard: no markers, <d,p> = 0 from this rank
+            gvk::fill(st, c->red_out, 8 * (act[na - 1] + 1), 0.0);
+        else if (na == 2)
             gvm::atx2(st, c->plan, wn[0], wn[1], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[1]].d,
                       sys[act[0]].p, sys[act[1]].p, tau, gam2, &hk);
         else
@@ -576,10 +590,12 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
             gvk::fill(s, mu, n, 0.0);
             AAT_HIP(hipMemcpyAsync(r, v->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         }
+        arm_scalars(c);
         gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);   // z = r / diag (:76-77)
         AAT_TRY(read_scalars(c, 2, sc));
         double rz = sc[0];
         const double* vv[1] = {v->d};
+        arm_scalars(c);
         gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
         double vn2;
         AAT_TRY(read_scalars(c, 1, &vn2));
@@ -589,11 +605,13 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
             AAT_TRY(lmmse_aat_device(c, p, tau, gam2, tmpM, d));              // d = Q p (:86)
             const double* xs[1] = {d};
             const double* ys[1] = {p};
+            arm_scalars(c);
             gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
             double dp;
             AAT_TRY(read_scalars(c, 1, &dp));
             const double alpha = rz / dp;                                     // :88
             gvk::axpby(s, mu, 1.0, mu, alpha, p, n);                           // mu += alpha p (:90-93)
+            arm_scalars(c);
             gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);   // :95-105
             AAT_TRY(read_scalars(c, 2, sc));
             const double beta = sc[0] / rz;                                    // :98,:107
@@ -698,10 +716,12 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
     {
         auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
             double sc[2];
+            arm_scalars(c);
             gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);
             if (read_scalars(c, 2, sc)) return 1;
             a_rz = sc[0];
             const double* vv[1] = {v_a->d};
+            arm_scalars(c);
             gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
             if (read_scalars(c, 1, &a_vn2)) return 1;
             if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
@@ -774,11 +794,13 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
                 const int i = a_iters++;                                           // one CG step (:86-120)
                 const double* xs[1] = {d};
                 const double* ys[1] = {p};
+                arm_scalars(c);
                 gvk::dots(s, 1, xs, ys, n, c->red_partial, c->red_out);
                 double dp, sc[2];
                 MIX_TRY(read_scalars(c, 1, &dp));
                 const double alpha = a_rz / dp;
                 gvk::axpby(s, mu, 1.0, mu, alpha, p, n);
+                arm_scalars(c);
                 gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);
                 MIX_TRY(read_scalars(c, 2, sc));
                 const double beta = sc[0] / a_rz;

@@ -48,7 +48,10 @@ void data::open_device(int device, int kernel_mode) {
     if (device < 0) device = gv_env_local_rank();
     if (gv_create(device, &ctx)) die(std::string("FATAL: ") + gv_last_error(nullptr));
     ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
-    ck(ctx, gv_set_layout(ctx, kernel_mode == 0, kernel_mode != 0), "gv_set_layout");
+    // kernel mode 1: two stripe sets (1, default) or the single tile layout (2: half the HBM, same results) -- --resident-layout
+    const char* lay = getenv("GVAMP_RESIDENT_LAYOUT");
+    const int stripes = kernel_mode != 0 ? ((lay && atoi(lay) == 2) ? 2 : 1) : 0;
+    ck(ctx, gv_set_layout(ctx, kernel_mode == 0, stripes), "gv_set_layout");
     ck(ctx, gv_set_kernel_mode(ctx, kernel_mode), "gv_set_kernel_mode");
     if (kernel_mode == 0 && rank == 0)
         std::cerr << "WARNING: --kernel-mode 0 selects the fp64 VALU kernels (parity anchor, 4-9 % of the HBM roofline): "

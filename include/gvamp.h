@@ -223,6 +223,10 @@ int gv_comm_init_local(gv_ctx* ctx, int group, int nranks, int rank);
  * (torch.distributed gloo).  Slower than RCCL (two PCIe hops per message); the sums must be identical on every rank. */
 typedef int (*gv_allreduce_fn)(void* user, double* buf, size_t n);
 int gv_comm_init_callback(gv_ctx* ctx, int nranks, int rank, gv_allreduce_fn fn, void* user);
+/* Overlap of the N-vector exchange of data::Ax with the decode (kernel mode 1, sharded jobs): tiles > 1 cuts the product into
+ * that many chunks of individuals and all-reduces each slice on a side HIP stream while the next chunk decodes; 0 / 1 = one
+ * message after the whole pass (default; also set by the environment variable GV_OVERLAP).  Bit-identical results. */
+int gv_set_overlap(gv_ctx* ctx, int tiles);
 int gv_comm_rank(const gv_ctx* ctx);
 int gv_comm_size(const gv_ctx* ctx);
 

@@ -15,13 +15,13 @@ ap.add_argument("--N", type=int, default=100000)
 ap.add_argument("--M", type=int, default=100000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--mode", type=int, default=0)
-ap.add_argument("--stripes-only", type=int, default=0)
+ap.add_argument("--stripes-only", type=int, default=0, help="1: two stripe sets, 2: one tile layout (no raw rows resident)")
 a = ap.parse_args()
 
 with capi.Shard(a.N, a.M) as sh:
     t = time.time()
     if a.stripes_only:
-        sh.set_layout(False, True)
+        sh.set_layout(False, a.stripes_only)
     sh.synth_bed(1234, 5000)
     sh.compute_markers_statistics()
     print("synth+stats s", time.time() - t, flush=True)
@@ -40,7 +40,7 @@ with capi.Shard(a.N, a.M) as sh:
         sh.ax_dev(x, p)
         sh.atx_dev(p, w)
     c = sh.counters()
-    print(c)
+    print(c, sh.decomp(), sh.tune_info())
     print("Ax  ms %.3f  GB/s %.1f" % (c["ms_ax"] / c["n_ax"], nbytes / (c["ms_ax"] / c["n_ax"] * 1e-3) / 1e9))
     print("ATx ms %.3f  GB/s %.1f" % (c["ms_atx"] / c["n_atx"], nbytes / (c["ms_atx"] / c["n_atx"] * 1e-3) / 1e9))
     # two-vector passes

@@ -191,3 +191,45 @@ def test_kernel_mode_0_warns_in_the_drivers(tmp_path):
     r1 = subprocess.run(base + ["--kernel-mode", "1"], capture_output=True, text=True, timeout=300)
     assert r0.returncode == 0 and r1.returncode == 0
     assert "--kernel-mode 0" in r0.stderr and "slower" in r0.stderr and "WARNING" not in r1.stderr
+
+
+def test_decomposition_picks_are_cached_across_processes(tmp_path):
+    """The first run on a (device, N, M, layout) measures the work decompositions and appends them to the cache file; the next
+    process reads them back instead of measuring (gv_tune_info).  Results never depend on the picks."""
+    import json
+    import sys
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from gvamp_amd import capi
+out = {}
+for stripes in (1, 2):
+    with capi.Shard(20000, 30000) as sh:
+        sh.set_layout(False, stripes)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(5, 5000)
+        sh.compute_markers_statistics()
+        assert sh.tune_info()[1] == "pending"
+        z = sh.Ax(np.ones(30000))
+        sec, src = sh.tune_info()
+        out[str(stripes)] = {"src": src, "sec": sec, "picks": sh.decomp(), "norm": float(np.linalg.norm(z))}
+print(json.dumps(out))
+""" % ROOT
+    env = dict(os.environ, GV_TUNE_CACHE_DIR=str(tmp_path / "cache"))
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    for k in ("1", "2"):
+        assert runs[0][k]["src"] == "measured" and runs[0][k]["sec"] > 0
+        assert runs[1][k]["src"] == "cache" and runs[1][k]["sec"] == 0
+        assert runs[0][k]["picks"] == runs[1][k]["picks"] and runs[0][k]["norm"] == runs[1][k]["norm"]
+    assert runs[0]["1"]["norm"] == runs[0]["2"]["norm"]
+    lines = open(tmp_path / "cache" / "decomp.txt").read().splitlines()
+    assert len(lines) == 2 and "|L0|" in lines[0] and "|L1|" in lines[1]
+    env["GV_TUNE_CACHE"] = "0"                                     # switched off: measured again, nothing written
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert json.loads(r.stdout.strip().splitlines()[-1])["1"]["src"] == "measured"
+    assert len(open(tmp_path / "cache" / "decomp.txt").read().splitlines()) == 2
