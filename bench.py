@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--CG-max-iter", type=int, default=50)
     ap.add_argument("--ld-block", type=int, default=64, help="second VAMP setting: markers per LD block (0 = skip that leg)")
     ap.add_argument("--ld-ppm", type=int, default=900000, help="second VAMP setting: within-block copy probability, 1e-6")
+    ap.add_argument("--no-tile-leg", action="store_true", help="skip the closing measurement of the one-layout (tile) kernels")
     ap.add_argument("--layout", type=int, default=1, help="resident re-encoding of kernel mode 1: 1 = two stripe sets "
                     "(2 x M*N/4 bytes), 2 = one tile layout (M*N/4 bytes)")
     ap.add_argument("--fuse-solves", type=int, default=2,
@@ -209,13 +210,15 @@ def main():
     sh.synth_bed(a.seed, 5000)
     sh.compute_markers_statistics()
     t_ingest = time.time() - t0
+    t_alloc, t_fill = sh.ingest_info()      # hipMalloc of the resident layouts (driver: page mapping / wipe) vs generating them
     if world > 1 or force_dist:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         sh.comm_init(world, rank, uid[0])
 
     rng = np.random.default_rng(7)          # same p on every rank's own slice
-    p = sh.vecM(rng.standard_normal(Mt)[S:S + M])
+    rng_p = rng.standard_normal(Mt)[S:S + M]
+    p = sh.vecM(rng_p)
     d = sh.vecM()
     tau, gam2 = 2.0, 1.35
 
@@ -244,6 +247,7 @@ def main():
         dt = float(t.item())
     cnt = sh.counters()
     sh.set_timing(0)
+    d_host = d.download()            # (after the timed region) the operator's output, compared with the tile-layout leg below
 
     job_bytes = 2 * alg_bytes(N, Mt)
     value = job_bytes * a.steps / dt / 1e9
@@ -279,7 +283,8 @@ def main():
                    "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
                    "resident_layout": ("fp64 raw rows" if a.mode == 0 else "two stripe sets, 2 x M*N/4 bytes" if a.layout == 1
                                        else "one tile layout, M*N/4 bytes"),
-                   "ingest_s": round(t_ingest, 2), "tune_s": round(tune_s, 3), "tune_source": tune_src},
+                   "ingest_s": round(t_ingest, 2), "ingest_alloc_s": round(t_alloc, 2), "ingest_fill_s": round(t_fill, 2),
+                   "tune_s": round(tune_s, 3), "tune_source": tune_src},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4),
@@ -340,7 +345,8 @@ def main():
         # what a user waits for: shard ingest (synthetic here: generated on the device) + picking the decompositions (0 when an
         # earlier run on this shape left them in the cache) + every VAMP iteration, the cold first one included
         out["vamp"]["time_to_solution_s"] = round(t_ingest + tune_s + out["vamp"]["wall_s_all_iterations"], 3)
-        out["vamp"]["time_to_solution_parts"] = {"ingest_s": round(t_ingest, 3), "tune_s": round(tune_s, 3), "tune_source": tune_src,
+        out["vamp"]["time_to_solution_parts"] = {"ingest_s": round(t_ingest, 3), "of_which_hipMalloc_s": round(t_alloc, 3),
+                                                 "tune_s": round(tune_s, 3), "tune_source": tune_src,
                                                  "iterations_s": out["vamp"]["wall_s_all_iterations"]}
         out["vamp"]["config"] = (
             "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, %d iterations; "
@@ -405,6 +411,56 @@ def main():
                                "(n_ax*t_ax + n_atx*t_atx) measured on the sample, scaled linearly by Mt/sample_markers")
         out["cpu_baseline"] = cb
     sh.close()
+    # ---- the same operator on ONE resident layout (gv_set_layout(.., 2): M*N/4 bytes instead of 2 x M*N/4), measured in the same
+    # process on the same box, and checked bit for bit against the two-layout result above --------------------------------
+    if a.mode == 1 and a.layout == 1 and not a.no_tile_leg:
+        barrier()
+        with capi.Shard(N, M, Mt=Mt, S=S, device=local_rank) as st:
+            st.set_layout(False, 2)
+            st.set_kernel_mode(1)
+            t1 = time.time()
+            st.synth_bed(a.seed, 5000)
+            st.compute_markers_statistics()
+            t_in = time.time() - t1
+            if world > 1 or force_dist:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                st.comm_init(world, rank, uid[0])
+            p2, d2 = st.vecM(rng_p), st.vecM()
+            for _ in range(2):
+                st.lmmse_mult(p2, tau, gam2, d2)
+            st.synchronize()
+            tt_s, tt_src = st.tune_info()
+            st.set_timing(2)
+            st.counters(reset=True)
+            barrier()
+            t1 = time.perf_counter()
+            nst = max(2, a.steps // 2)
+            for _ in range(nst):
+                st.lmmse_mult(p2, tau, gam2, d2)
+            st.synchronize()
+            barrier()
+            dt2 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            c2 = st.counters()
+            same = bool(np.array_equal(d2.download(), d_host))
+            if world > 1:
+                t = torch.tensor([1.0 if same else 0.0], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                same = bool(t.item() == 1.0)
+            m_ax = c2["ms_ax_kernel"] / max(c2["n_ax_kernel"], 1)
+            m_atx = c2["ms_atx_kernel"] / max(c2["n_atx_kernel"], 1)
+            out["tile_layout"] = {
+                "what": "the same step on ONE resident re-encoding that serves Ax and ATx (DESIGN.md section 3): resident genotype "
+                        "bytes per GPU %.1f GB instead of %.1f GB" % (M * ((N + 3) // 4) / 1e9, 2 * M * ((N + 3) // 4) / 1e9),
+                "value_GBps": round(job_bytes * nst / dt2 / 1e9, 2), "ms_per_step": round(dt2 / nst * 1e3, 4), "steps": nst,
+                "ax": {"avg_ms": round(m_ax, 4), "GBps": round(shard_bytes / (m_ax * 1e-3) / 1e9, 1) if m_ax > 0 else None},
+                "atx": {"avg_ms": round(m_atx, 4), "GBps": round(shard_bytes / (m_atx * 1e-3) / 1e9, 1) if m_atx > 0 else None},
+                "bit_identical_to_two_layouts": same, "ingest_s": round(t_in, 2), "tune_s": round(tt_s, 3), "tune_source": tt_src,
+                "decomposition": st.decomp()}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

@@ -22,7 +22,7 @@ EXPORTS = [
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
-    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_copy_bandwidth", "gv_read_bandwidth",
+    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
 
@@ -132,6 +132,7 @@ def load():
     L.gv_reset_counters.argtypes = [vp]
     L.gv_get_decomp.argtypes = [vp, C.POINTER(DecompInfo)]
     L.gv_tune_info.argtypes = [vp, dp, C.POINTER(C.c_int)]
+    L.gv_ingest_info.argtypes = [vp, dp, dp]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.gv_read_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     _LIB = L
@@ -447,6 +448,12 @@ class Shard:
                     n_ax_kernel=c.n_ax_kernel, n_atx_kernel=c.n_atx_kernel, ms_ax_kernel=c.ms_ax_kernel,
                     ms_atx_kernel=c.ms_atx_kernel, n_ax_pass=c.n_ax_pass, n_atx_pass=c.n_atx_pass,
                     n_allreduce=c.n_allreduce)
+
+    def ingest_info(self):
+        """(seconds allocating the resident layouts, seconds filling them) of the last ingest"""
+        a, f = C.c_double(), C.c_double()
+        self._ck(self.L.gv_ingest_info(self.h, C.byref(a), C.byref(f)))
+        return a.value, f.value
 
     def tune_info(self):
         """(seconds spent picking the decompositions, source: 'pending' / 'model' / 'measured' / 'cache' / 'fixed')"""

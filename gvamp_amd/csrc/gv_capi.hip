@@ -992,6 +992,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     c->have_raw = c->have_stripes = c->have_stats = false;
     if (c->want_raw && !c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(M > 0 ? M : 1) * P));
     if (!c->want_raw && c->bed) { (void)hipFree(c->bed); c->bed = nullptr; }
+    const auto t_in0 = std::chrono::steady_clock::now();
     const int want_layout = c->want_tile ? 1 : 0;
     if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
         // (re)build the geometry and the buffers of the MFMA family for the layout asked for
@@ -1028,6 +1029,8 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         pl.partial_bytes = pa > pb ? pa : pb;
         HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
+    HIPCHK(c, hipDeviceSynchronize());
+    const auto t_in1 = std::chrono::steady_clock::now();      // the layouts are allocated (the driver maps / wipes 100+ GB)
     const int64_t CH = file ? 8192 : 32768;   // file source: each pinned staging buffer is CH * mbytes bytes
     uint8_t* tmp = nullptr;
     uint8_t* stage[2] = {nullptr, nullptr};
@@ -1083,6 +1086,8 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         if (stage_free[b]) (void)hipEventDestroy(stage_free[b]);
     }
     if (tmp) (void)hipFree(tmp);
+    c->ingest_alloc_s = std::chrono::duration<double>(t_in1 - t_in0).count();
+    c->ingest_fill_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in1).count();
     if (rc) return rc;
     c->have_raw = c->want_raw;
     c->have_stripes = c->want_stripes;
@@ -1593,6 +1598,11 @@ int gv_reset_counters(gv_ctx* c) {
     c->cnt = gv_counters{};
     return 0;
 }
+int gv_ingest_info(gv_ctx* c, double* alloc_seconds, double* fill_seconds) {
+    if (alloc_seconds) *alloc_seconds = c->ingest_alloc_s;
+    if (fill_seconds) *fill_seconds = c->ingest_fill_s;
+    return 0;
+}
 int gv_tune_info(gv_ctx* c, double* seconds, int* source) {
     if (seconds) *seconds = c->tune_seconds;
     if (source) *source = c->ks_tuned ? c->tune_source : -1;
@@ -1650,9 +1660,13 @@ int gv_read_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {
     if (blocks / nwaves < 16) nwaves = blocks / 16 > 0 ? blocks / 16 : 1;
     const int64_t bpw = blocks / nwaves;
     unsigned int* sink = reinterpret_cast<unsigned int*>(c->red_out);
-    gvk::read_bw(c->stream, buf, bpw, nwaves, sink);
+    // lane -> piece pattern of the loads: that of the resident layout's kernels (GV_READ_PERM = 0 / 1 / 2 overrides: linear, tile
+    // layout ATx side, tile layout Ax side)
+    int perm = (c->have_stripes && c->plan.layout == 1) ? 1 : 0;
+    if (const char* e = getenv("GV_READ_PERM")) perm = atoi(e);
+    gvk::read_bw(c->stream, buf, bpw, nwaves, sink, perm);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < reps; i++) gvk::read_bw(c->stream, buf, bpw, nwaves, sink);
+    for (int i = 0; i < reps; i++) gvk::read_bw(c->stream, buf, bpw, nwaves, sink, perm);
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     KCHK(c);

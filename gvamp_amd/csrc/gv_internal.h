@@ -49,6 +49,7 @@ struct gv_ctx {
     std::vector<gvm::Decomp> dec_cand_m, dec_cand_n;
     bool ks_fixed_m = false, ks_fixed_n = false;   // an override fixed the decomposition: nothing to pick
     bool ks_tuned = false;
+    double ingest_alloc_s = 0.0, ingest_fill_s = 0.0;   // last ingest: allocating the resident layouts / filling them
     double tune_seconds = 0.0;      // wall time the pick cost (0 when it came from the cache)
     int tune_source = 0;            // 0 model's first candidate, 1 measured, 2 cache, 3 fixed by an override / nothing to tune
 
@@ -155,10 +156,13 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
 // device-resident CG step (gv_solvers.hip: cg_run_device)
 void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
             double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-            double* const* red, double diag, int64_t n, unsigned int* counters);
+            double* const* red, double diag, int64_t n);
+void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);   // ordered sum of block partials
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
-                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq);
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride);
+void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
+               const int* ride, int64_t n);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,
                double* partial, double* out);                 // mu += alpha p ; out[0] = <v, mu>
 void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double diag, double* z, const double* mu,
@@ -170,7 +174,7 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
 void pvals_test(hipStream_t s, const uint32_t* cnt, const double* mave, const double* msig, const double* sums4,
                 const double* xself, double self_scale, const int* chrom, int ch, int64_t M, double* pvals);
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n);
-void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink);
+void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink, int perm = 0);
 }  // namespace gvk
 
 // ---- internals shared by the translation units of the C ABI (gv_capi.hip, gv_solvers.hip) ------------------------------

@@ -393,19 +393,25 @@ __global__ void k_copy(const double2* __restrict__ src, double2* __restrict__ ds
 // 4 KiB blocks (one coalesced, non-temporal KiB per instruction), two blocks in flight, nothing but an XOR per load.
 // What it reaches is the ceiling a streaming kernel can be held against on this part.
 typedef unsigned int rd_u32x4 __attribute__((ext_vector_type(4)));
+// perm: which 16-byte piece of a 4 KiB block a lane takes in load i -- 0: lane-linear (the stripe kernels), 1: the ATx side of
+// the tile layout (KiB i, piece (lane & 15) * 4 + (lane >> 4)), 2: its Ax side (256 contiguous bytes of each KiB)
 __global__ __launch_bounds__(256, 3) void k_read_stream(const rd_u32x4* __restrict__ src, int64_t blocks_per_wave,
-                                                        int64_t nwaves, unsigned int* __restrict__ sink) {
-    const int lane = threadIdx.x & 63;
+                                                        int64_t nwaves, unsigned int* __restrict__ sink, int perm) {
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= nwaves) return;
-    const rd_u32x4* p = src + w * blocks_per_wave * 256 + lane;
+    const rd_u32x4* p = src + w * blocks_per_wave * 256;
+    int off[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        off[i] = perm == 1 ? i * 64 + r * 4 + g : (perm == 2 ? (r >> 2) * 64 + (4 * i + g) * 4 + (r & 3) : i * 64 + lane);
     rd_u32x4 acc = {0, 0, 0, 0};
     rd_u32x4 a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) a[i] = __builtin_nontemporal_load(p + i * 64);
+    for (int i = 0; i < 4; i++) a[i] = __builtin_nontemporal_load(p + off[i]);
     for (int64_t k = 1; k < blocks_per_wave; k++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) b[i] = __builtin_nontemporal_load(p + k * 256 + i * 64);
+        for (int i = 0; i < 4; i++) b[i] = __builtin_nontemporal_load(p + k * 256 + off[i]);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc ^= a[i];
 #pragma unroll
@@ -540,16 +546,14 @@ __global__ __launch_bounds__(256) void k_cg_b(double* __restrict__ r, const doub
 // ---- device-resident CG step (gv_solvers.hip: cg_run_device) ------------------------------------------------------------
 // One launch for every still-active system (blockIdx.y): alpha = <r,z> / <d,p> from the system's state block and the reduced
 // <d,p> the ATx epilogue left, then k_cg_a and k_cg_b in one sweep -- mu += alpha p, r -= alpha d, z = r / diag -- with the
-// block partials of <v,mu>, <r,z>, <r,r>; the block that takes the last ticket adds them up in the fixed order of k_finalize
-// (red[v][0..2]).  (The reference leaves r one step behind on an Onsager-rule exit, vamp.cpp:1176-1193; here r is always
+// block partials of <v,mu>, <r,z>, <r,r>, added up by gvk::finalize in the fixed order of k_finalize (red[v][0..2]).  (The reference leaves r one step behind on an Onsager-rule exit, vamp.cpp:1176-1193; here r is always
 // current, which is what the by-products of gv_cg_solve2x want and nobody else reads.)
 struct CgxAB {
     double* st[2]; double* mu[2]; const double* p[2]; const double* v[2]; double* r[2]; const double* d[2]; double* z[2];
     const double* dp[2]; double* part[2]; double* red[2];
 };
-__global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n, unsigned int* __restrict__ counters) {
-    __shared__ double sh[256];
-    __shared__ bool is_last;
+__global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n) {
+    __shared__ double sh[4];
     const int v = blockIdx.y;
     double* st = a.st[v];
     if (st[gvm::ST_ACTIVE] == 0.0) return;
@@ -579,28 +583,9 @@ __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n,
     if (threadIdx.x == 0) {
         double* o = a.part[v] + (int64_t)blockIdx.x * 3;
         o[0] = s_vmu; o[1] = s_rz; o[2] = s_rr;
-        __threadfence();
-        const unsigned int t = atomicAdd(counters + v, 1u);
-        is_last = t == gridDim.x - 1;
-        if (is_last) counters[v] = 0;
+        if (blockIdx.x == 0) st[gvm::ST_ALPHA] = alpha;                   // for A mu += alpha A p (k_axpy_st)
     }
-    __syncthreads();
-    if (!is_last) return;
-    if (threadIdx.x == 0) st[gvm::ST_ALPHA] = alpha;                      // for A mu += alpha A p (k_axpy_st)
-    for (int k = 0; k < 3; k++) {
-        double acc = 0.0;
-        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
-            acc += __longlong_as_double((long long)__hip_atomic_load(
-                reinterpret_cast<const unsigned long long*>(a.part[v] + (int64_t)b * 3 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) a.red[v][k] = sh[0];
-    }
+    // (block partials -> gvk::finalize behind this kernel; see k_fin_atx_dot for why not a last-block ticket)
 }
 // y += st[ST_ALPHA] * x while the system is active (A mu accumulated from the A p_k, gv_cg_extras.a_mu_a)
 __global__ void k_axpy_st(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ st, int64_t n) {
@@ -609,15 +594,33 @@ __global__ void k_axpy_st(double* __restrict__ y, const double* __restrict__ x, 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += alpha * x[i];
 }
+// the rider's product (see gvm::CgHook::ride) out of the slot that carried it
+__global__ void k_ride_copy(double* __restrict__ out, const double* __restrict__ w0, const double* __restrict__ w1,
+                            const double* __restrict__ st0, const double* __restrict__ st1, const int* __restrict__ ride,
+                            int64_t n) {
+    if (*ride != 1) return;
+    const bool a0 = st0[gvm::ST_ACTIVE] != 0.0, a1 = st1[gvm::ST_ACTIVE] != 0.0;
+    if (a0 == a1) return;
+    const double* __restrict__ src = a0 ? w1 : w0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[i];
+}
 // The scalar part of a CG step (vamp.cpp:1174-1223) for every system, on the device: iteration count, Onsager rule, beta,
 // <r,z>, relative residual and its trace, stopping rules; then *go = some system is still running, and the status of every
 // system goes to the host mailbox (slot = seq & 1: the host reads status s while the device may already write s + 1).
-struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; };
+struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; int* ride; };
 constexpr int CGX_STATUS = 8;   // doubles per system in the mailbox: active, iters, converged, rel_err, onsager, n_relres, stepped
 __global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
                              unsigned long long* flag, unsigned long long seq) {
     __shared__ int any;
-    if (threadIdx.x == 0) any = 0;
+    if (threadIdx.x == 0) {
+        any = 0;
+        // the rider rode in this step if it was pending and exactly one system had finished before the step (the flags
+        // still say so: they are only changed below)
+        if (a.ride && *a.ride == 1 && a.nsys == 2 &&
+            ((a.st[0][gvm::ST_ACTIVE] != 0.0) != (a.st[1][gvm::ST_ACTIVE] != 0.0)))
+            *a.ride = 2;
+    }
     __syncthreads();
     const int v = threadIdx.x;
     if (v < a.nsys) {
@@ -658,6 +661,7 @@ __global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __rest
         double* mb = mailbox + (seq & 1ull) * (2 * CGX_STATUS) + v * CGX_STATUS;
         mb[0] = st[gvm::ST_ACTIVE]; mb[1] = st[gvm::ST_ITERS]; mb[2] = st[gvm::ST_CONV]; mb[3] = st[gvm::ST_RELERR];
         mb[4] = st[gvm::ST_ONS]; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED];
+        mb[7] = a.ride ? (double)*a.ride : 0.0;
     }
     __threadfence_system();
     __syncthreads();
@@ -1005,21 +1009,32 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
 
 void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
             double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-            double* const* red, double diag, int64_t n, unsigned int* counters) {
+            double* const* red, double diag, int64_t n) {
     CgxAB a{};
     for (int k = 0; k < nsys; k++) {
         a.st[k] = st[k]; a.mu[k] = mu[k]; a.p[k] = p[k]; a.v[k] = v[k]; a.r[k] = r[k]; a.d[k] = d[k]; a.z[k] = z[k];
         a.dp[k] = dp[k]; a.part[k] = part[k]; a.red[k] = red[k];
     }
-    hipLaunchKernelGGL(k_cgx_ab, dim3(red_blocks(n, 256), nsys), dim3(256), 0, s, a, diag, n, counters);
+    const int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_cgx_ab, dim3(nb, nsys), dim3(256), 0, s, a, diag, n);
+    // (an inactive system's kernel slice returns at once and its stale partials are summed into a slot nobody reads)
+    for (int k = 0; k < nsys; k++) hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, s, part[k], nb, 3, red[k]);
+}
+void finalize(hipStream_t s, const double* partial, int nb, int K, double* out) {
+    hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
 }
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n) {
     hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
 }
+void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
+               const int* ride, int64_t n) {
+    hipLaunchKernelGGL(k_ride_copy, dim3(nblk(n, 256)), dim3(256), 0, s, out, w0, w1, st0, st1, ride, n);
+}
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
-                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq) {
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride) {
     CgxDecide a{};
     a.nsys = nsys;
+    a.ride = ride;
     for (int k = 0; k < nsys; k++) { a.st[k] = st[k]; a.red[k] = red[k]; a.relres[k] = relres[k]; }
     hipLaunchKernelGGL(k_cgx_decide, dim3(1), dim3(64), 0, s, a, gam2, max_iter, go, mailbox, flag, seq);
 }
@@ -1063,9 +1078,9 @@ void pvals_test(hipStream_t s, const uint32_t* cnt, const double* mave, const do
 void copy_bw(hipStream_t s, const double* src, double* dst, int64_t n) {
     hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, s, (const double2*)src, (double2*)dst, n / 2);
 }
-void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink) {
+void read_bw(hipStream_t s, const void* src, int64_t blocks_per_wave, int64_t nwaves, unsigned int* sink, int perm) {
     hipLaunchKernelGGL(k_read_stream, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, (const rd_u32x4*)src,
-                       blocks_per_wave, nwaves, sink);
+                       blocks_per_wave, nwaves, sink, perm);
 }
 
 }  // namespace gvk

@@ -218,7 +218,8 @@ constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per v
 // block partials: [0] = max(|c|,|e|), [1] = sum mave*c
 // CG hook (device-resident CG): x is the search direction p of system st; when that system took a step and is still
 // running, p <- z + beta p (vamp.cpp:1209-1210) happens here, on the way into the operands, instead of in a launch of its own.
-struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2]; };
+struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2];
+                const int* ride; const double* alt_x; };
 __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
                                                  int64_t M, double* __restrict__ partial, double* __restrict__ scal,
                                                  unsigned int* __restrict__ counters) {
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     double* __restrict__ cv = a.cv[v];
     double* __restrict__ ev = a.ev[v];
     const double* st = a.st[v];
+    // the rider takes the slot of the one system that has finished (uniform over the launch: nothing changes these flags
+    // between the k_cgx_decide of the previous step and the one of this step)
+    if (a.ride && *a.ride == 1 && st && st[gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) x = a.alt_x;
     const bool upd = st && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;
     const double beta = upd ? st[gvm::ST_BETA] : 0.0;
     const double* zz = a.z[v];
@@ -1110,17 +1114,15 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
 }
 
 // The same epilogue as one half of a device-resident CG step: out = d = tau ATx + gam2 p (addx = p is the search direction)
-// and, in the same sweep, the block partials of <d, p> in the summation order of gvk::dots (grid-stride, block tree); the
-// block that takes the last ticket adds them up in the fixed order of k_finalize and leaves <d, p> in dot_out[v][0].
+// and, in the same sweep, the block partials of <d, p> in the summation order of gvk::dots (grid-stride, block tree);
+// gvk::finalize adds them up in the fixed order of k_finalize and leaves <d, p> in dot_out[v][0].
 // A slot whose system has finished is skipped (its d is not needed and its scalars must not move).
 struct FinAtxDot { double* out[2]; const double* addx[2]; const double* st[2]; double* part[2]; double* dot_out[2]; int pv[2]; };
 __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                      const double* __restrict__ scal_base, const double* __restrict__ mave,
                                                      const double* __restrict__ msig, double inv_sqrt_n, FinAtxDot a, double tau,
-                                                     double gam2, int ppk, int64_t nkb, int64_t skL,
-                                                     unsigned int* __restrict__ counters) {
-    __shared__ double sh[256];
-    __shared__ bool is_last;
+                                                     double gam2, int ppk, int64_t nkb, int64_t skL) {
+    __shared__ double sh[4];
     const int v = blockIdx.y, p0 = 2 * a.pv[v];
     const double* st = a.st[v];
     if (st && st[gvm::ST_ACTIVE] == 0.0) return;
@@ -1154,24 +1156,9 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-        __threadfence();
-        const unsigned int t = atomicAdd(counters + v, 1u);
-        is_last = t == gridDim.x - 1;
-        if (is_last) counters[v] = 0;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    double acc = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) acc += ld_l2(a.part[v] + b);
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.dot_out[v][0] = sh[0];
+    if (threadIdx.x == 0) a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    // (the block partials are added up by gvk::finalize, launched behind this kernel: a last-block ticket would serialise
+    // ~1000 atomics on one address, 50 ns each -- measured 74 us for this kernel at M = 500k against 16 us without)
 }
 
 // data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
@@ -1339,8 +1326,10 @@ static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, c
         f.out[v] = out[v]; f.addx[v] = addx[v]; f.st[v] = cg.state[v]; f.part[v] = cg.dot_part[v]; f.dot_out[v] = cg.dot_out[v];
         f.pv[v] = v;
     }
-    hipLaunchKernelGGL(k_fin_atx_dot, dim3(dot_blocks(pl.M), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL, cg.dot_counters);
+    const int nb = dot_blocks(pl.M);
+    hipLaunchKernelGGL(k_fin_atx_dot, dim3(nb, nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL);
+    for (int v = 0; v < nv; v++) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
 }
 
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
@@ -1421,9 +1410,11 @@ static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64
 void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
              double* red_partial, const CgHook* cg) {
     const int nv = xb ? 2 : 1, nb = prep_blocks(pl.M);
-    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    if (cg)
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr, nullptr};
+    if (cg) {
         for (int v = 0; v < nv; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
+        if (nv == 2) { pa.ride = cg->ride; pa.alt_x = cg->alt_x; }
+    }
     hipLaunchKernelGGL(k_prep_ax, dim3(nb, nv), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
     quant_ax(s, pl, nv);
 }

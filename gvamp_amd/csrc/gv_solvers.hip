@@ -191,7 +191,7 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
 // *go == 0, the update kernels on the system's ACTIVE flag): one step of empty launches, ~50 us.  Sharded jobs: the
 // reductions are all-reduced in-stream on the device buffer (RCCL), still without the host.  Per system the arithmetic is
 // that of the host-driven loop -- the same reductions in the same order, the same IEEE divisions and square roots.
-struct CgxStatus { double active, iters, conv, rel, ons, nrel, stepped; };
+struct CgxStatus { double active, iters, conv, rel, ons, nrel, stepped, ride; };
 
 static int cgx_alloc(gv_ctx* c, int max_iter) {
     if (!c->cgx_state) {
@@ -225,13 +225,19 @@ static int cgx_wait(gv_ctx* c, unsigned long long seq, CgxStatus* out2) {
     const double* mb = c->mbox + (seq & 1ull) * 16;
     for (int v = 0; v < 2; v++) {
         const double* q = mb + 8 * v;
-        out2[v] = CgxStatus{q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
+        out2[v] = CgxStatus{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
     }
     return 0;
 }
 
 // sys[k] (k < nsys <= 2) are initialised (phase 1: r, z, p = z, rz, norm_v set; req = p, res = d).  Runs them to their
 // stopping rules.  *ride_done tells whether the rider's product was taken along.
+//
+// The rider (ride_x -> ride_out = A ride_x, the z1 of --fuse-solves 2) wants the free slot of a two-vector pass in the first
+// step after ONE of the two systems has finished.  The host learns that a step late, so the slot is re-assigned on the
+// device: while the rider is pending every step is enqueued two-vector shaped (slot v = system v); k_prep_ax feeds ride_x
+// into the slot of a system that has finished (if the other one is still running), k_ride_copy moves the product out and
+// k_cgx_decide marks the rider done (status word 7) -- the same step in which the host-driven loop would have placed it.
 static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x,
                          double* ride_out, bool* ride_done) {
     const int64_t M = c->M, npad = c->npad;
@@ -244,6 +250,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     if (ensure_work(c) || ensure_w2(c)) return 1;
     if (M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
     c->plan.ev0 = c->plan.ev1 = nullptr;       // no per-launch events inside the loop
+    const bool riding = ride_x != nullptr && nsys == 2;
     // ---- initial states -> device
     double* pin = c->cgx_pin;
     int go0 = 0;
@@ -259,35 +266,38 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     }
     int* pin_go = reinterpret_cast<int*>(pin + 2 * gvm::ST_SIZE);
     pin_go[0] = go0;
+    pin_go[1] = riding ? 1 : 0;                // 1: rider pending, 2: rode
     HIPCHK(c, hipMemcpyAsync(c->cgx_state, pin, sizeof(double) * 2 * gvm::ST_SIZE, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->cgx_go, pin_go, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->cgx_go, pin_go, 2 * sizeof(int), hipMemcpyHostToDevice, st));
     double* dst[2] = {c->cgx_state, c->cgx_state + gvm::ST_SIZE};
     double* drel[2] = {c->cgx_rel, c->cgx_rel + c->cgx_relcap};
+    int* d_ride = c->cgx_go + 1;
     unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
     bool host_active[2] = {nsys > 0 && sys[0].active, nsys > 1 && sys[1].active};
-    int done_iters[2] = {nsys > 0 ? sys[0].iters : 0, nsys > 1 ? sys[1].iters : 0};
+    const int done_iters[2] = {nsys > 0 ? sys[0].iters : 0, nsys > 1 ? sys[1].iters : 0};
     CgxStatus last[2] = {};
-    bool have_last = false;
-    // bookkeeping per enqueued step: which systems it carried, whether the rider rode
-    struct Step { unsigned long long seq; bool ride; };
-    std::vector<Step> steps;
-    int executed = 0;                       // steps that ran with *go == 1
-    bool ride_pending = ride_x != nullptr, rode = false;
+    bool have_last = false, ride_pending = riding, rode_seen = false;
+    std::vector<unsigned long long> steps;      // status sequence number of every enqueued step
     auto apply_status = [&](const CgxStatus* s2) {
         for (int k = 0; k < nsys; k++) host_active[k] = s2[k].active != 0.0;
         last[0] = s2[0]; last[1] = s2[1];
         have_last = true;
+        if (s2[0].ride == 2.0) { ride_pending = false; rode_seen = true; }
     };
     for (;;) {
         int act[2], na = 0;
         for (int k = 0; k < nsys; k++) if (host_active[k]) act[na++] = k;
         if (na == 0) break;
-        // ---- enqueue one step for the systems the host believes active
+        // ---- enqueue one step: the systems the host believes active; two-vector shaped (slot v = system v) while both run
+        // or while the rider still waits for a slot
+        const bool two = na == 2 || ride_pending;
+        if (two) { act[0] = 0; act[1] = 1; }
+        const int ns = two ? 2 : 1;
         gvm::CgHook hk;
         hk.go = c->cgx_go;
         hk.dot_counters = c->cgx_counters;
-        const bool ride_now = na == 1 && ride_pending;
-        for (int j = 0; j < na; j++) {
+        if (ride_pending) { hk.ride = d_ride; hk.alt_x = ride_x; }
+        for (int j = 0; j < ns; j++) {
             CgSys& s = sys[act[j]];
             hk.state[j] = dst[act[j]];
             hk.p[j] = s.p;
@@ -296,28 +306,19 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             hk.dot_out[j] = c->red_out + 8 * act[j];
         }
         double* wn[2] = {c->w_n->d, c->w_n2->d};
-        if (na == 2 || ride_now) {
-            const double* xb = na == 2 ? sys[act[1]].p : ride_x;
-            double* ob = na == 2 ? wn[1] : ride_out;
+        if (two) {
             if (ovl) {             // chunks of individuals, each slice exchanged on the side stream behind the next chunk
-                if (ax_overlapped(c, 2, sys[act[0]].p, xb, wn[0], ob, &hk)) return 1;
+                if (ax_overlapped(c, 2, sys[0].p, sys[1].p, wn[0], wn[1], &hk)) return 1;
             } else if (M == 0) {   // empty shard: zeros into the same collectives (the search directions are empty vectors)
-                gvk::fill(st, wn[0], npad, 0.0);
-                gvk::fill(st, ob, npad, 0.0);
+                gvk::fill(st, wn[0], 2 * npad, 0.0);
             } else
-                gvm::ax2(st, c->plan, sys[act[0]].p, xb, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], ob, &hk);
+                gvm::ax2(st, c->plan, sys[0].p, sys[1].p, c->mave, c->msig, c->mask2, npad, multi ? 1.0 : scale, c->red_partial, wn[0], wn[1], &hk);
             KCHK(c);
             if (multi && !ovl) {
-                if (na == 2) {
-                    if (comm_allreduce(c, wn[0], 2 * npad)) return 1;      // w_n | w_n2: one message
-                    gvk::scale_vec(st, wn[0], 2 * npad, scale);
-                } else {
-                    if (comm_allreduce(c, wn[0], npad)) return 1;
-                    if (comm_allreduce(c, ob, npad)) return 1;
-                    gvk::scale_vec(st, wn[0], npad, scale);
-                    gvk::scale_vec(st, ob, npad, scale);
-                }
+                if (comm_allreduce(c, wn[0], 2 * npad)) return 1;      // w_n | w_n2: one message
+                gvk::scale_vec(st, wn[0], 2 * npad, scale);
             }
+            if (ride_pending) gvk::ride_copy(st, ride_out, wn[0], wn[1], dst[0], dst[1], d_ride, npad);
         } else {
             if (ovl) {
                 if (ax_overlapped(c, 1, sys[act[0]].p, nullptr, wn[0], nullptr, &hk)) return 1;
@@ -330,63 +331,61 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             }
         }
         if (M == 0)            // empty shard: no markers, <d,p> = 0 from this rank
-            gvk::fill(st, c->red_out, 8 * (act[na - 1] + 1), 0.0);
-        else if (na == 2)
-            gvm::atx2(st, c->plan, wn[0], wn[1], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[1]].d,
-                      sys[act[0]].p, sys[act[1]].p, tau, gam2, &hk);
+            gvk::fill(st, c->red_out, 8 * (act[ns - 1] + 1), 0.0);
+        else if (two)
+            gvm::atx2(st, c->plan, wn[0], wn[1], npad, c->mave, c->msig, scale, c->red_partial, sys[0].d, sys[1].d,
+                      sys[0].p, sys[1].p, tau, gam2, &hk);
         else
             gvm::atx(st, c->plan, wn[0], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[0]].p, tau, gam2, &hk);
         KCHK(c);
-        const int K = 8 * (act[na - 1] + 1);
+        const int K = 8 * (act[ns - 1] + 1);
         if (multi && comm_allreduce(c, c->red_out, K)) return 1;               // <d,p>
         {
             double *a_st[2], *a_mu[2], *a_r[2], *a_z[2], *a_part[2], *a_red[2];
             const double *a_p[2], *a_v[2], *a_d[2], *a_dp[2];
-            for (int j = 0; j < na; j++) {
+            for (int j = 0; j < ns; j++) {
                 CgSys& s = sys[act[j]];
                 a_st[j] = dst[act[j]]; a_mu[j] = s.mu; a_p[j] = s.p; a_v[j] = s.v; a_r[j] = s.r; a_d[j] = s.d; a_z[j] = s.z;
                 a_dp[j] = c->red_out + 8 * act[j];
                 a_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8;
                 a_red[j] = c->red_out + 8 * act[j];
             }
-            gvk::cgx_ab(st, na, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M, c->cgx_counters + 2);
-            for (int j = 0; j < na; j++)
+            gvk::cgx_ab(st, ns, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M);
+            for (int j = 0; j < ns; j++)
                 if (sys[act[j]].az) gvk::axpy_st(st, sys[act[j]].az, wn[j], dst[act[j]], npad);   // A mu += alpha A p
             KCHK(c);
             if (multi && comm_allreduce(c, c->red_out, K)) return 1;           // <v,mu>, <r,z>, <r,r>
             const double* c_red[2] = {c->red_out, c->red_out + 8};
             double* c_rel[2] = {sys[0].relres ? drel[0] : nullptr, (nsys > 1 && sys[1].relres) ? drel[1] : nullptr};
             const unsigned long long seq = ++c->mbox_seq;
-            gvk::cgx_decide(st, nsys, dst, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq);
+            gvk::cgx_decide(st, nsys, dst, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq,
+                            (two && ride_pending) ? d_ride : nullptr);
             KCHK(c);
-            steps.push_back(Step{seq, ride_now});
+            steps.push_back(seq);
         }
-        if (ride_now) ride_pending = false;
         // ---- the status of the step BEFORE the one just enqueued
         if (steps.size() >= 2) {
             CgxStatus s2[2];
-            if (cgx_wait(c, steps[steps.size() - 2].seq, s2)) return 1;
+            if (cgx_wait(c, steps[steps.size() - 2], s2)) return 1;
             apply_status(s2);
         }
     }
     // ---- drain: the last enqueued step's status is the final one (a dropped step republishes the unchanged state)
     if (!steps.empty()) {
         CgxStatus s2[2];
-        if (cgx_wait(c, steps.back().seq, s2)) return 1;
+        if (cgx_wait(c, steps.back(), s2)) return 1;
         apply_status(s2);
     }
-    // executed steps = the largest iteration count reached inside this loop; a rider rode if its step was executed
+    bool rode = false;
     if (have_last) {
-        int most = 0;
+        int executed = 0;                       // steps that ran with *go == 1 = the largest iteration count reached in here
         for (int k = 0; k < nsys; k++) {
             const int it = (int)last[k].iters - done_iters[k];
-            if (it > most) most = it;
+            if (it > executed) executed = it;
             c->cnt.n_ax += it;
             c->cnt.n_atx += it;
         }
-        executed = most;
-        for (size_t i = 0; i < steps.size(); i++)
-            if (steps[i].ride && (int)i < executed) rode = true;
+        rode = riding && rode_seen;
         if (rode) c->cnt.n_ax += 1;
         c->cnt.n_ax_pass += executed;
         c->cnt.n_atx_pass += executed;

@@ -256,6 +256,9 @@ typedef struct {
     float taper;             /* uniform split: taper of the segment lengths */
     int tuned;               /* 1 once the pick has been made (measured or read from the cache) */
 } gv_decomp_info;
+/* Wall time of the last ingest (gv_upload_bed / gv_upload_bed_file / gv_synth_bed), split into allocating the resident
+ * layouts (hipMalloc of 100+ GB: the driver maps and wipes the pages; 0 when the buffers were reused) and filling them. */
+int gv_ingest_info(gv_ctx* ctx, double* alloc_seconds, double* fill_seconds);
 int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
 /* How the picks were made: *source = -1 not yet (the first matvec in kernel mode 1 makes them), 0 the cost model's first
  * candidate (tuning impossible), 1 measured on the device now (*seconds of wall time), 2 read from the cache an earlier run on

@@ -64,7 +64,8 @@ def main():
         "kernel_sources_sha256": kernel_sources_sha256(),
     }
     for key, frag in (("ax", "k_mfma_matvec<1,"), ("atx", "k_mfma_matvec<0,"), ("ax2", "k_mfma_matvec<3,"),
-                      ("atx2", "k_mfma_matvec<2,")):
+                      ("atx2", "k_mfma_matvec<2,"), ("tile_ax", "k_mfma_tile<1, 3,"), ("tile_atx", "k_mfma_tile<0, 0,"),
+                      ("tile_atx2", "k_mfma_tile<0, 2,")):
         fk, wk = pick(fetch, frag), pick(write, frag)
         if fk is None or wk is None:
             continue

@@ -95,9 +95,8 @@ def test_dual_solve_with_by_products_device_loop_equals_host_loop(N, M, warm, ri
         with host_loop():
             h = run()
         assert d["sa"] == h["sa"] and d["sb"] == h["sb"]
-        for k in ("n_ax", "n_atx", "n_atx_pass"):
+        for k in ("n_ax", "n_atx", "n_ax_pass", "n_atx_pass"):
             assert d["cnt"][k] == h["cnt"][k], (k, d["cnt"][k], h["cnt"][k])
-        assert h["cnt"]["n_ax_pass"] <= d["cnt"]["n_ax_pass"] <= h["cnt"]["n_ax_pass"] + (1 if ride else 0)   # a late rider
         assert np.allclose(d["ra"], h["ra"], rtol=1e-10) and np.allclose(d["rb"], h["rb"], rtol=1e-10)
         assert np.isclose(d["ons"], h["ons"], rtol=1e-12)
         for k in ("mu_a", "mu_b", "amu", "ata"):
@@ -128,11 +127,9 @@ def test_full_vamp_run_device_loop_vs_host_loop_and_oracle(oracle):
         d, h = runs[("d", fuse)], runs[("h", fuse)]
         for it in range(5):
             td, th, to = d.trace[it], h.trace[it], ref.trace[it]
-            for f in ("cg_iters", "onsager_iters", "n_ax", "n_atx", "n_atx_pass", "L_after"):
+            # (the rider z1 = A x1_hat of fuse 2 is placed on the device, in the very step the host-driven loop would use)
+            for f in ("cg_iters", "onsager_iters", "n_ax", "n_atx", "n_ax_pass", "n_atx_pass", "L_after"):
                 assert td[f] == th[f], (fuse, it, f, td[f], th[f])
-            # the host of the device loop learns one step late that a slot of the two-vector pass has become free, so the
-            # rider z1 = A x1_hat (fuse 2) can miss it and take a pass of its own
-            assert th["n_ax_pass"] <= td["n_ax_pass"] <= th["n_ax_pass"] + (1 if fuse == 2 else 0), (fuse, it)
             assert (td["cg_iters"], td["onsager_iters"]) == (to["cg_iters"], to["onsager_iters"])
             assert np.isclose(td["gamw"], th["gamw"], rtol=1e-10) and np.isclose(td["gamw"], to["gamw"], rtol=1e-6)
         assert rel(d.x_est, h.x_est) < 1e-11 and rel(d.x_est, ref.x_est) < 1e-7
