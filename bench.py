@@ -257,7 +257,13 @@ def main():
     ms_atx = cnt["ms_atx_kernel"] / max(cnt["n_atx_kernel"], 1)
     ax_gbps = shard_bytes / (ms_ax * 1e-3) / 1e9 if ms_ax > 0 else 0.0
     atx_gbps = shard_bytes / (ms_atx * 1e-3) / 1e9 if ms_atx > 0 else 0.0
-    kname = "k_mfma_matvec<1, SK> (Ax)" if a.mode == 1 else "k_ax_f64"
+    dec = sh.decomp()
+    if a.mode == 1 and a.layout == 2:     # template arguments: <DIR, MODE, balanced decomposition, device-CG instantiation>
+        kname = "k_mfma_tile<1, 3, %s, false> (Ax)" % ("true" if "balanced_cells" in dec["ax"] else "false")
+    elif a.mode == 1:                     # <MODE, balanced decomposition, device-CG instantiation>
+        kname = "k_mfma_matvec<1, %s, false> (Ax)" % ("true" if "balanced_cells" in dec["ax"] else "false")
+    else:
+        kname = "k_ax_f64"
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes of this same command (counters cannot be
     # read from inside the process).  The newest committed summary is quoted ONLY when it was taken on this configuration
     # AND on these very kernel sources (sha256 of gv_mfma.hip recorded by scripts/pmc_summary.py); otherwise null.
@@ -297,7 +303,7 @@ def main():
     }
     # what each rank ran: shard, picked decompositions, kernel and exchange times of the timed region (HIP events)
     mine = {"rank": rank, "markers": M, "first_marker": S, "ms_ax_kernel": round(ms_ax, 4), "ms_atx_kernel": round(ms_atx, 4),
-            "ms_allreduce_per_ax": round(cnt["ms_allreduce"] / max(cnt["n_allreduce"], 1), 4), "decomposition": sh.decomp()}
+            "ms_allreduce_per_ax": round(cnt["ms_allreduce"] / max(cnt["n_allreduce"], 1), 4), "decomposition": dec}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world

@@ -290,7 +290,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 }
 
 // ---- persisted picks ---------------------------------------------------------------------------------------------
-// The decomposition picked for a (device, CU count, N, M) is appended to a small text file under $GV_TUNE_CACHE_DIR, else
+// The decomposition picked for a (device ISA, CU count, N, M, layout) is appended to a small text file under $GV_TUNE_CACHE_DIR, else
 // $XDG_CACHE_HOME/gvamp_amd, else ~/.cache/gvamp_amd (GV_TUNE_CACHE=0: neither read nor written), so that only the first
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
@@ -309,10 +309,9 @@ static std::string tune_cache_file() {
 static std::string tune_key(gv_ctx* c) {
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
-    std::string name = pr.name;
-    for (char& ch : name) if (ch == ' ' || ch == '|') ch = '_';
+    // the device is identified by ISA target and CU count (the marketing name is not stable: it reads empty under rocprofv3)
     char buf[256];
-    snprintf(buf, sizeof(buf), "v%d|%s|%s|%d|%lld|%lld|L%d|", GV_TUNE_VERSION, name.c_str(), pr.gcnArchName, pr.multiProcessorCount,
+    snprintf(buf, sizeof(buf), "v%d|%s|%d|%lld|%lld|L%d|", GV_TUNE_VERSION, pr.gcnArchName, pr.multiProcessorCount,
              (long long)c->N, (long long)c->M, c->plan.layout);
     return buf;
 }
@@ -982,8 +981,32 @@ int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 
 // Ingest: fills the resident layouts chunk by chunk (markers [m0, m0+mc), m0 % 256 == 0) so that the raw rows never
 // have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
+// nbytes of the file at `off` into the pinned staging buffer, by GV_IO_THREADS (default 4) concurrent pread streams: one
+// thread copying out of the page cache moves ~9 GB/s, a fraction of what the PCIe link takes
+static bool read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
+    int nt = 4;
+    if (const char* e = getenv("GV_IO_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 32 ? 32 : atoi(e));
+    if (nbytes < ((size_t)8 << 20)) nt = 1;
+    std::vector<char> ok(nt, 1);
+    auto work = [&](int t) {
+        const size_t lo = nbytes * (size_t)t / (size_t)nt, hi = nbytes * (size_t)(t + 1) / (size_t)nt;
+        size_t done = lo;
+        while (done < hi) {
+            const ssize_t r = pread(fd, dst + done, hi - done, (off_t)(off + (int64_t)done));
+            if (r <= 0) { ok[t] = 0; return; }
+            done += (size_t)r;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (std::thread& x : th) x.join();
+    for (char o : ok) if (!o) return false;
+    return true;
+}
+
 static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr, FILE* file = nullptr,
-                  uint32_t ld_block = 0, uint32_t ld_thr = 0) {
+                  uint32_t ld_block = 0, uint32_t ld_thr = 0, int64_t file_off = 0) {
     NEED(c, c->N > 0, "ingest: gv_set_dims must be called first");
     NEED(c, c->want_raw || c->want_stripes, "ingest: gv_set_layout disabled both layouts");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1055,7 +1078,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage[sb];
             if (file) {
                 if (chunk >= 2) e = hipEventSynchronize(stage_free[sb]);      // the copy of chunk - 2 has left this buffer
-                if (e == hipSuccess && fread(stage[sb], 1, (size_t)mc * c->mbytes, file) != (size_t)mc * c->mbytes) {
+                if (e == hipSuccess && !read_slab(fileno(file), file_off + (int64_t)m0 * c->mbytes, stage[sb], (size_t)mc * c->mbytes)) {
                     rc = fail(c, "ingest: short read on the .bed file at marker %lld", (long long)(c->S + m0));
                     break;
                 }
@@ -1117,7 +1140,7 @@ int gv_upload_bed_file(gv_ctx* c, const char* path, int64_t offset) {
         fclose(f);
         return fail(c, "gv_upload_bed_file: cannot seek to %lld in %s", (long long)offset, path);
     }
-    int rc = ingest(c, nullptr, false, 0, 0, f);
+    int rc = ingest(c, nullptr, false, 0, 0, f, 0, 0, offset);
     fclose(f);
     return rc;
 }

@@ -438,13 +438,16 @@ __device__ unsigned long long g_wgt[4 * 16384];   // development build only: per
 constexpr int GV_MAX_KS = 64;
 struct KBounds { uint32_t b[GV_MAX_KS + 1]; };
 
-template <int MODE, bool SK>
+// GO: the instantiation the device-resident CG loop launches (cg_run_device) -- it alone carries the `go` test, and it shows up
+// under its own name in kernel traces, so that the ~3 us launches of a dropped CG step do not dilute the statistics of the
+// streaming kernel proper.
+template <int MODE, bool SK, bool GO>
 __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                  const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                  int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial,
                                                  const int* __restrict__ go) {
     // device-resident CG: a step enqueued before the host knew that every system had converged is dropped here
-    if (go && __builtin_nontemporal_load(go) == 0) return;
+    if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
     constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
     __shared__ u32x4 sB[2][SS];
@@ -758,13 +761,13 @@ __device__ __forceinline__ void compute_ax_t(const ABufT& a, const u32x4* sb, in
 // DIR 0: (rg nkb + kb), DIR 1: (kb nrg + rg) -- the layout is stored marker-group-major.
 // partial layout as k_mfma_matvec: [(piece * P + plane) * rows_p + row] * 8 + digit; DIR 0: rows_p = 64 nrg, P = 2 (MODE 0)
 // or 4 (MODE 2); DIR 1: rows_p = 256 nrg, P = nv.
-template <int DIR, int MODE, bool SK>
+template <int DIR, int MODE, bool SK, bool GO>
 __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                       const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                       int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial, int nv,
                                                       const int* __restrict__ go, int64_t rstride) {
     // rstride (DIR 1): row groups per K-step in memory -- nrg, or more when this launch covers a sub-range of the row groups
-    if (go && __builtin_nontemporal_load(go) == 0) return;
+    if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (DIR == 1) ? 64 : ((MODE == 0) ? 128 : 256);   // u32x4 per K-step of one digit buffer
     constexpr int SS = (DIR == 1) ? 128 : 256;                         // u32x4 per LDS stage
     constexpr int ROWS = (DIR == 1) ? 256 : 64;                        // rows per row group
@@ -1206,12 +1209,15 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
     const int64_t rstride = pl.rstride_n > 0 ? pl.rstride_n : nrg;
-    if (d.skL > 0)
-        hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride);
-    else
-        hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride);
+#define GV_LAUNCH_T(SKV, GOV)                                                                                              \
+    hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,     \
+                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride)
+    if (MODE == 4 || !go) {
+        if (d.skL > 0) GV_LAUNCH_T(true, false); else GV_LAUNCH_T(false, false);
+    } else if constexpr (MODE != 4) {
+        if (d.skL > 0) GV_LAUNCH_T(true, true); else GV_LAUNCH_T(false, true);
+    }
+#undef GV_LAUNCH_T
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb) {
@@ -1262,12 +1268,15 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
         }
         kb.b[ks] = (uint32_t)nkb;
     }
-    if (d.skL > 0)
-        hipLaunchKernelGGL((k_mfma_matvec<MODE, true>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go);
-    else
-        hipLaunchKernelGGL((k_mfma_matvec<MODE, false>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,
-                           (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go);
+#define GV_LAUNCH_MV(SKV, GOV)                                                                                             \
+    hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,         \
+                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go)
+    if (MODE == 4 || !go) {            // (the people-statistics plane is never part of a CG step)
+        if (d.skL > 0) GV_LAUNCH_MV(true, false); else GV_LAUNCH_MV(false, false);
+    } else if constexpr (MODE != 4) {
+        if (d.skL > 0) GV_LAUNCH_MV(true, true); else GV_LAUNCH_MV(false, true);
+    }
+#undef GV_LAUNCH_MV
     if (pl.ev1) (void)hipEventRecord(pl.ev1, s);
 }
 
