@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -120,6 +120,7 @@ def load():
                                    C.POINTER(CgStats), dp, dp, vp, vp]
     L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
     L.gv_pvals_loco.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp]
+    L.gv_pvals_loco_pred.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp, dp]
     L.gv_comm_unique_id.argtypes = [C.c_void_p]
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -394,6 +395,15 @@ class Shard:
                                          aat_mu_a.h if aat_mu_a is not None else None,
                                          ata_mu_b.h if ata_mu_b is not None else None))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
+
+    def pvals_calc_loco_pred(self, z1, y, x1_hat, chrom):
+        """gv_pvals_loco_pred: (pvals[M], predictors[23, 4*mbytes])"""
+        out = np.zeros(max(self.M, 1))
+        pred = np.zeros((23, 4 * self.mbytes))
+        ch = np.ascontiguousarray(chrom, dtype=np.int32)
+        assert ch.size == self.M
+        self._ck(self.L.gv_pvals_loco_pred(self.h, z1.h, y.h, x1_hat.h, ch.ctypes.data_as(C.POINTER(C.c_int)), _dp(out), _dp(pred)))
+        return out[:self.M].copy(), pred
 
     def pvals_calc(self, z1, y, x1_hat, chrom=None):
         """data::pvals_calc (chrom None) / data::pvals_calc_LOCO on device handles; returns pvals[M]."""

@@ -1442,7 +1442,7 @@ static int marker_sums_p_p2(gv_ctx* c, const double* p, double* p2_scratch, doub
 
 // chrom == NULL: leave-one-out (the marker's own effect is added back analytically); else leave-one-chromosome-out.
 static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom,
-                      double* pvals) {
+                      double* pvals, double* chrom_pred = nullptr) {
     NEED(c, z1->space == GV_SPACE_N && y->space == GV_SPACE_N && x1_hat->space == GV_SPACE_M, "gv_pvals: bad vector spaces");
     NEED(c, c->have_stats, "gv_pvals: marker statistics must be computed first");
     if (ensure_work(c)) return 1;
@@ -1483,10 +1483,13 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
         for (int ch = 0; ch < 24; ch++) present[ch] = 0;
         for (int64_t k = 0; k < M; k++) if (chrom[k] >= 1 && chrom[k] <= 23) present[chrom[k]] += 1;
         PV_TRY(allreduce_scalars(c, present, 24));
+        if (chrom_pred) memset(chrom_pred, 0, sizeof(double) * 23 * 4 * (size_t)c->mbytes);   // chromosomes nobody holds: zeros
         for (int ch = 1; ch <= 23; ch++) {
             if (present[ch] == 0) continue;      // no rank holds a marker of this chromosome
             gvk::select_eq(c->stream, xch->d, x1_hat->d, chrom_dev, ch, M);
             PV_TRY(ax_device(c, xch->d, ych->d));                                // chromosome predictor, all ranks (:1268-1272)
+            if (chrom_pred)                                                      // the vector the reference dumps (:1276-1281)
+                PV_TRY(to_host(c, chrom_pred + (size_t)(ch - 1) * 4 * c->mbytes, ych->d, sizeof(double) * 4 * c->mbytes));
             gvk::axpby(c->stream, ych->d, 1.0, ych->d, 1.0, ymod->d, c->npad);   // + y_mod (:1284)
             PV_TRY(marker_sums_p_p2(c, ych->d, sq->d, sums_dev));
             gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, nullptr, 0.0, chrom_dev, ch, M, pv_dev);
@@ -1506,6 +1509,11 @@ int gv_pvals_loo(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_
 int gv_pvals_loco(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom, double* pvals) {
     NEED(c, chrom != nullptr, "gv_pvals_loco: chrom is NULL");
     return pvals_impl(c, z1, y, x1_hat, chrom, pvals);
+}
+int gv_pvals_loco_pred(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom, double* pvals,
+                       double* chrom_pred) {
+    NEED(c, chrom != nullptr, "gv_pvals_loco_pred: chrom is NULL");
+    return pvals_impl(c, z1, y, x1_hat, chrom, pvals, chrom_pred);
 }
 
 int gv_allreduce_host(gv_ctx* c, double* buf, int n) {

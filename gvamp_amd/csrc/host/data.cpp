@@ -240,12 +240,23 @@ std::vector<double> data::ATx(double* __restrict__ phen) {
     return out;
 }
 
-std::vector<double> data::pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco) {
+std::vector<double> data::pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco, const std::string& pred_prefix) {
     std::vector<double> pv(M > 0 ? M : 1, 0.0);
     if (loco) {
         std::vector<int> ch_info = read_chromosome_info(bimfp);
         ch_info.resize(M > 0 ? M : 1, 0);
-        ck(ctx, gv_pvals_loco(ctx, z1, y, x1_hat, ch_info.data(), pv.data()), "gv_pvals_loco");
+        if (pred_prefix.empty())
+            ck(ctx, gv_pvals_loco(ctx, z1, y, x1_hat, ch_info.data(), pv.data()), "gv_pvals_loco");
+        else {
+            // the per-chromosome predictors of data.cpp:1276-1281: <prefix>_LOCO_chr_<ch>.csv, 4*mbytes values, rank 0
+            std::vector<double> pred((size_t)23 * 4 * mbytes, 0.0);
+            ck(ctx, gv_pvals_loco_pred(ctx, z1, y, x1_hat, ch_info.data(), pv.data(), pred.data()), "gv_pvals_loco_pred");
+            for (int ch = 1; ch <= 23 && rank == 0; ch++) {
+                const std::string fp = pred_prefix + "_LOCO_chr_" + std::to_string(ch) + ".csv";
+                store_vec_to_file(fp, std::vector<double>(pred.begin() + (size_t)(ch - 1) * 4 * mbytes, pred.begin() + (size_t)ch * 4 * mbytes));
+                if (!gv_host_quiet()) std::cout << "filepath predictors = " << fp << std::endl;
+            }
+        }
     } else
         ck(ctx, gv_pvals_loo(ctx, z1, y, x1_hat, pv.data()), "gv_pvals_loo");
     pv.resize(M > 0 ? M : 0);
@@ -254,7 +265,8 @@ std::vector<double> data::pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, 
 
 static std::vector<std::vector<double>> pvals_host(data* d, gv_ctx* ctx, int M, size_t mbytes,
                                                    std::vector<std::vector<double>>& z1, std::vector<double>& y,
-                                                   std::vector<std::vector<double>>& x1_hat, bool loco) {
+                                                   std::vector<std::vector<double>>& x1_hat, bool loco,
+                                                   const std::vector<std::string>& prefixes = std::vector<std::string>()) {
     std::vector<std::vector<double>> out;
     gv_vec *dz = nullptr, *dy = nullptr, *dx = nullptr;
     ck(ctx, gv_vec_alloc(ctx, GV_SPACE_N, &dz), "gv_vec_alloc");
@@ -270,7 +282,7 @@ static std::vector<std::vector<double>> pvals_host(data* d, gv_ctx* ctx, int M, 
         std::vector<double> xp(x1_hat[ie]);
         xp.resize(M > 0 ? M : 1, 0.0);
         ck(ctx, gv_vec_upload(ctx, dx, xp.data()), "gv_vec_upload");
-        out.push_back(d->pvals_calc_dev(dz, dy, dx, loco));
+        out.push_back(d->pvals_calc_dev(dz, dy, dx, loco, (loco && ie < prefixes.size()) ? prefixes[ie] : std::string()));
     }
     gv_vec_free(ctx, dz);
     gv_vec_free(ctx, dy);
@@ -289,7 +301,7 @@ std::vector<std::vector<double>> data::pvals_calc(std::vector<std::vector<double
 std::vector<std::vector<double>> data::pvals_calc_LOCO(std::vector<std::vector<double>> z1, std::vector<double> y,
                                                        std::vector<std::vector<double>> x1_hat,
                                                        std::vector<std::string> filepath) {
-    std::vector<std::vector<double>> pv = pvals_host(this, ctx, M, mbytes, z1, y, x1_hat, true);
+    std::vector<std::vector<double>> pv = pvals_host(this, ctx, M, mbytes, z1, y, x1_hat, true, filepath);
     for (size_t ie = 0; ie < pv.size() && ie < filepath.size(); ie++)
         mpi_store_vec_to_file(filepath[ie] + "_pvals_LOCO.bin", pv[ie], S, M);          // data.cpp:1347-1350
     return pv;

@@ -81,5 +81,6 @@ public:
                                                      std::vector<std::vector<double>> x1_hat,
                                                      std::vector<std::string> filepath);
     // the same on device handles (what vamp::infere_linear calls): z1, y N-space; x1_hat M-space
-    std::vector<double> pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco);
+    // pred_prefix (LOCO only, may be empty): also dump the per-chromosome predictors <prefix>_LOCO_chr_<ch>.csv (data.cpp:1276-1281)
+    std::vector<double> pvals_calc_dev(gv_vec* z1, gv_vec* y, gv_vec* x1_hat, bool loco, const std::string& pred_prefix = std::string());
 };

@@ -589,7 +589,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         mpi_store_vec_to_file(pre + "_pvals.bin", pv, S, M);
         if (verbose && rank == 0) std::cout << "filepath_out_pvals = " << pre + "_pvals.bin" << std::endl;
         if (dataset->get_bimfp() != "") {
-            std::vector<double> pl = dataset->pvals_calc_dev(z1, y, x1_hat, true);
+            std::vector<double> pl = dataset->pvals_calc_dev(z1, y, x1_hat, true, pre);   // + <pre>_LOCO_chr_<ch>.csv (data.cpp:1276-1281)
             mpi_store_vec_to_file(pre + "_pvals_LOCO.bin", pl, S, M);
             if (verbose && rank == 0) std::cout << "filepath_out_pvals_LOCO = " << pre << std::endl;
         }

@@ -201,6 +201,11 @@ int gv_pvals_loo(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x
  * chromosome one Ax (with its cross-rank all-reduce) + one marker pass.  Markers of other chromosomes get 0. */
 int gv_pvals_loco(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom,
                   double* pvals);
+/* The same, also returning the per-chromosome genetic predictors the reference dumps as <file>_LOCO_chr_<ch>.csv
+ * (data.cpp:1276-1281): chrom_pred[(ch-1) * 4*mbytes + n] = (A x1_hat restricted to chromosome ch)[n], summed over ranks,
+ * ch = 1..23 (zeros for a chromosome no rank holds).  chrom_pred: 23 * 4*mbytes host doubles, or NULL. */
+int gv_pvals_loco_pred(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, const int* chrom,
+                       double* pvals, double* chrom_pred);
 
 /* SUM all-reduce of n host doubles over the attached communicator (identity when none): MPI_Allreduce of
  * scalars in vamp.cpp:313,990,1012-1013 */

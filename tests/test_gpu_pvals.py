@@ -72,3 +72,10 @@ def test_gvamp_sim_store_pvals_files(tmp_path, oracle):
     ypad[:N] = y_full
     assert np.allclose(np.fromfile(out + "s_pvals.bin"), oracle.pvals(bed, N, M, z1, ypad, x1), rtol=1e-7)
     assert np.allclose(np.fromfile(out + "s_pvals_LOCO.bin"), oracle.pvals(bed, N, M, z1, ypad, x1, chrom=chrom), rtol=1e-7)
+    # the per-chromosome predictors the reference dumps next to them (data.cpp:1276-1281): A x1_hat restricted to a
+    # chromosome, 4*mbytes values with the default 6 significant digits; zeros for chromosomes without markers
+    for ch in (1, 7, 23, 15):
+        pred = np.loadtxt(out + "s_LOCO_chr_%d.csv" % ch)
+        want = oracle.ax(bed, N, M, mave, msig, np.where(chrom == ch, x1, 0.0))
+        assert pred.shape == want.shape and np.allclose(pred, want, rtol=2e-5, atol=1e-9), ch
+    assert np.all(np.loadtxt(out + "s_LOCO_chr_15.csv") == 0)
