@@ -17,7 +17,7 @@ SPACE_M, SPACE_N = 0, 1
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_synth_bed_ld", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
-    "gv_ax", "gv_atx", "gv_set_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
+    "gv_ax", "gv_atx", "gv_set_layout", "gv_get_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
@@ -84,6 +84,7 @@ def load():
     L.gv_atx.argtypes = [vp, dp, dp]
     L.gv_set_kernel_mode.argtypes = [vp, C.c_int]
     L.gv_set_layout.argtypes = [vp, C.c_int, C.c_int]
+    L.gv_get_layout.argtypes = [vp]
     L.gv_get_kernel_mode.argtypes = [vp]
     L.gv_vec_alloc.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.gv_vec_free.argtypes = [vp, vp]
@@ -251,6 +252,9 @@ class Shard:
 
     def set_layout(self, raw_rows=True, stripes=True):
         self._ck(self.L.gv_set_layout(self.h, int(raw_rows), int(stripes)))
+
+    def get_layout(self):
+        return self.L.gv_get_layout(self.h)
 
     def set_kernel_mode(self, mode):
         self._ck(self.L.gv_set_kernel_mode(self.h, mode))

@@ -1016,6 +1016,15 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     if (c->want_raw && !c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(M > 0 ? M : 1) * P));
     if (!c->want_raw && c->bed) { (void)hipFree(c->bed); c->bed = nullptr; }
     const auto t_in0 = std::chrono::steady_clock::now();
+    if (c->want_auto && c->want_stripes && !(pl.tiles || pl.stripes_m)) {
+        // gv_set_layout(.., 3): two stripe sets (the faster ATx, by 2-5 %) when they fit the free HBM with room for the
+        // vectors and scratch, else the one tile layout (half the bytes)
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        const double one = (double)((M + 63) / 64) * (double)((c->N + 255) / 256) * 4096.0;
+        const double other = (c->want_raw ? (double)M * (double)P : 32768.0 * (double)P) + 64.0 * (double)(M + c->npad) + 2.0e9;
+        c->want_tile = 2.0 * one + other > 0.92 * (double)free_b;
+    }
     const int want_layout = c->want_tile ? 1 : 0;
     if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
         // (re)build the geometry and the buffers of the MFMA family for the layout asked for
@@ -1119,10 +1128,11 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
 
 int gv_set_layout(gv_ctx* c, int raw_rows, int stripes) {
     NEED(c, raw_rows || stripes, "gv_set_layout: at least one layout is required");
-    NEED(c, stripes >= 0 && stripes <= 2, "gv_set_layout: stripes is 0 (none), 1 (two stripe sets) or 2 (one tile layout)");
+    NEED(c, stripes >= 0 && stripes <= 3, "gv_set_layout: stripes is 0 (none), 1 (two stripe sets), 2 (one tile layout) or 3 (auto)");
     c->want_raw = raw_rows != 0;
     c->want_stripes = stripes != 0;
     c->want_tile = stripes == 2;
+    c->want_auto = stripes == 3;
     return 0;
 }
 
@@ -1629,6 +1639,7 @@ int gv_reset_counters(gv_ctx* c) {
     c->cnt = gv_counters{};
     return 0;
 }
+int gv_get_layout(const gv_ctx* c) { return c->have_stripes ? (c->plan.layout == 1 ? 2 : 1) : 0; }
 int gv_ingest_info(gv_ctx* c, double* alloc_seconds, double* fill_seconds) {
     if (alloc_seconds) *alloc_seconds = c->ingest_alloc_s;
     if (fill_seconds) *fill_seconds = c->ingest_fill_s;

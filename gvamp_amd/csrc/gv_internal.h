@@ -41,6 +41,7 @@ struct gv_ctx {
     bool have_stats = false;
     int kernel_mode = 0;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
     bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
+    bool want_auto = false;                      // gv_set_layout(.., 3): want_tile is decided at ingest from the free HBM
     bool want_tile = false;                      // the MFMA family's layout: false = two stripe sets, true = one tile layout
     bool have_raw = false, have_stripes = false;
     gvm::Plan plan;

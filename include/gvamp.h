@@ -72,10 +72,12 @@ int gv_atx(gv_ctx* ctx, const double* p, double* out);
 /* Resident HBM layouts built at the next gv_upload_bed / gv_synth_bed: raw_rows = the PLINK rows (pitch-padded;
  * needed by kernel mode 0 and gv_download_bed); stripes selects the re-encoded 2-bit layout of kernel mode 1:
  *   0 none, 1 two stripe sets (marker-major for ATx, individual-major for Ax: 2 x M*N/4 bytes resident),
- *   2 ONE tile layout that serves both products (M*N/4 bytes resident; bit-identical results).
+ *   2 ONE tile layout that serves both products (M*N/4 bytes resident; bit-identical results),
+ *   3 auto: two stripe sets when they fit the free HBM at ingest (their ATx is 2-5 % faster), else the tile layout.
  * Default: raw rows + two stripe sets.  With raw_rows = 0 the rows stream through a chunk buffer and only the re-encoded
  * layout stays resident. */
 int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
+int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0 none, 1 two stripe sets, 2 tile layout */
 /* kernel family for Ax/ATx: 0 = fp64 VALU kernels (parity anchor), 1 = i8 MFMA fixed-point kernels. */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);
 int gv_get_kernel_mode(const gv_ctx* ctx);

@@ -212,3 +212,43 @@ def test_config5_xxt_run_properties():
         assert (a["cg_iters"], a["onsager_iters"]) == (b["cg_iters"], b["onsager_iters"])
         assert a["n_ax_pass"] + a["n_atx_pass"] < 0.7 * (b["n_ax_pass"] + b["n_atx_pass"])
     assert rel(x2.x_est, std.x_est) < 2e-2
+
+
+def test_tile_layout_holds_twice_the_shard(oracle):
+    """N=400k x M=2M = 200 GB of 2-bit genotypes on ONE GPU: two stripe sets would need 400 GB of the 288; gv_set_layout(.., 3)
+    (auto) falls back to the one tile layout.  Sampled columns vs the oracle, the adjoint identity over all 200 GB (Ax and
+    ATx read the same bytes through different lane patterns), linearity, reproducibility, two-vector = one-vector."""
+    N, Mt, seed, miss = 400000, 2000000, 777, 5000
+    rng = np.random.default_rng(9)
+    sample = np.array([0, 63, 64, 4095, 65536, 999999, 1000000, 1048576, 1999935, 1999999])
+    mini = np.concatenate([synth.synth_bed(N, 1, seed=seed, miss_ppm=miss, S=int(j)) for j in sample])
+    o_mave, o_msig = oracle.marker_stats(mini, N, len(sample))
+    with capi.Shard(N, Mt) as sh:
+        sh.set_layout(False, 3)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(seed, miss)
+        assert sh.get_layout() == 2                       # the two stripe sets did not fit
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        assert np.allclose(mave[sample], o_mave, rtol=1e-13, atol=1e-15) and np.allclose(msig[sample], o_msig, rtol=1e-10)
+        p = rng.standard_normal(N)
+        w = sh.ATx(p)
+        assert rel(w[sample], oracle.atx(mini, N, len(sample), o_mave, o_msig, p)) < 1e-10
+        xs = rng.standard_normal(len(sample))
+        x = np.zeros(Mt)
+        x[sample] = xs
+        assert rel(sh.Ax(x), oracle.ax(mini, N, len(sample), o_mave, o_msig, xs)) < 1e-10
+        x1, x2 = rng.standard_normal(Mt), rng.standard_normal(Mt)
+        z1, z2 = sh.Ax(x1), sh.Ax(x2)
+        lhs, rhs = float(z1 @ p), float(x1 @ w)
+        assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs))
+        assert rel(sh.Ax(2.5 * x1 - 0.75 * x2), 2.5 * z1 - 0.75 * z2) < 1e-12
+        assert np.array_equal(sh.Ax(x1), z1) and np.array_equal(sh.ATx(p), w)
+        va, vb, oa, ob = sh.vecM(x1), sh.vecM(x2), sh.vecN(), sh.vecN()
+        sh.ax2_dev(va, vb, oa, ob)
+        assert np.array_equal(oa.download()[:N], z1[:N]) and np.array_equal(ob.download()[:N], z2[:N])
+    with capi.Shard(20000, 30000) as sh:                  # a small shard: auto keeps the two stripe sets
+        sh.set_layout(False, 3)
+        sh.set_kernel_mode(1)
+        sh.synth_bed(1, 5000)
+        assert sh.get_layout() == 1

@@ -167,4 +167,4 @@ def test_tile_layout_halves_the_resident_bytes_and_mode0_still_needs_raw_rows():
         with pytest.raises(capi.GvError, match="raw row layout"):
             sh.Ax(np.ones(M))
         with pytest.raises(capi.GvError):
-            sh.set_layout(False, 3)
+            sh.set_layout(False, 4)
