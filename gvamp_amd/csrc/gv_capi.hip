@@ -27,8 +27,12 @@ int fail(gv_ctx* c, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
-    else g_create_err = buf;
+    if (c) {
+        c->err = buf;
+        c->pub_armed = false;          // an armed read-back whose reduction never ran must not leave read_scalars spinning
+        gvk::disarm_publish();
+    } else
+        g_create_err = buf;
     return 1;
 }
 

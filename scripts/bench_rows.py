@@ -23,7 +23,7 @@ def shard_bytes(N, M):
 def vamp_row(name, N, M, iterations, **kw):
     raw = kw.pop("raw_rows", False)
     with capi.Shard(N, M) as sh:
-        sh.set_layout(raw, True)
+        sh.set_layout(raw, int(os.environ.get("GV_LAYOUT", "1")))
         sh.set_kernel_mode(1)
         t = time.perf_counter()
         sh.synth_bed(4242, 5000)
@@ -48,7 +48,7 @@ def vamp_row(name, N, M, iterations, **kw):
 def pvals_row(N, M):
     rng = np.random.default_rng(0)
     with capi.Shard(N, M) as sh:
-        sh.set_layout(False, True)
+        sh.set_layout(False, int(os.environ.get("GV_LAYOUT", "1")))
         sh.set_kernel_mode(1)
         sh.synth_bed(4242, 5000)
         sh.compute_markers_statistics()

@@ -13,7 +13,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 fuse = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 xxt = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 with capi.Shard(N, M) as sh:
-    sh.set_layout(False, True)
+    sh.set_layout(False, int(os.environ.get("GV_LAYOUT", "1")))
     sh.set_kernel_mode(1)
     sh.synth_bed(4242, 5000)
     sh.compute_markers_statistics()
