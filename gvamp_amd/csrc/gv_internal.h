@@ -71,11 +71,10 @@ struct gv_ctx {
     bool pub_armed = false;
     unsigned long long pub_seq = 0;
     void* xfer_pin = nullptr;      // 4 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
-    // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` flag, 4 ticket counters,
-    // residual traces (2 x cgx_relcap doubles), a pinned staging block for the initial states
+    // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` / rider flags, residual traces
+    // (2 x cgx_relcap doubles), a pinned staging block for the initial states
     double* cgx_state = nullptr;
     int* cgx_go = nullptr;
-    unsigned int* cgx_counters = nullptr;
     double* cgx_rel = nullptr;
     int cgx_relcap = 0;
     double* cgx_pin = nullptr;

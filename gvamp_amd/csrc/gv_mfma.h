@@ -25,7 +25,7 @@ struct CgHook {
     // Ax side (k_prep_ax): the search direction is advanced on the way in, p <- z + beta p, when the system stepped
     double* p[2] = {nullptr, nullptr};
     const double* z[2] = {nullptr, nullptr};
-    // ATx side (k_fin_atx_dot): <out, addx> = <Q p, p>, block partials + ordered finish by the last block -> dot_out[v][0]
+    // ATx side (k_fin_atx_dot): <out, addx> = <Q p, p>, block partials, then gvk::finalize -> dot_out[v][0]
     // Rider (gv_cg_extras.ride_x): while *ride == 1 and exactly one of the two systems has finished, the finished system's
     // slot of a two-vector Ax pass carries alt_x instead (decided on the device: the host learns of a finished system one
     // step late); the product lands in that slot's output, k_ride_copy moves it out and k_cgx_decide sets *ride = 2.
@@ -33,7 +33,6 @@ struct CgHook {
     const double* alt_x = nullptr;
     double* dot_part[2] = {nullptr, nullptr};
     double* dot_out[2] = {nullptr, nullptr};
-    unsigned int* dot_counters = nullptr;    // 2 ticket counters, zero between launches
 };
 
 struct Plan {

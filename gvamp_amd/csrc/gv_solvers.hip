@@ -179,11 +179,12 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
 
 // ---- the steady state of cg_run with every scalar on the device (kernel mode 1) ------------------------------------------
 // A CG step of the host-driven loop above costs three scalar round trips (alpha, the Onsager rule, beta / the residual
-// rule): the host waits for a reduction, computes one division and launches the next small kernel, ~20 launches and ~60 us
-// of idle GPU per step -- 3 % of a step at N=400k x M=1M, 10-17 % on a 2.5-12.5 GB shard (profiles/r2_*_gaps.txt).  Here the
+// rule): the host waits for a reduction, computes one division and launches the next small kernel -- ~15 us of idle GPU each
+// through the mailbox on one GPU (1-2 % of a step at 12.5-100 GB shards: DESIGN.md section 5 has the A/B, which is a tie
+// there), plus a small-message all-reduce latency each on a sharded job, which is what this loop is for.  Here the
 // state of each system (gvm::ST_*) lives in HBM; the step is
 //   Ax pass   [k_prep_ax: p <- z + beta p on the way in | k_quant | stream | k_fin_ax | all-reduce]
-//   ATx pass  [k_prep_atx | k_quant | stream | k_fin_atx_dot: d = tau A^T A p + gam2 p and <d,p>, finished by the last block]
+//   ATx pass  [k_prep_atx | k_quant | stream | k_fin_atx_dot: d = tau A^T A p + gam2 p and the partials of <d,p> | k_finalize]
 //   k_cgx_ab  [alpha = <r,z>/<d,p>; mu += alpha p; r -= alpha d; z = r/diag; <v,mu>, <r,z>, <r,r>]
 //   k_cgx_decide [Onsager rule, beta, residual rule, trace; go flag; status -> host mailbox]
 // and the host only ENQUEUES: it reads the status of step s - 1 after it has enqueued step s, so the device always has
@@ -197,8 +198,6 @@ static int cgx_alloc(gv_ctx* c, int max_iter) {
     if (!c->cgx_state) {
         HIPCHK(c, hipMalloc(&c->cgx_state, sizeof(double) * 2 * gvm::ST_SIZE));
         HIPCHK(c, hipMalloc(&c->cgx_go, sizeof(int) * 4));
-        HIPCHK(c, hipMalloc(&c->cgx_counters, sizeof(unsigned int) * 4));
-        HIPCHK(c, hipMemsetAsync(c->cgx_counters, 0, sizeof(unsigned int) * 4, c->stream));
         HIPCHK(c, hipHostMalloc(&c->cgx_pin, sizeof(double) * (2 * gvm::ST_SIZE + 2)));
     }
     if (max_iter > c->cgx_relcap) {
@@ -295,7 +294,6 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         const int ns = two ? 2 : 1;
         gvm::CgHook hk;
         hk.go = c->cgx_go;
-        hk.dot_counters = c->cgx_counters;
         if (ride_pending) { hk.ride = d_ride; hk.alt_x = ride_x; }
         for (int j = 0; j < ns; j++) {
             CgSys& s = sys[act[j]];
