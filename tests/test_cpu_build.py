@@ -134,3 +134,19 @@ def test_run_sharded_launcher_sets_the_rank_environment(tmp_path):
     bad = subprocess.run([sys.executable, launcher, "-n", "2", "--", sys.executable, "-c",
                           "import os,sys,time; sys.exit(7) if os.environ['RANK']=='1' else time.sleep(30)"], timeout=60)
     assert bad.returncode == 7
+
+
+def test_bench_never_downgrades_the_gpu_count():
+    """`bench.py --gpus N` must not print a line for another world size (runs without a GPU: both refusals happen before
+    anything touches one).  Under a launcher with WORLD_SIZE != --gpus: exit 2.  Started bare on a box with fewer GPUs: exit 3."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+    import torch
+    if torch.cuda.device_count() < 8:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode == 3 and "GPU" in r.stderr and not r.stdout.strip()
