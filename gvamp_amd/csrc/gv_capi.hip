@@ -557,14 +557,14 @@ bool use_overlap(const gv_ctx* c) {   // nothing rank-local in here: every rank 
 }
 
 // data::Ax on device pointers.  x: M doubles, out: npad doubles.
-int ax_device(gv_ctx* c, const double* x, double* out) {
+int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg) {
     NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
     const double scale = 1.0 / sqrt((double)c->N);
     const bool multi = is_multi(c);
     if (c->kernel_mode == 1 && use_overlap(c)) {
         if (c->M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
         c->plan.ev0 = c->plan.ev1 = nullptr;
-        if (ax_overlapped(c, 1, x, nullptr, out, nullptr, nullptr)) return 1;
+        if (ax_overlapped(c, 1, x, nullptr, out, nullptr, cg)) return 1;
         c->cnt.n_ax++;
         c->cnt.n_ax_pass++;
         return 0;
@@ -578,7 +578,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
         gv_ctx::EvRec* er = ev_next(c, 0);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out);
+        gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out, cg);
         KCHK(c);
         t.stop();
     } else {
@@ -610,7 +610,7 @@ int ax_device(gv_ctx* c, const double* x, double* out) {
 }
 
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
-int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, double tau, double gam2) {
+int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, double tau, double gam2, const gvm::CgHook* cg) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     if (c->M == 0) {   // empty shard
         c->cnt.n_atx++;
@@ -624,7 +624,7 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
         gv_ctx::EvRec* er = ev_next(c, 1);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2);
+        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2, cg);
     } else {
         NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
         gv_ctx::EvRec* er = ev_next(c, 1);
@@ -641,7 +641,7 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
 }
 
 // two-vector forms: ONE pass over the shard in kernel mode 1, two single passes otherwise
-int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb) {
+int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb, const gvm::CgHook* cg) {
     // The collective sequence below must not depend on rank-local state (an empty shard, M == 0, enters the same calls
     // with zeros): it is chosen by the kernel mode -- the same on every rank of a job -- and the output pointers only.
     if (c->kernel_mode != 1) {
@@ -654,7 +654,7 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     if (use_overlap(c)) {
         if (c->M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
         c->plan.ev0 = c->plan.ev1 = nullptr;
-        if (ax_overlapped(c, 2, xa, xb, outa, outb, nullptr)) return 1;
+        if (ax_overlapped(c, 2, xa, xb, outa, outb, cg)) return 1;
         c->cnt.n_ax += 2;
         c->cnt.n_ax_pass += 1;
         return 0;
@@ -669,7 +669,7 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
         gv_ctx::EvRec* er = ev_next(c, 0);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::ax2(c->stream, c->plan, xa, xb, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, outa, outb);
+        gvm::ax2(c->stream, c->plan, xa, xb, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, outa, outb, cg);
         KCHK(c);
         t.stop();
     }
@@ -696,7 +696,7 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     return 0;
 }
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
-                const double* addxb, double tau, double gam2) {
+                const double* addxb, double tau, double gam2, const gvm::CgHook* cg) {
     if (c->M == 0) {   // empty shard: no local markers, no collective in ATx
         c->cnt.n_atx += 2;
         c->cnt.n_atx_pass += 1;
@@ -713,7 +713,7 @@ int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, dou
     c->plan.ev0 = er ? er->a : nullptr;
     c->plan.ev1 = er ? er->b : nullptr;
     gvm::atx2(c->stream, c->plan, pa, pb, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, outa, outb, addxa,
-              addxb, tau, gam2);
+              addxb, tau, gam2, cg);
     KCHK(c);
     t.stop();
     c->cnt.n_atx += 2;

@@ -161,6 +161,9 @@ void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
                 int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride);
+void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
+              double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
+              unsigned long long* flag, unsigned long long seq);
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,
@@ -196,11 +199,13 @@ int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream);
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes);
 int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes);
 // data::Ax / data::ATx (and their two-vector forms) on device pointers, in the kernel family of the context
-int ax_device(gv_ctx* c, const double* x, double* out);
-int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0);
-int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb);
+// (cg: the slots of the pass that belong to a CG system with device-resident scalars -- gvm::CgHook)
+int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg = nullptr);
+int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0,
+               const gvm::CgHook* cg = nullptr);
+int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb, const gvm::CgHook* cg = nullptr);
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
-                const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0);
+                const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0, const gvm::CgHook* cg = nullptr);
 int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out);
 bool use_overlap(const gv_ctx* c);    // data::Ax cut into chunks whose exchange runs on the side stream (GV_OVERLAP)
 int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double* outa, double* outb, const gvm::CgHook* cg);

@@ -594,6 +594,86 @@ __global__ void k_axpy_st(double* __restrict__ y, const double* __restrict__ x, 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += alpha * x[i];
 }
+// ---- vamp::CG_solverAAT (denoiserXXT.cpp:52-130), the N-space CG of --use-XXT-denoiser 1, with its scalars on the device ----
+// d = tau d + gam2 p (the rest of lmmse_multAAT, denoiserXXT.cpp:30-33) and the block partials of <d, p> (:88)
+__global__ __launch_bounds__(256) void k_aat_dq(double* __restrict__ d, const double* __restrict__ p, double tau, double gam2,
+                                                int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double pi = p[i];
+        const double di = fma(tau, d[i], gam2 * pi);
+        d[i] = di;
+        s = fma(di, pi, s);
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// alpha = <r,z> / <d,p> (:88); mu += alpha p (:90-93); r -= alpha d; z = r / diag[n] (:95-105); partials of <r,z>, <r,r>
+__global__ __launch_bounds__(256) void k_aat_ab(double* __restrict__ st, double* __restrict__ mu, const double* __restrict__ p,
+                                                double* __restrict__ r, const double* __restrict__ d, double* __restrict__ z,
+                                                const double* __restrict__ diag, const double* __restrict__ dp, int64_t n,
+                                                double* __restrict__ partial) {
+    __shared__ double sh[4];
+    if (st[gvm::ST_ACTIVE] == 0.0) return;
+    const double alpha = st[gvm::ST_RZ] / dp[0];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double s0 = 0, s1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        mu[i] = fma(alpha, p[i], mu[i]);
+        const double ri = fma(-d[i], alpha, r[i]);
+        const double zi = ri / diag[i];
+        r[i] = ri;
+        z[i] = zi;
+        s0 = fma(ri, zi, s0);
+        s1 = fma(ri, ri, s1);
+    }
+    s0 = block_sum_256(s0, sh);
+    s1 = block_sum_256(s1, sh);
+    if (threadIdx.x == 0) {
+        partial[(int64_t)blockIdx.x * 2] = s0;
+        partial[(int64_t)blockIdx.x * 2 + 1] = s1;
+        if (blockIdx.x == 0) st[gvm::ST_ALPHA] = alpha;
+    }
+}
+// beta, <r,z>, ||r|| / ||v|| and its trace, the 1e-4 stopping rule (:98-120); status -> host mailbox (slot seq & 1, system 0).
+// ST_NORMV holds ||v||^2 for this solver (the reference takes the square root of the ratio, :113-114).
+__global__ void k_aat_decide(double* __restrict__ st, const double* __restrict__ red, double* __restrict__ relres, int max_iter,
+                             double* mailbox, unsigned long long* flag, unsigned long long seq) {
+    if (threadIdx.x == 0) {
+        if (st[gvm::ST_ACTIVE] != 0.0) {
+            const int iters = (int)st[gvm::ST_ITERS] + 1;
+            st[gvm::ST_ITERS] = (double)iters;
+            st[gvm::ST_BETA] = red[0] / st[gvm::ST_RZ];
+            st[gvm::ST_RZ] = red[0];
+            const double rel = sqrt(red[1] / st[gvm::ST_NORMV]);
+            st[gvm::ST_RELERR] = rel;
+            if (relres) relres[iters - 1] = rel;
+            st[gvm::ST_NRELRES] = (double)iters;
+            st[gvm::ST_STEPPED] = 1.0;
+            if (rel < 1e-4) {
+                st[gvm::ST_CONV] = 1.0;
+                st[gvm::ST_ACTIVE] = 0.0;
+            } else if (iters >= max_iter)
+                st[gvm::ST_ACTIVE] = 0.0;
+        } else
+            st[gvm::ST_STEPPED] = 0.0;
+        double* mb = mailbox + (seq & 1ull) * (2 * 8);
+        mb[0] = st[gvm::ST_ACTIVE]; mb[1] = st[gvm::ST_ITERS]; mb[2] = st[gvm::ST_CONV]; mb[3] = st[gvm::ST_RELERR];
+        mb[4] = 0.0; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED]; mb[7] = 0.0;
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// p = z + beta p (:109-110) while the system is running, beta from its state block
+__global__ void k_p_update_st(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ st, int64_t n) {
+    if (st[gvm::ST_ACTIVE] == 0.0 || st[gvm::ST_STEPPED] == 0.0) return;
+    const double beta = st[gvm::ST_BETA];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = fma(beta, p[i], z[i]);
+}
+
 // the rider's product (see gvm::CgHook::ride) out of the slot that carried it
 __global__ void k_ride_copy(double* __restrict__ out, const double* __restrict__ w0, const double* __restrict__ w1,
                             const double* __restrict__ st0, const double* __restrict__ st1, const int* __restrict__ ride,
@@ -1025,6 +1105,18 @@ void finalize(hipStream_t s, const double* partial, int nb, int K, double* out) 
 }
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n) {
     hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
+}
+// one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
+void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
+              double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
+              unsigned long long* flag, unsigned long long seq) {
+    const int nb = red_blocks(n, 256);
+    hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, red);
+    hipLaunchKernelGGL(k_aat_ab, dim3(nb), dim3(256), 0, s, st, mu, p, r, d, z, diag, red, n, partial);
+    hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, red + 2);
+    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq);
+    hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);
 }
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n) {

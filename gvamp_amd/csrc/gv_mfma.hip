@@ -1150,16 +1150,19 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
         const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
         const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
         const double r = msig[m] * fma(-mave[m], P - sm, sa) * inv_sqrt_n;
-        const double pm = addx[m];
-        const double d = fma(tau, r, gam2 * pm);
-        out[m] = d;
-        s = fma(d, pm, s);
+        if (addx) {                                  // a CG slot: d = tau r + gam2 p and <d, p>
+            const double pm = addx[m];
+            const double d = fma(tau, r, gam2 * pm);
+            out[m] = d;
+            s = fma(d, pm, s);
+        } else
+            out[m] = r;                              // a plain product sharing the pass (gv_cg_solve_aat2: A^T p of the N-space system)
     }
     s = wave_sum_d(s);   // the butterfly of gvk::dots (bit-identical sums)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0 && a.part[v]) a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
     // (the block partials are added up by gvk::finalize, launched behind this kernel: a last-block ticket would serialise
     // ~1000 atomics on one address, 50 ns each -- measured 74 us for this kernel at M = 500k against 16 us without)
 }
@@ -1338,7 +1341,8 @@ static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, c
     const int nb = dot_blocks(pl.M);
     hipLaunchKernelGGL(k_fin_atx_dot, dim3(nb, nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL);
-    for (int v = 0; v < nv; v++) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
+    for (int v = 0; v < nv; v++)
+        if (cg.dot_out[v]) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
 }
 
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,

@@ -406,6 +406,59 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     return 0;
 }
 
+// ---- device-resident scalars, one read-back per operator application: the solvers of --use-XXT-denoiser 1 -----------------
+// (gv_cg_solve_aat, gv_cg_solve_aat2).  Their passes alternate between two systems half an application out of phase, so the
+// host keeps scheduling pass by pass; but a CG step no longer costs two or three scalar round trips and a dozen
+// host-paced launches: the step's kernels (alpha, updates, beta, stopping rule) run back to back on the device and the host
+// reads ONE status word set per completed application.
+static bool cgx_usable(const gv_ctx* c) {
+    const char* cgdev = getenv("GV_CG_DEVICE");
+    return c->kernel_mode == 1 && c->have_stripes && c->M > 0 && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
+}
+// initial state of one system -> device block blk (0 / 1); normv: ||v|| (M-space systems) or ||v||^2 (CG_solverAAT)
+static int cgx_upload_state(gv_ctx* c, int blk, double rz, double normv, int denoiser, bool active) {
+    double* q = c->cgx_pin + blk * gvm::ST_SIZE;
+    for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+    q[gvm::ST_RZ] = rz; q[gvm::ST_NORMV] = normv; q[gvm::ST_ACTIVE] = active ? 1.0 : 0.0; q[gvm::ST_DENOISER] = denoiser;
+    HIPCHK(c, hipMemcpyAsync(c->cgx_state + blk * gvm::ST_SIZE, q, sizeof(double) * gvm::ST_SIZE, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the pinned block may be rewritten for the other system right away
+    return 0;
+}
+// one CG_solverAAT step (state block 0) after d = A (A^T p) has arrived
+static int aat_step_device(gv_ctx* c, double* mu, double* p, double* r, double* d, double* z, const double* DG, double tau,
+                           double gam2, int max_iter, bool want_rel, CgxStatus* out) {
+    const unsigned long long seq = ++c->mbox_seq;
+    gvk::aat_step(c->stream, c->cgx_state, mu, p, r, d, z, DG, tau, gam2, c->npad, c->red_partial, c->red_out + 16,
+                  want_rel ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq);
+    KCHK(c);
+    CgxStatus s2[2];
+    if (cgx_wait(c, seq, s2)) return 1;
+    *out = s2[0];
+    return 0;
+}
+// one precondCG_solver step of the M-space system in state block 1 after d = Q p has arrived through an ATx pass whose
+// epilogue (CgHook: dot_part / dot_out = red_partial / red_out) left <d,p>
+static int mspace_step_device(gv_ctx* c, CgSys& sb, double gam2, double diag, int max_iter, bool multi, CgxStatus* out) {
+    double* dst1 = c->cgx_state + gvm::ST_SIZE;
+    if (multi && comm_allreduce(c, c->red_out, 8)) return 1;
+    double *a_st[1] = {dst1}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z}, *a_part[1] = {c->red_partial},
+           *a_red[1] = {c->red_out};
+    const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out};
+    gvk::cgx_ab(c->stream, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, c->M);
+    KCHK(c);
+    if (multi && comm_allreduce(c, c->red_out, 8)) return 1;
+    const double* c_red[1] = {c->red_out};
+    double* c_rel[1] = {sb.relres ? c->cgx_rel + c->cgx_relcap : nullptr};
+    const unsigned long long seq = ++c->mbox_seq;
+    gvk::cgx_decide(c->stream, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
+                    reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq, nullptr);
+    KCHK(c);
+    CgxStatus s2[2];
+    if (cgx_wait(c, seq, s2)) return 1;
+    *out = s2[0];
+    return 0;
+}
+
 // ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
 // one system is still active (a two-vector pass costs what a one-vector pass costs), else by a pass of its own.
 static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x = nullptr,
@@ -597,6 +650,23 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
         double vn2;
         AAT_TRY(read_scalars(c, 1, &vn2));
         AAT_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (cgx_usable(c) && max_iter > 0) {      // scalars on the device, one read-back per step
+            AAT_TRY(cgx_alloc(c, max_iter));
+            AAT_TRY(cgx_upload_state(c, 0, rz, vn2, 1, true));
+            for (int i = 0; i < max_iter; i++) {
+                AAT_TRY(atx_device(c, p, tmpM));                                   // A^T p, then A (A^T p) (:22-23)
+                AAT_TRY(ax_device(c, tmpM, d));
+                CgxStatus stt;
+                AAT_TRY(aat_step_device(c, mu, p, r, d, z, DG->d, tau, gam2, max_iter, relres != nullptr, &stt));
+                iters = (int)stt.iters;
+                rel_err = stt.rel;
+                n_relres = (int)stt.nrel;
+                if (stt.active == 0.0) { converged = (int)stt.conv; break; }
+            }
+            if (relres && n_relres > 0) AAT_TRY(to_host(c, relres, c->cgx_rel, sizeof(double) * (size_t)n_relres));
+            AAT_HIP(hipGetLastError());
+            goto done;
+        }
         for (int i = 0; i < max_iter; i++) {
             iters = i + 1;
             AAT_TRY(lmmse_aat_device(c, p, tau, gam2, tmpM, d));              // d = Q p (:86)
@@ -681,6 +751,8 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
     hipStream_t s = c->stream;
     const int64_t n = c->npad, M = c->M;
     const bool multi = is_multi(c);
+    const bool dev = cgx_usable(c) && max_iter > 0;      // scalars of both systems on the device (state blocks 0 = a, 1 = b)
+    if (dev && cgx_alloc(c, max_iter)) return 1;
     gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr, *MA = nullptr;
     auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) vec_del(c, x); };
     for (gv_vec** x : {&R, &Z, &P, &D, &DG})
@@ -709,6 +781,7 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
         MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
         MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
         if (max_iter <= 0) sb.active = false;
+        if (dev) MIX_TRY(cgx_upload_state(c, 1, sb.rz, sb.norm_v, 0, sb.active));
     }
     {
         auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
@@ -740,6 +813,7 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
             gvk::fill(s, mu, n, 0.0);
             MIX_HIP(hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
             MIX_TRY(a_init_scalars());
+            if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
             a_phase = 1;
             if (max_iter > 0) a_post(p, d); else a_finish();
         }
@@ -760,13 +834,24 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
             else break;
             // system b's second half is the ATx of lmmse_mult: its tau * . + gam2 * req epilogue is fused as in gv_cg_solve
             auto addx = [&](const HalfOp* h) -> const double* { return (h == &hb && h->stage == 1) ? sb.req : nullptr; };
+            // device scalars: system b's slot of the pass advances its search direction on the way in (Ax half) and leaves
+            // d = Q_B p and <d,p> on the way out (ATx half)
+            gvm::CgHook hk;
+            const gvm::CgHook* hkp = nullptr;
+            for (int k = 0; k < nt && dev; k++)
+                if (todo[k] == &hb) {
+                    hk.state[k] = c->cgx_state + gvm::ST_SIZE;
+                    if (hb.stage == 0) { hk.p[k] = sb.p; hk.z[k] = sb.z; }
+                    else { hk.dot_part[k] = c->red_partial; hk.dot_out[k] = c->red_out; }
+                    hkp = &hk;
+                }
             if (nt == 2) {
-                if (todo[0]->kind() == 0) MIX_TRY(ax2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out()));
+                if (todo[0]->kind() == 0) MIX_TRY(ax2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out(), hkp));
                 else MIX_TRY(atx2_device(c, todo[0]->in(), todo[1]->in(), todo[0]->out(), todo[1]->out(), addx(todo[0]),
-                                         addx(todo[1]), tau, gam2));
+                                         addx(todo[1]), tau, gam2, hkp));
             } else {
-                if (todo[0]->kind() == 0) MIX_TRY(ax_device(c, todo[0]->in(), todo[0]->out()));
-                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out(), addx(todo[0]), tau, gam2));
+                if (todo[0]->kind() == 0) MIX_TRY(ax_device(c, todo[0]->in(), todo[0]->out(), hkp));
+                else MIX_TRY(atx_device(c, todo[0]->in(), todo[0]->out(), addx(todo[0]), tau, gam2, hkp));
             }
             for (int k = 0; k < nt; k++) {
                 HalfOp* h = todo[k];
@@ -774,18 +859,34 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
                 h->pending = false;
                 if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
                     sb.wslot = c->w_n->d;
-                    CgSys* one[1] = {&sb};
-                    MIX_TRY(cg_consume_all(c, one, 1, gam2, diag_b, max_iter, multi));
+                    if (dev) {
+                        CgxStatus stt;
+                        MIX_TRY(mspace_step_device(c, sb, gam2, diag_b, max_iter, multi, &stt));
+                        sb.iters = (int)stt.iters; sb.converged = (int)stt.conv; sb.onsager = stt.ons;
+                        sb.n_relres = (int)stt.nrel; sb.rel_err = stt.rel; sb.active = stt.active != 0.0;
+                    } else {
+                        CgSys* one[1] = {&sb};
+                        MIX_TRY(cg_consume_all(c, one, 1, gam2, diag_b, max_iter, multi));
+                    }
                     b_post();
                     continue;
                 }
                 if (a_phase == 2) { a_phase = 3; continue; }                        // A^T mu_a done
-                gvk::axpby(s, ha.dst, tau, ha.dst, gam2, ha.src, n);                // Q_A src complete
+                if (a_phase == 0 || !dev) gvk::axpby(s, ha.dst, tau, ha.dst, gam2, ha.src, n);   // Q_A src complete
                 if (a_phase == 0) {                                                // r = v - Q mu0 (:71-73)
                     gvk::axpby(s, r, 1.0, v_a->d, -1.0, r, n);
                     MIX_TRY(a_init_scalars());
+                    if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
                     a_phase = 1;
                     if (max_iter > 0) a_post(p, d); else a_finish();
+                    continue;
+                }
+                if (dev) {                                                         // one CG step (:86-120), scalars on the device
+                    CgxStatus stt;
+                    MIX_TRY(aat_step_device(c, mu, p, r, d, z, DG->d, tau, gam2, max_iter, relres_a != nullptr, &stt));
+                    a_iters = (int)stt.iters; a_rel = stt.rel; a_nrel = (int)stt.nrel;
+                    if (stt.active == 0.0) { a_conv = (int)stt.conv; a_finish(); }
+                    else a_post(p, d);
                     continue;
                 }
                 const int i = a_iters++;                                           // one CG step (:86-120)
@@ -810,6 +911,11 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
                 else if (a_iters >= max_iter) a_finish();
                 else a_post(p, d);
             }
+        }
+        if (dev) {        // residual traces were written on the device
+            if (relres_a && a_nrel > 0) MIX_TRY(to_host(c, relres_a, c->cgx_rel, sizeof(double) * (size_t)a_nrel));
+            if (relres_b && sb.n_relres > 0)
+                MIX_TRY(to_host(c, relres_b, c->cgx_rel + c->cgx_relcap, sizeof(double) * (size_t)sb.n_relres));
         }
         if (aat_mu_a) {   // Q_A mu_a = v_a - r  =>  A A^T mu_a = (v_a - r - gam2 mu_a) / tau
             gvk::axpby(s, aat_mu_a->d, 1.0 / tau, v_a->d, -1.0 / tau, r, n);
