@@ -42,6 +42,10 @@ def vamp_row(name, N, M, iterations, **kw):
             "seconds_per_iter": [round(t["seconds"], 4) for t in its], "cg_iters": [t["cg_iters"] for t in its],
             "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
             "pass_GBps": round(sum(t["n_ax_pass"] + t["n_atx_pass"] for t in tail) * shard_bytes(N, M) / secs / 1e9, 1),
+            # the same time priced per vector PRODUCT (what a one-product-per-pass engine would have had to stream): not a
+            # bandwidth -- a two-vector pass reads the shard once for two products
+            "n_ax": [t["n_ax"] for t in its], "n_atx": [t["n_atx"] for t in its],
+            "product_equiv_GBps": round(sum(t["n_ax"] + t["n_atx"] for t in tail) * shard_bytes(N, M) / secs / 1e9, 1),
             "corr_with_truth": round(float(np.corrcoef(r.x_est, beta)[0, 1]), 4), "ingest_s": round(ingest, 2)}
 
 
