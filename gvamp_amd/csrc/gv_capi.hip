@@ -612,7 +612,8 @@ int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg) {
 // data::ATx on device pointers.  p: npad doubles (zero at NA / pad slots), out: M doubles.
 int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, double tau, double gam2, const gvm::CgHook* cg) {
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
-    if (c->M == 0) {   // empty shard
+    if (c->M == 0) {   // empty shard: no markers; the <d,p> a CG hook asks for is 0 from this rank (it is all-reduced next)
+        if (cg && cg->dot_out[0]) { gvk::fill(c->stream, cg->dot_out[0], 8, 0.0); KCHK(c); }
         c->cnt.n_atx++;
         c->cnt.n_atx_pass++;
         return 0;
@@ -698,6 +699,9 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
                 const double* addxb, double tau, double gam2, const gvm::CgHook* cg) {
     if (c->M == 0) {   // empty shard: no local markers, no collective in ATx
+        for (int k = 0; k < 2 && cg; k++)
+            if (cg->dot_out[k]) gvk::fill(c->stream, cg->dot_out[k], 8, 0.0);
+        KCHK(c);
         c->cnt.n_atx += 2;
         c->cnt.n_atx_pass += 1;
         return 0;
@@ -1410,13 +1414,17 @@ int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double*
         // two halves of the sum of squares have their own operand tables (k_prep_people); the quadratic half reads the
         // a^2 plane of the codes (MODE 4 of the streaming kernel)
         hipStream_t s = c->stream;
-        double* ones = c->cg_d->d;
-        gvk::fill(s, ones, c->M, 1.0);
-        gvm::ax(s, c->plan, ones, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, c->mave_p->d);
-        gvm::ax_people(s, c->plan, 0, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->numb_p->d);
-        gvm::ax_people(s, c->plan, 1, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->msig_p->d);
-        gvm::ax_people(s, c->plan, 2, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->w_n->d);
-        gvk::axpby(s, c->msig_p->d, 1.0, c->msig_p->d, 1.0, c->w_n->d, c->npad);
+        if (c->M == 0) {      // an empty shard adds zeros to the three sums, through the same collectives as its peers
+            for (int kind = 0; kind < 3; kind++) gvk::fill(s, dst[kind]->d, c->npad, 0.0);
+        } else {
+            double* ones = c->cg_d->d;
+            gvk::fill(s, ones, c->M, 1.0);
+            gvm::ax(s, c->plan, ones, c->mave, c->msig, c->mask2, c->npad, 1.0, c->red_partial, c->mave_p->d);
+            gvm::ax_people(s, c->plan, 0, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->numb_p->d);
+            gvm::ax_people(s, c->plan, 1, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->msig_p->d);
+            gvm::ax_people(s, c->plan, 2, c->mave, c->msig, c->mask2, c->npad, c->red_partial, c->w_n->d);
+            gvk::axpby(s, c->msig_p->d, 1.0, c->msig_p->d, 1.0, c->w_n->d, c->npad);
+        }
         KCHK(c);
         for (int kind = 0; kind < 3; kind++)
             if (comm_allreduce(c, dst[kind]->d, c->npad)) return 1;     // data.cpp:604-606

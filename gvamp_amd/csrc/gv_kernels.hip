@@ -1069,9 +1069,11 @@ void axpby(hipStream_t s, double* out, double a, const double* x, double b, cons
 }
 
 void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n) {
+    if (n <= 0) return;            // an empty shard (M == 0) steps through the solver with empty vectors
     hipLaunchKernelGGL(k_p_update, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, beta, n);
 }
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad) {
+    if (npad <= 0) return;
     hipLaunchKernelGGL(k_mask_copy, dim3(nblk(npad, 256)), dim3(256), 0, s, out, in, mask2, npad);
 }
 
@@ -1104,6 +1106,7 @@ void finalize(hipStream_t s, const double* partial, int nb, int K, double* out) 
     hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
 }
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n) {
+    if (n <= 0) return;
     hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
 }
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
@@ -1120,6 +1123,7 @@ void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, doubl
 }
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n) {
+    if (n <= 0) return;
     hipLaunchKernelGGL(k_ride_copy, dim3(nblk(n, 256)), dim3(256), 0, s, out, w0, w1, st0, st1, ride, n);
 }
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,

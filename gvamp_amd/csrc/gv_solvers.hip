@@ -413,7 +413,8 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
 // reads ONE status word set per completed application.
 static bool cgx_usable(const gv_ctx* c) {
     const char* cgdev = getenv("GV_CG_DEVICE");
-    return c->kernel_mode == 1 && c->have_stripes && c->M > 0 && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
+    // (nothing rank-local in here: an empty shard, M == 0, must take the same sequence of collectives as its peers)
+    return c->kernel_mode == 1 && c->have_stripes && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
 }
 // initial state of one system -> device block blk (0 / 1); normv: ||v|| (M-space systems) or ||v||^2 (CG_solverAAT)
 static int cgx_upload_state(gv_ctx* c, int blk, double rz, double normv, int denoiser, bool active) {

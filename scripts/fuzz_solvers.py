@@ -1,0 +1,238 @@
+"""Randomised solver runs (development; run on a GPU box):   python scripts/fuzz_solvers.py [cases] [seed]
+Per case a random shard (N, M around the tile / block boundaries, missing genotypes, NA phenotypes, either resident layout),
+random tau / gam2 / iteration cap / warm start / rider, and
+  A. gv_cg_solve and gv_cg_solve2x with the device-resident loop against the host-driven loop (GV_CG_DEVICE=0): same
+     iteration counts, product counts and traces, iterates to 1e-12, the rider's product bit for bit;
+  B. the same solves on 2-4 in-process marker shards (random cut points, empty shards allowed, exchange overlapped or not)
+     against the single shard: same iteration counts, iterates to 1e-9 (the sharded sums add in another order), and the
+     overlapped exchange bit-identical to the one-message form."""
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gvamp_amd import capi, synth
+
+EDGE_N = [4, 5, 63, 64, 65, 255, 256, 257, 511, 513, 1023, 1024, 1025, 4097]
+EDGE_M = [1, 2, 3, 5, 63, 64, 65, 127, 129, 255, 256, 257, 1023, 1025, 2049]
+_group = [int(time.time()) % 100000 * 10]
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+def close(a, b, tol):
+    """rel. l2 distance below tol; where the reference side is not finite (a degenerate case: one marker gives every
+    individual a 0/0 variance in compute_people_statistics, as in the reference) the two sides must be non-finite alike"""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if a.shape != b.shape:
+        return False
+    if not np.all(np.isfinite(b)):
+        return bool(np.array_equal(np.isfinite(a), np.isfinite(b)))
+    return bool(rel(a, b) < tol)
+
+
+def trace_close(a, b, rtol):
+    """residual traces of two runs that round differently: the first steps agree to rounding; later ones only while CG has
+    not lost its orthogonality (a non-converging run on a tiny ill-conditioned system is chaotic in its late steps)"""
+    n = min(len(a), len(b), 5)
+    return bool(np.allclose(a[:n], b[:n], rtol=rtol, atol=1e-9, equal_nan=True))
+
+
+def pick(rng, edges, hi):
+    return int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(2, hi))
+
+
+class host_loop:
+    def __enter__(self):
+        os.environ["GV_CG_DEVICE"] = "0"
+
+    def __exit__(self, *a):
+        os.environ.pop("GV_CG_DEVICE", None)
+
+
+def solves(sh, M, S, P):
+    """the two solver entry points on one shard (or one rank of a group); returns everything comparable"""
+    va, vb = sh.vecM(P["va"][S:S + M]), sh.vecM(P["vb"][S:S + M])
+    mu0 = sh.vecM(P["mu0"][S:S + M]) if P["warm"] else None
+    rx = sh.vecM(P["rx"][S:S + M]) if P["ride"] else None
+    mu = sh.vecM()
+    sh.counters(reset=True)
+    st, rr = sh.cg_solve(va, mu0, P["tau"], P["gam2"], P["denoiser"], P["max_iter"], mu)
+    c1 = sh.counters(reset=True)
+    mu_a, mu_b, ro, amu, ata = sh.vecM(), sh.vecM(), sh.vecN(), sh.vecN(), sh.vecM()
+    (sa, ra), (sb, rb) = sh.cg_solve2x(va, mu0, vb, P["tau"], P["gam2"], P["max_iter"], mu_a, mu_b, ride_x=rx,
+                                       ride_out=ro if P["ride"] else None, a_mu_a=amu, ata_mu_b=ata)
+    c2 = sh.counters(reset=True)
+    keys = ("n_ax", "n_atx", "n_ax_pass", "n_atx_pass")
+    x = {}
+    if P["xxt"]:       # the N-space solver of --use-XXT-denoiser 1, alone and sharing its passes with the Onsager solve
+        sh.compute_people_statistics()
+        vn = sh.vecN(P["vn"])
+        mn0 = sh.vecN(P["mn0"]) if P["warm"] else None
+        mn, mn2, atm, mb2, aat, ata2 = sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecM()
+        s1, r1 = sh.cg_solve_aat(vn, mn0, P["tau"], P["gam2"], P["max_iter"], mn)
+        (s2, r2), (s3, r3) = sh.cg_solve_aat2(vn, mn0, vb, P["tau"], P["gam2"], P["max_iter"], mn2, atm, mb2, aat_mu_a=aat,
+                                              ata_mu_b=ata2)
+        x = dict(xit=(s1.iters, s1.converged, s2.iters, s2.converged, s3.iters, s3.converged), xr1=r1, xr2=r2, xr3=r3,
+                 mn=mn.download(), mn2=mn2.download(), atm=atm.download(), mb2=mb2.download(), aat=aat.download(),
+                 ata2=ata2.download())
+    return dict(**x, it=(st.iters, st.converged, st.n_relres, sa.iters, sa.converged, sa.n_relres, sb.iters, sb.converged, sb.n_relres),
+                cnt=tuple(c1[k] for k in keys) + tuple(c2[k] for k in keys), rr=rr, ra=ra, rb=rb, ons=sb.onsager,
+                mu=mu.download(), mu_a=mu_a.download(), mu_b=mu_b.download(), ro=ro.download(), amu=amu.download(),
+                ata=ata.download())
+
+
+def make_shard(N, M, Mt, S, bed_rows, layout, m4, nonas):
+    sh = capi.Shard(N, M, Mt=Mt, S=S)
+    sh.set_layout(False, layout)
+    sh.set_kernel_mode(1)
+    sh.upload_bed(bed_rows)
+    if m4 is not None:
+        sh.set_mask(m4, nonas)
+    return sh
+
+
+def run_group(N, Mt, bed, cuts, layout, m4, nonas, P, overlap):
+    nr = len(cuts) - 1
+    out, errors = [None] * nr, []
+    _group[0] += 1
+    group = _group[0]
+    mb = (N + 3) // 4
+
+    def work(rank):
+        try:
+            S, M = cuts[rank], cuts[rank + 1] - cuts[rank]
+            with make_shard(N, M, Mt, S, bed[S * mb:(S + M) * mb], layout, m4, nonas) as sh:
+                sh.comm_init_local(group, nr, rank)
+                sh.set_overlap(overlap)
+                sh.compute_markers_statistics()
+                out[rank] = solves(sh, M, S, P)
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nr)]
+    for t in th:
+        t.start()
+    t_end = time.time() + 40
+    for t in th:
+        t.join(timeout=max(0.1, t_end - time.time()))
+    assert not errors, ("rank failed", errors)
+    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
+    return out
+
+
+def run_case(seed0, k):
+    rng = np.random.default_rng(seed0 * 100003 + k)
+    N, M = pick(rng, EDGE_N, 3000), pick(rng, EDGE_M, 4000)
+    miss = int(rng.choice([0, 2000, 50000]))
+    fna = float(rng.choice([0.0, 0.0, 0.02]))
+    layout = int(rng.integers(1, 3))
+    bed = synth.synth_bed(N, M, seed=int(rng.integers(1 << 30)), miss_ppm=miss)
+    present = rng.random(N) >= fna
+    m4, nonas = None, N
+    if fna > 0 or N % 4:
+        m4 = np.zeros((N + 3) // 4, dtype=np.uint8)
+        for n in np.nonzero(present)[0]:
+            m4[n >> 2] |= 1 << (n & 3)
+        nonas = int(present.sum())
+    P = dict(tau=float(10.0 ** rng.uniform(-2, 2)), gam2=float(10.0 ** rng.uniform(-3, 2)), denoiser=int(rng.integers(2)),
+             max_iter=int(rng.choice([0, 1, 2, 5, 40])), warm=bool(rng.integers(2)), ride=bool(rng.integers(2)),
+             va=rng.standard_normal(M), vb=np.sign(rng.standard_normal(M)) / np.sqrt(M), mu0=rng.standard_normal(M) * 0.1,
+             rx=rng.standard_normal(M), xxt=bool(rng.random() < 0.4))
+    n4 = 4 * ((N + 3) // 4)
+    P["vn"], P["mn0"] = np.zeros(n4), np.zeros(n4)
+    P["vn"][:N] = rng.standard_normal(N) * present
+    P["mn0"][:N] = rng.standard_normal(N) * present * 0.1
+    info = dict(N=N, M=M, miss=miss, fna=fna, layout=layout, **{q: P[q] for q in ("tau", "gam2", "denoiser", "max_iter", "warm", "ride", "xxt")})
+    # ---- A: device-resident loop against the host-driven loop
+    with make_shard(N, M, M, 0, bed, layout, m4, nonas) as sh:
+        sh.compute_markers_statistics()
+        d = solves(sh, M, 0, P)
+        with host_loop():
+            h = solves(sh, M, 0, P)
+    assert d["it"] == h["it"], ("iteration counts", info, d["it"], h["it"])
+    assert d["cnt"] == h["cnt"], ("product counts", info, d["cnt"], h["cnt"])
+    for key in ("rr", "ra", "rb"):
+        assert len(d[key]) == len(h[key]) and np.allclose(d[key], h[key], rtol=1e-9, atol=1e-13), (key, info)
+    for key in ("mu", "mu_a", "mu_b", "amu", "ata"):
+        assert rel(d[key], h[key]) < 1e-12, (key, info, rel(d[key], h[key]))
+    if P["ride"]:
+        assert np.array_equal(d["ro"], h["ro"]), ("rider", info)
+    # rounding differences between two correct CG runs grow with the conditioning of tau A A^T + gam2 I (largest eigenvalue of
+    # A A^T ~ (1 + sqrt(M/N))^2) and, once a run fails to converge within its cap, without bound: iterates are compared when the
+    # solve converged or was capped within 5 steps, traces over their first 5 steps
+    kappa = 1.0 + P["tau"] / P["gam2"] * (1.0 + np.sqrt(M / N)) ** 2
+    short = P["max_iter"] <= 5
+    # (40 steps on a system of fewer unknowns than that: CG has long lost orthogonality, two roundings drift apart further)
+    loose = 1e3 if (not short and min(N, M) <= 130) else 1.0
+    if P["xxt"]:
+        # (the N-space solver's device scalars use fused multiply-adds the host-driven form does not: equal to rounding)
+        for key in ("xr1", "xr2", "xr3"):
+            assert trace_close(d[key], h[key], 1e-13 * kappa ** 2 + 1e-9), (key, info, d[key][:5], h[key][:5])
+        okx = (short or (d["xit"][1] and h["xit"][1]), short or (d["xit"][3] and h["xit"][3] and d["xit"][5] and h["xit"][5]))
+        for key, ok in (("mn", okx[0]), ("mn2", okx[1]), ("atm", okx[1]), ("mb2", okx[1]), ("aat", okx[1]), ("ata2", okx[1])):
+            if ok:
+                assert close(d[key], h[key], loose * (1e-13 * kappa ** 2 + 1e-9)), (key, info, rel(d[key], h[key]), kappa)
+    # ---- B: marker shards in one process
+    nr = int(rng.integers(2, 5))
+    cuts = sorted(int(c) for c in rng.integers(0, M + 1, size=nr - 1))
+    cuts = [0] + cuts + [M]
+    info["cuts"] = cuts
+    plain = run_group(N, M, bed, cuts, layout, m4, nonas, P, 0)
+    ovl = run_group(N, M, bed, cuts, layout, m4, nonas, P, int(rng.integers(2, 6)))
+    for r in range(nr):
+        for key in plain[r]:
+            a, b = plain[r][key], ovl[r][key]
+            assert (a == b) if isinstance(a, tuple) else np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), ("overlap", key, info)
+        assert plain[r]["it"] == plain[0]["it"], ("ranks disagree on iteration counts", info, plain[r]["it"], plain[0]["it"])
+    if short:
+        assert plain[0]["it"] == d["it"], ("sharded iteration counts", info, plain[0]["it"], d["it"])
+    cat = lambda key: np.concatenate([plain[r][key] for r in range(nr)])
+    # a sharded run adds the same terms in another order: compare at the conditioning of the solve, not bit for bit
+    tol_sh = loose * (1e-13 * kappa ** 2 + 1e-9)
+    conv = lambda it, i: short or bool(it[i])
+    if conv(d["it"], 1):
+        assert rel(cat("mu"), d["mu"]) < tol_sh, ("sharded mu", info, rel(cat("mu"), d["mu"]), kappa)
+    if conv(d["it"], 4) and conv(d["it"], 7):
+        for key in ("mu_a", "mu_b", "ata"):
+            assert rel(cat(key), d[key]) < tol_sh, ("sharded " + key, info, rel(cat(key), d[key]), kappa)
+        assert rel(plain[0]["amu"], d["amu"]) < tol_sh, ("sharded amu", info, rel(plain[0]["amu"], d["amu"]), kappa)
+    for key in ("rr", "ra", "rb"):
+        assert trace_close(plain[0][key], d[key], tol_sh), ("sharded " + key, info, plain[0][key][:5], d[key][:5])
+    if P["ride"]:
+        assert rel(plain[0]["ro"], d["ro"]) < 1e-12, ("sharded rider", info)
+    if P["xxt"]:
+        for key in ("xr1", "xr2", "xr3"):
+            assert trace_close(plain[0][key], d[key], tol_sh), ("sharded " + key, info, plain[0][key][:5], d[key][:5])
+        if short or all(d["xit"][1::2]):
+            for key in ("atm", "mb2", "ata2"):
+                assert close(cat(key), d[key], tol_sh), ("sharded " + key, info, rel(cat(key), d[key]), kappa)
+            for key in ("mn", "mn2", "aat"):
+                assert close(plain[0][key], d[key], tol_sh), ("sharded " + key, info, rel(plain[0][key], d[key]), kappa)
+    return info
+
+
+def main(ncases, seed):
+    t0 = time.time()
+    bad = []
+    for k in range(ncases):
+        try:
+            info = run_case(seed, k)
+        except AssertionError as e:
+            bad.append((k, str(e)))
+            print("CASE %d FAILED: %s" % (k, e), flush=True)
+            continue
+        if k % 10 == 0:
+            print("case %d ok %s  (%.0f s)" % (k, info, time.time() - t0), flush=True)
+    os.environ.pop("GV_CG_DEVICE", None)
+    print("%d cases, %d failed, %.0f s" % (ncases, len(bad), time.time() - t0))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)

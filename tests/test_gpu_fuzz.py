@@ -16,3 +16,14 @@ def test_random_shapes_both_layouts_bit_identical_and_vs_oracle(oracle):
     spec.loader.exec_module(fz)
     bad = fz.main(120, 20261003)
     assert not bad, bad
+
+
+def test_random_solver_runs_device_loop_host_loop_and_marker_shards():
+    """scripts/fuzz_solvers.py: gv_cg_solve / gv_cg_solve2x / the XXT solvers on random shards -- device-resident loop against
+    the host-driven one, and 2-4 in-process marker shards (empty ones included, exchange overlapped or not) against one shard"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_solvers.py")
+    spec = importlib.util.spec_from_file_location("fuzz_solvers", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = fz.main(100, 3)
+    assert not bad, bad
