@@ -27,3 +27,14 @@ def test_random_solver_runs_device_loop_host_loop_and_marker_shards():
     spec.loader.exec_module(fz)
     bad = fz.main(100, 3)
     assert not bad, bad
+
+
+def test_random_full_vamp_runs_vs_oracle(oracle):
+    """scripts/fuzz_vamp.py: random shapes / priors / models (linear, XXT denoiser, probit) / kernel families / layouts /
+    fuse levels / divide_work marker shards against the oracle's run of the same configuration"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_vamp.py")
+    spec = importlib.util.spec_from_file_location("fuzz_vamp", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = fz.main(40, 5)
+    assert not bad, bad
