@@ -38,3 +38,13 @@ def test_random_full_vamp_runs_vs_oracle(oracle):
     spec.loader.exec_module(fz)
     bad = fz.main(40, 5)
     assert not bad, bad
+
+
+def test_random_pvalue_runs_vs_oracle(oracle):
+    """scripts/fuzz_pvals.py: LOO / LOCO p-values on random shards, both kernel families, both resident layouts"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_pvals.py")
+    spec = importlib.util.spec_from_file_location("fuzz_pvals", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = fz.main(80, 9)
+    assert not bad, bad
