@@ -16,6 +16,8 @@ from oracle import gvoracle as oracle
 
 oracle.lib()
 seed0 = 1
+BIG = False
+NT = min(32, os.cpu_count() or 1)     # oracle threads
 EDGE_N = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097]
 EDGE_M = [1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2049]
 ENVK = ("GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_TAPER", "GV_PRIO", "GV_TUNE_CACHE")
@@ -37,12 +39,24 @@ def pick(rng, edges, hi):
 
 def run_case(k):
     rng = np.random.default_rng(seed0 * 100003 + k)
-    N, M = pick(rng, EDGE_N, 3000), pick(rng, EDGE_M, 3000)
-    if N * M > 30_000_000:
-        M = max(1, 30_000_000 // N)
+    if BIG:     # mid-size shards: several quads of row groups, hundreds of K-blocks, the tuner's own picks among the random ones
+        N, M = int(rng.integers(3000, 90000)), int(rng.integers(3000, 90000))
+        if N * M > 1_200_000_000:
+            M = max(1, 1_200_000_000 // N)
+    else:
+        N, M = pick(rng, EDGE_N, 3000), pick(rng, EDGE_M, 3000)
+        if N * M > 30_000_000:
+            M = max(1, 30_000_000 // N)
     miss = int(rng.choice([0, 0, 2000, 50000, 300000]))
     fna = float(rng.choice([0.0, 0.0, 0.01, 0.3]))
-    bed = synth.synth_bed(N, M, seed=int(rng.integers(1 << 30)), miss_ppm=miss).copy()
+    bseed = int(rng.integers(1 << 30))
+    if BIG:     # generated on the device (the numpy twin of the recipe takes minutes at this size), fetched for the oracle
+        with capi.Shard(N, M) as g:
+            g.set_layout(True, False)
+            g.synth_bed(bseed, miss)
+            bed = g.download_bed().copy()
+    else:
+        bed = synth.synth_bed(N, M, seed=bseed, miss_ppm=miss).copy()
     mb = (N + 3) // 4
     b2 = bed.reshape(M, mb)
     if M >= 3 and rng.random() < 0.5:               # a monomorphic marker (all genotype 2 -> code 00) and an all-missing one
@@ -106,14 +120,14 @@ def run_case(k):
         assert np.array_equal(a[key], b[key], equal_nan=True), ("layouts differ", key)
     assert np.array_equal(a["z"], a["za"]) and np.array_equal(a["z2"], a["zb"]), "two-vector Ax != one-vector Ax"
     assert np.array_equal(a["w"], a["wa"]) and np.array_equal(a["w2"], a["wb"]), "two-vector ATx != one-vector ATx"
-    o_mave, o_msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas)
+    o_mave, o_msig = oracle.marker_stats(bed, N, M, mask4=m4, nonas=nonas, nthreads=NT)
     ok = np.isfinite(o_msig)
     assert np.allclose(a["mave"], o_mave, rtol=1e-13, atol=1e-15, equal_nan=True), "mave"
     assert np.array_equal(np.isfinite(a["msig"]), ok), "msig finiteness"
     assert np.allclose(a["msig"][ok], o_msig[ok], rtol=1e-12), "msig"
     info = (N, M, miss, fna, env)
     if ok.all() and np.isfinite(o_mave).all() and nonas >= 2:
-        oz, ow = oracle.ax(bed, N, M, o_mave, o_msig, x, mask4=m4), oracle.atx(bed, N, M, o_mave, o_msig, p)
+        oz, ow = oracle.ax(bed, N, M, o_mave, o_msig, x, mask4=m4, nthreads=NT), oracle.atx(bed, N, M, o_mave, o_msig, p, nthreads=NT)
         # the yardstick of a sum is the size of its terms, not of what is left after they cancel (a marker column is centred:
         # with M = 1..3 markers the entries of Ax are differences of nearly equal numbers in fp64 and in fixed point alike)
         sz = max(np.linalg.norm(oz), np.abs(o_msig * x).max() * np.sqrt(M) * 3.0 / np.sqrt(N) * np.sqrt(N))
@@ -125,9 +139,9 @@ def run_case(k):
     return info
 
 
-def main(ncases, seed):
-    global seed0
-    seed0 = seed
+def main(ncases, seed, big=False):
+    global seed0, BIG
+    seed0, BIG = seed, big
     saved = {k: os.environ.get(k) for k in ENVK}
     t0 = time.time()
     bad = []
@@ -139,7 +153,7 @@ def main(ncases, seed):
                 bad.append((k, str(e)))
                 print("CASE %d FAILED: %s" % (k, e), flush=True)
                 continue
-            if k % 10 == 0:
+            if k % 10 == 0 or BIG:
                 print("case %d ok %s  (%.0f s)" % (k, info, time.time() - t0), flush=True)
     finally:
         for k, v in saved.items():
@@ -152,4 +166,5 @@ def main(ncases, seed):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                       len(sys.argv) > 3 and sys.argv[3] == "big") else 0)
