@@ -877,9 +877,15 @@ extern "C" {
 
 int gv_abi_version(void) { return GV_ABI_VERSION; }
 
+// Contexts of one process (the in-process rank groups of the tests: one thread per rank) are created and torn down under one
+// lock: stream / event creation and destruction racing across threads is where a runtime is least exercised, and neither
+// call is on any hot path.
+static std::mutex g_lifecycle_mu;
+
 int gv_create(int device, gv_ctx** out) {
     if (!out) return fail(nullptr, "gv_create: out is NULL");
     *out = nullptr;
+    std::lock_guard<std::mutex> life(g_lifecycle_mu);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -930,6 +936,8 @@ void gv_destroy(gv_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    std::lock_guard<std::mutex> life(g_lifecycle_mu);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     free_dataset(c);
     while (!c->live_vecs.empty()) vec_del(c, *c->live_vecs.begin());   // vectors the caller never gave back

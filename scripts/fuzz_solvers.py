@@ -121,8 +121,9 @@ def run_group(N, Mt, bed, cuts, layout, m4, nonas, P, overlap):
     t_end = time.time() + 40
     for t in th:
         t.join(timeout=max(0.1, t_end - time.time()))
+    if any(t.is_alive() for t in th):     # its peers left the sequence of collectives: nothing after this is trustworthy
+        raise RuntimeError("a rank is stuck in a collective; errors so far: %r" % (errors,))
     assert not errors, ("rank failed", errors)
-    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
     return out
 
 

@@ -233,3 +233,43 @@ print(json.dumps(out))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert json.loads(r.stdout.strip().splitlines()[-1])["1"]["src"] == "measured"
     assert len(open(tmp_path / "cache" / "decomp.txt").read().splitlines()) == 2
+
+
+@pytest.mark.parametrize("stripes", [1, 2])
+def test_bed_file_slab_equals_upload_from_memory_and_a_short_file_fails_loudly(tmp_path, stripes):
+    """read_genotype_data (data.cpp:201-234): a rank's slab at byte offset 3 + S*mbytes of the .bed, streamed through the
+    double-buffered pinned staging (several chunks, several reader threads) -- the same resident bytes as an upload from
+    memory; a file that ends inside the slab, or does not exist, is an error, never zero-filled genotypes."""
+    N, Mt = 4101, 20000                       # mbytes = 1026: 3 staging chunks of 8192 markers = 8.4 MB each, 4 reader threads
+    S, M = 700, 19000
+    bed = synth.synth_bed(N, Mt, seed=5, miss_ppm=7000)
+    mb = (N + 3) // 4
+    path = str(tmp_path / "f.bed")
+    synth.write_bed(path, bed)
+    x = np.random.default_rng(0).standard_normal(M)
+    res = []
+    for from_file in (False, True):
+        with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+            sh.set_layout(stripes == 1, stripes)
+            sh.set_kernel_mode(1)
+            if from_file:
+                sh.upload_bed_file(path)                      # default offset: 3 + S * mbytes
+            else:
+                sh.upload_bed(bed[S * mb:(S + M) * mb])
+            sh.compute_markers_statistics()
+            res.append((sh.marker_stats(), sh.Ax(x), sh.download_bed() if stripes == 1 else None))
+    assert np.array_equal(res[0][0][0], res[1][0][0]) and np.array_equal(res[0][0][1], res[1][0][1])
+    assert np.array_equal(res[0][1], res[1][1])
+    if stripes == 1:
+        assert np.array_equal(res[1][2], bed[S * mb:(S + M) * mb])
+    short = str(tmp_path / "short.bed")
+    with open(short, "wb") as f:
+        f.write(open(path, "rb").read()[:3 + (S + M) * mb - 1000])
+    with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+        sh.set_layout(False, stripes)
+        with pytest.raises(capi.GvError, match="short read"):
+            sh.upload_bed_file(short)
+        with pytest.raises(capi.GvError, match="could not open"):
+            sh.upload_bed_file(str(tmp_path / "nope.bed"))
+        with pytest.raises(capi.GvError):                     # nothing usable is resident after the failed ingest
+            sh.compute_markers_statistics()
