@@ -166,6 +166,71 @@ def test_empty_shard_rank_enters_the_same_collectives(tmp_path):
     assert np.allclose(out[0][1], -2.0 * out[0][0], rtol=1e-12, atol=1e-15) and np.array_equal(out[0][0], out[0][2])
 
 
+def test_empty_shard_rank_in_the_xxt_solvers_and_a_warm_started_dual_solve():
+    """Round-2 regressions found by scripts/fuzz_solvers.py: (1) a warm-started gv_cg_solve2x takes one host-driven CG step for
+    the cold system before the device loop starts -- on an empty shard its p-update was a zero-size launch; (2) the solvers of
+    --use-XXT-denoiser 1 chose device or host scalars by M > 0, i.e. an empty rank issued other collectives than its peers."""
+    import threading
+    from gvamp_amd import capi, synth
+    N, Mt = 600, 3
+    bed = synth.synth_bed(N, Mt, seed=8)
+    mb = (N + 3) // 4
+    rng = np.random.default_rng(1)
+    va, vb, mu0 = rng.standard_normal(Mt), np.sign(rng.standard_normal(Mt)) / np.sqrt(Mt), rng.standard_normal(Mt) * 0.1
+    vn = np.zeros(4 * mb)
+    vn[:N] = rng.standard_normal(N)
+    cuts = [0, 2, 2, 3]                      # rank 1 is empty
+    out, errors = [None] * 3, []
+
+    def work(rank):
+        try:
+            S, M = cuts[rank], cuts[rank + 1] - cuts[rank]
+            with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+                sh.set_layout(False, True)
+                sh.set_kernel_mode(1)
+                sh.upload_bed(bed[S * mb:(S + M) * mb])
+                sh.comm_init_local(4343, 3, rank)
+                sh.compute_markers_statistics()
+                a, b, m0 = sh.vecM(va[S:S + M]), sh.vecM(vb[S:S + M]), sh.vecM(mu0[S:S + M])
+                mu_a, mu_b = sh.vecM(), sh.vecM()
+                (sa, _), (sb, _) = sh.cg_solve2x(a, m0, b, 2.0, 0.5, 10, mu_a, mu_b)       # (1)
+                sh.compute_people_statistics()
+                dn, mn, atm, mb2 = sh.vecN(vn), sh.vecN(), sh.vecM(), sh.vecM()
+                (s2, _), (s3, _) = sh.cg_solve_aat2(dn, None, b, 2.0, 0.5, 10, mn, atm, mb2)   # (2)
+                out[rank] = (sa.iters, sb.iters, s2.iters, s3.iters, mu_a.download(), mn.download(), mb2.download())
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(3)]
+    for t in th:
+        t.start()
+    import time
+    t_end = time.time() + 90
+    for t in th:
+        t.join(timeout=max(0.1, t_end - time.time()))
+    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
+    assert not errors, errors
+    assert out[0][:4] == out[1][:4] == out[2][:4]                       # every rank counted the same steps
+    assert np.array_equal(out[0][5], out[1][5]) and np.array_equal(out[0][5], out[2][5])     # N-space solution replicated
+    assert out[1][4].size == 0 and out[1][6].size == 0
+    # against one shard holding all three markers
+    with capi.Shard(N, Mt) as sh:
+        sh.set_layout(False, True)
+        sh.set_kernel_mode(1)
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        a, b, m0 = sh.vecM(va), sh.vecM(vb), sh.vecM(mu0)
+        mu_a, mu_b = sh.vecM(), sh.vecM()
+        sh.cg_solve2x(a, m0, b, 2.0, 0.5, 10, mu_a, mu_b)
+        sh.compute_people_statistics()
+        dn, mn, atm, mb2 = sh.vecN(vn), sh.vecN(), sh.vecM(), sh.vecM()
+        sh.cg_solve_aat2(dn, None, b, 2.0, 0.5, 10, mn, atm, mb2)
+        one = (mu_a.download(), mn.download(), mb2.download())
+    assert np.allclose(np.concatenate([out[r][4] for r in range(3)]), one[0], rtol=1e-9, atol=1e-12)
+    assert np.allclose(out[0][5], one[1], rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.concatenate([out[r][6] for r in range(3)]), one[2], rtol=1e-9, atol=1e-12)
+
+
 def _toy_bed(tmp_path):
     p = tmp_path / "toy.bed"
     p.write_bytes(lzma.open(os.path.join(G, "toy.bed.xz")).read())
