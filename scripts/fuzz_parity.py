@@ -1,6 +1,7 @@
 """Randomised differential test of the product (HIP, through the C ABI) against the CPU oracle on small random shapes.
 
   python scripts/fuzz_parity.py [n_cases] [seed] [sharded]
+  python scripts/fuzz_parity.py <n_cases> <seed> only <case> [tol]     replay one case of a run (every earlier case passed), verbose
 
 Every case draws N, M, missing rate, NA-phenotype rate, shard offset, kernel family and a set of options, then checks the
 matvecs (1e-12) and a short VAMP run (1e-6, identical CG counts) against the oracle.  Development tool: the fixed cases
@@ -22,7 +23,8 @@ def rel(a, b):
     return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
 
 
-def one_case(rng, idx):
+def draw_case(rng, idx):
+    """every random input of a case, drawn without touching the GPU (so that a failing case can be replayed: --only)"""
     N = int(rng.choice([5, 17, 64, 255, 256, 257, 1000, 1003, 2048, 3001, 4100]))
     M = int(rng.choice([1, 3, 63, 64, 65, 255, 256, 257, 700, 1025, 2500]))
     miss = int(rng.choice([0, 1000, 20000, 200000]))
@@ -32,16 +34,35 @@ def one_case(rng, idx):
     Mt = S + M + int(rng.choice([0, 5]))
     seed = int(rng.integers(1, 10**6))
     desc = dict(case=idx, N=N, M=M, miss=miss, fna=fna, mode=mode, S=S, Mt=Mt, seed=seed)
-    bed = synth.synth_bed(N, M, seed=seed, miss_ppm=miss, S=S)
     mb = (N + 3) // 4
     present = rng.random(N) >= fna
     if present.sum() < 3:
         present[:3] = True
+    x = rng.standard_normal(M) * rng.choice([1e-20, 1.0, 1e15])
+    use_mask = bool(fna > 0 or N % 4)
+    p = np.zeros(4 * mb)
+    p[:N] = rng.standard_normal(N) * (present if use_mask else 1.0)
+    d = dict(desc=desc, present=present, x=x, p=p, use_mask=use_mask, vamp=False)
+    # a short VAMP run when the shard is a whole data set with enough signal to be meaningful
+    if S == 0 and Mt == M and M >= 63 and N >= 255 and miss <= 20000:
+        fuse = int(rng.integers(0, 3))
+        xxt = int(rng.random() < 0.25)
+        probit = int(rng.random() < 0.25) and not xxt
+        desc.update(fuse=fuse, xxt=xxt, probit=probit)
+        d.update(vamp=True, yv=rng.standard_normal(N))
+    return d
+
+
+def one_case(rng, idx, tol=1e-5, verbose=False):
+    d = draw_case(rng, idx)
+    desc, present, x, p, use_mask = d["desc"], d["present"], d["x"], d["p"], d["use_mask"]
+    N, M, miss, fna, mode, S, Mt, seed = (desc[k] for k in ("N", "M", "miss", "fna", "mode", "S", "Mt", "seed"))
+    bed = synth.synth_bed(N, M, seed=seed, miss_ppm=miss, S=S)
+    mb = (N + 3) // 4
     m4 = np.zeros(mb, dtype=np.uint8)
     for n in np.nonzero(present)[0]:
         m4[n >> 2] |= 1 << (n & 3)
     nonas = int(present.sum())
-    use_mask = fna > 0 or N % 4
     with capi.Shard(N, M, Mt=Mt, S=S) as sh:
         sh.upload_bed(bed)
         if use_mask:
@@ -52,22 +73,15 @@ def one_case(rng, idx):
         o_mave, o_msig = oracle.marker_stats(bed, N, M, mask4=m4 if use_mask else None, nonas=nonas if use_mask else None)
         assert np.allclose(mave, o_mave, rtol=1e-13, atol=1e-15), "mave"
         assert np.allclose(msig, o_msig, rtol=1e-12, atol=0), "msig"
-        x = rng.standard_normal(M) * rng.choice([1e-20, 1.0, 1e15])
         z = sh.Ax(x)
         oz = oracle.ax(bed, N, M, o_mave, o_msig, x, mask4=m4 if use_mask else None)
         assert rel(z, oz) < 1e-12, ("Ax", rel(z, oz))
-        p = np.zeros(4 * mb)
-        p[:N] = rng.standard_normal(N) * (present if use_mask else 1.0)
         w = sh.ATx(p)
         ow = oracle.atx(bed, N, M, o_mave, o_msig, p)
         assert rel(w, ow) < 1e-12, ("ATx", rel(w, ow))
-        # a short VAMP run when the shard is a whole data set with enough signal to be meaningful
-        if S == 0 and Mt == M and M >= 63 and N >= 255 and miss <= 20000:
-            fuse = int(rng.integers(0, 3))
-            xxt = int(rng.random() < 0.25) if mode == 0 or True else 0
-            probit = int(rng.random() < 0.25) and not xxt
-            desc.update(fuse=fuse, xxt=xxt, probit=probit)
-            yv = rng.standard_normal(N)
+        if d["vamp"]:
+            fuse, xxt, probit = desc["fuse"], desc["xxt"], desc["probit"]
+            yv = d["yv"]
             if probit:
                 yv = (yv > 0).astype(float)
             kw = dict(iterations=3, CG_max_iter=15, rho=0.5, seed=seed % 97 + 1, gam1=1e-8, gamw=1.0 if probit else 2.0)
@@ -79,22 +93,42 @@ def one_case(rng, idx):
             if probit:
                 kw["model"] = okw["model"] = "bin_class"
             probs, vars_ = [0.9, 0.1], [0, 0.02]
-            if use_mask:
-                # file semantics: y scaled over the present individuals (data.cpp:172-182); restated for the product's vector ctor
-                ys = np.where(present, yv, 0.0)
-                avg = ys[present].mean()
-                ys = ys * np.sqrt((nonas - 1) / np.sum((ys[present] - avg) ** 2))
-                ref = oracle.infere(bed, N, M, np.where(present, yv, 0.0), probs, vars_, **okw)
-                r = hostapi.infere_linear(sh, np.where(present, ys, np.finfo(float).max), probs, vars_, mask4=m4, nonas=nonas,
-                                          fuse_solves=fuse, **kw)
-            else:
-                ref = oracle.infere(bed, N, M, yv, probs, vars_, **okw)
-                r = hostapi.infere_linear(sh, yv, probs, vars_, fuse_solves=fuse, **kw)
+
+            def product(fuse_level):
+                if use_mask:
+                    # file semantics: y scaled over the present individuals (data.cpp:172-182); restated for the product's vector ctor
+                    ys = np.where(present, yv, 0.0)
+                    avg = ys[present].mean()
+                    ys = ys * np.sqrt((nonas - 1) / np.sum((ys[present] - avg) ** 2))
+                    return hostapi.infere_linear(sh, np.where(present, ys, np.finfo(float).max), probs, vars_, mask4=m4,
+                                                 nonas=nonas, fuse_solves=fuse_level, **kw)
+                return hostapi.infere_linear(sh, yv, probs, vars_, fuse_solves=fuse_level, **kw)
+
+            ref = oracle.infere(bed, N, M, np.where(present, yv, 0.0) if use_mask else yv, probs, vars_, **okw)
+            r = product(fuse)
+            if verbose:       # replay of one case: where does the difference come from?
+                for i, (t_p, t_o) in enumerate(zip(r.trace, ref.trace)):
+                    keys = ("gam1_denoise", "alpha1", "eta1", "gam2", "alpha2", "eta2", "gam1_next", "gamw", "beta1", "tau2", "tau1_next")
+                    print("   it %d: cg %s / %s ; relative differences product vs oracle: " % (i + 1, t_p["cg_iters"], int(t_o["cg_iters"])) +
+                          ", ".join("%s %.1e" % (k, abs(t_p[k] - t_o[k]) / (abs(t_o[k]) or 1.0)) for k in keys))
+                print("   x_est vs oracle: %.3e   |x_est| %.3e  |oracle| %.3e" % (rel(r.x_est, ref.x_est), np.linalg.norm(r.x_est),
+                                                                                  np.linalg.norm(ref.x_est)))
+                for fl in (0, 1, 2):
+                    if fl != fuse:
+                        print("   fuse %d vs fuse %d: %.3e ; fuse %d vs oracle %.3e" % (
+                            fl, fuse, rel(product(fl).x_est, r.x_est), fl, rel(product(fl).x_est, ref.x_est)))
+                sh.set_kernel_mode(1 - mode)
+                print("   other kernel family vs this one: %.3e" % rel(product(fuse).x_est, r.x_est))
+                sh.set_kernel_mode(mode)
             assert r.niter == ref.niter, "niter"
             assert [t["cg_iters"] for t in r.trace] == [int(t["cg_iters"]) for t in ref.trace], "cg counts"
-            # pure-noise phenotypes are the worst case for the iteration-1 cancellation: 1e-6 here,
-            # the fixed cases of tests/ (simulated signal) hold 1e-7; the north-star tolerance is 1e-5
-            assert rel(r.x_est, ref.x_est) < 1e-6, ("x_est", rel(r.x_est, ref.x_est))
+            # pure-noise phenotypes are the worst case for the cancellations of iteration 1: with gam1 = 1e-8
+            # and no signal, alpha2 = 1 - O(1e-8), so gam1_next = gam2 (1 / alpha2 - 1) carries 1e8 x the rounding difference of
+            # alpha2 (replayed case 89 of seed 777005, probit, N = 255 < M = 1025: every scalar of iteration 1 within 6e-14 of the
+            # oracle's, gam1_next 4.6e-6 off, x_est 1.9e-6; the two kernel families of the product, whose reductions run in the
+            # same order, within 1.3e-9 of each other).  Hence the north-star tolerance 1e-5 here; the fixed cases of tests/
+            # (simulated signal) hold 1e-7
+            assert rel(r.x_est, ref.x_est) < tol, ("x_est", rel(r.x_est, ref.x_est))
     return desc
 
 
@@ -161,6 +195,13 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
+    if len(sys.argv) > 4 and sys.argv[3] == "only":
+        # replay ONE case of a run in which every earlier case passed: the earlier cases' draws are consumed on the host
+        only = int(sys.argv[4])
+        for i in range(only):
+            draw_case(rng, i)
+        print(one_case(rng, only, tol=float(sys.argv[5]) if len(sys.argv) > 5 else 1e-5, verbose=True), flush=True)
+        return
     bad = 0
     for i in range(n):
         state = rng.bit_generator.state
