@@ -48,9 +48,10 @@ void data::open_device(int device, int kernel_mode) {
     if (device < 0) device = gv_env_local_rank();
     if (gv_create(device, &ctx)) die(std::string("FATAL: ") + gv_last_error(nullptr));
     ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
-    // kernel mode 1: two stripe sets (1, default) or the single tile layout (2: half the HBM, same results) -- --resident-layout
+    // kernel mode 1: two stripe sets (1), the single tile layout (2: half the HBM, same bits), or -- the default, 3 -- two stripe
+    // sets when they fit the free HBM and the tile layout when they do not (--resident-layout)
     const char* lay = getenv("GVAMP_RESIDENT_LAYOUT");
-    const int stripes = kernel_mode != 0 ? ((lay && atoi(lay) >= 1 && atoi(lay) <= 3) ? atoi(lay) : 1) : 0;
+    const int stripes = kernel_mode != 0 ? ((lay && atoi(lay) >= 1 && atoi(lay) <= 3) ? atoi(lay) : 3) : 0;
     ck(ctx, gv_set_layout(ctx, kernel_mode == 0, stripes), "gv_set_layout");
     ck(ctx, gv_set_kernel_mode(ctx, kernel_mode), "gv_set_kernel_mode");
     if (kernel_mode == 0 && rank == 0)

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
         int dev = opt.get_device() >= 0 ? opt.get_device() : gv_env_local_rank();
         if (gv_create(dev, &synth_ctx) || gv_set_dims(synth_ctx, N, M, Mt, S) ||
             gv_set_layout(synth_ctx, opt.get_kernel_mode() == 0,
-                          opt.get_kernel_mode() != 0 ? ((opt.get_resident_layout() >= 1 && opt.get_resident_layout() <= 3) ? opt.get_resident_layout() : 1) : 0) ||
+                          opt.get_kernel_mode() != 0 ? ((opt.get_resident_layout() >= 1 && opt.get_resident_layout() <= 3) ? opt.get_resident_layout() : 3) : 0) ||
             gv_set_kernel_mode(synth_ctx, opt.get_kernel_mode()) ||
             gv_synth_bed(synth_ctx, (uint64_t)opt.get_synth_seed(), opt.get_synth_miss_ppm())) {
             std::cout << "FATAL: " << gv_last_error(synth_ctx) << std::endl;
