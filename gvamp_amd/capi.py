@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -37,6 +37,10 @@ class CgStats(C.Structure):
 
 class CgExtras(C.Structure):
     _fields_ = [("ride_x", C.c_void_p), ("ride_out", C.c_void_p), ("a_mu_a", C.c_void_p), ("ata_mu_b", C.c_void_p)]
+
+
+class CgWarm(C.Structure):
+    _fields_ = [("ata_mu_start_a", C.c_void_p), ("a_mu_start_a", C.c_void_p), ("ata_mu_a", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -107,6 +111,8 @@ def load():
                                C.POINTER(CgStats), dp, dp]
     L.gv_cg_solve2x.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
                                 C.POINTER(CgStats), dp, dp, C.POINTER(CgExtras)]
+    L.gv_cg_solve2w.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
+                                C.POINTER(CgStats), dp, dp, C.POINTER(CgExtras), C.POINTER(CgWarm)]
     L.gv_set_phen.argtypes = [vp, vp, dp]
     L.gv_lmmse_mult.argtypes = [vp, vp, C.c_double, C.c_double, vp]
     L.gv_cg_solve.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, C.POINTER(CgStats), dp]
@@ -119,6 +125,8 @@ def load():
     L.gv_cg_solve_aat.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.POINTER(CgStats), dp]
     L.gv_cg_solve_aat2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, C.POINTER(CgStats),
                                    C.POINTER(CgStats), dp, dp, vp, vp]
+    L.gv_cg_solve_aat2w.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, C.POINTER(CgStats),
+                                    C.POINTER(CgStats), dp, dp, vp, vp, vp]
     L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
     L.gv_pvals_loco.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp]
     L.gv_pvals_loco_pred.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp, dp]
@@ -344,13 +352,20 @@ class Shard:
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def cg_solve2x(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, ride_x=None, ride_out=None, a_mu_a=None,
-                   ata_mu_b=None):
-        """gv_cg_solve2 plus its pass-free by-products (include/gvamp.h: gv_cg_extras)."""
+                   ata_mu_b=None, ata_mu_start_a=None, a_mu_start_a=None, ata_mu_a=None):
+        """gv_cg_solve2 plus its pass-free by-products (include/gvamp.h: gv_cg_extras) and, when one of the last three
+        arguments is given, the warm start whose initial residual costs no pass (gv_cg_warm, gv_cg_solve2w)."""
         sa, sb = CgStats(), CgStats()
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
         ex = CgExtras(*[v.h if v is not None else None for v in (ride_x, ride_out, a_mu_a, ata_mu_b)])
-        self._ck(self.L.gv_cg_solve2x(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
-                                      max_iter, mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb), C.byref(ex)))
+        ms = mu_start_a.h if mu_start_a is not None else None
+        if ata_mu_start_a is None and a_mu_start_a is None and ata_mu_a is None:
+            self._ck(self.L.gv_cg_solve2x(self.h, v_a.h, ms, v_b.h, tau, gam2, max_iter, mu_a.h, mu_b.h, C.byref(sa),
+                                          C.byref(sb), _dp(ra), _dp(rb), C.byref(ex)))
+        else:
+            wm = CgWarm(*[v.h if v is not None else None for v in (ata_mu_start_a, a_mu_start_a, ata_mu_a)])
+            self._ck(self.L.gv_cg_solve2w(self.h, v_a.h, ms, v_b.h, tau, gam2, max_iter, mu_a.h, mu_b.h, C.byref(sa),
+                                          C.byref(sb), _dp(ra), _dp(rb), C.byref(ex), C.byref(wm)))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def denoise(self, r1, gam1, probs, vars_scaled, x1_out, d_out=None):
@@ -390,14 +405,17 @@ class Shard:
                                         mu_out.h, C.byref(st), _dp(rr)))
         return st, rr[:st.n_relres].copy()
 
-    def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None):
-        """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes."""
+    def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None,
+                      aat_mu_start_a=None):
+        """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes;
+        aat_mu_start_a = A A^T mu_start_a known from the previous call (gv_cg_solve_aat2w): no pass for the initial residual."""
         sa, sb = CgStats(), CgStats()
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
-        self._ck(self.L.gv_cg_solve_aat2(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
-                                         max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
-                                         aat_mu_a.h if aat_mu_a is not None else None,
-                                         ata_mu_b.h if ata_mu_b is not None else None))
+        self._ck(self.L.gv_cg_solve_aat2w(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
+                                          max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
+                                          aat_mu_a.h if aat_mu_a is not None else None,
+                                          ata_mu_b.h if ata_mu_b is not None else None,
+                                          aat_mu_start_a.h if aat_mu_start_a is not None else None))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def pvals_calc_loco_pred(self, z1, y, x1_hat, chrom):

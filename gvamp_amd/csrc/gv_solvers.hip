@@ -42,6 +42,9 @@ struct CgSys {
     double* az = nullptr;          // N-space: A mu, accumulated from the A p_k of the operator applications
     const double* wslot = nullptr; // N-space buffer holding A req after the last application
     bool keep_resid = false;       // keep r = v - Q mu exact on the Onsager-rule exit too
+    // warm start whose products are already known (gv_cg_solve2w): A^T A mu0 and A mu0 -- no pass for the initial residual
+    const double* ata0 = nullptr;
+    const double* amu0 = nullptr;
 };
 
 static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
@@ -469,7 +472,17 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
     for (int k = 0; k < nsys; k++) {
         CgSys& s = sys[k];
-        if (s.mu0) {
+        if (s.mu0 && s.ata0) {
+            // r = v - Q mu0 with A^T A mu0 handed in by the caller (the previous solve left it: Q' mu0 = v' - r'), so the
+            // initial residual of a warm start (vamp.cpp:1142-1145) costs no pass over the shard
+            HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            gvk::axpby(c->stream, s.r, 1.0, s.v, -tau, s.ata0, M);
+            gvk::axpby(c->stream, s.r, 1.0, s.r, -gam2, s.mu0, M);
+            if (s.az && s.amu0 != s.az)
+                HIPCHK(c, hipMemcpyAsync(s.az, s.amu0, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, c->stream));   // A mu0
+            KCHK(c);
+            if (cg_finish_init(c, s, diag, multi)) return 1;
+        } else if (s.mu0) {
             HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
             s.phase = 0;
             s.req = s.mu;
@@ -555,6 +568,12 @@ int gv_cg_solve(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double tau, 
 int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                   int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
                   double* relres_b, const gv_cg_extras* ex) {
+    return gv_cg_solve2w(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, st_a, st_b, relres_a, relres_b, ex, nullptr);
+}
+
+int gv_cg_solve2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b, double* relres_a,
+                  double* relres_b, const gv_cg_extras* ex, const gv_cg_warm* wm) {
     NEED(c, v_a->space == GV_SPACE_M && v_b->space == GV_SPACE_M && mu_a->space == GV_SPACE_M && mu_b->space == GV_SPACE_M,
          "gv_cg_solve2: M-space vectors required");
     NEED(c, mu_a != v_a && mu_a != mu_start_a && mu_b != v_b && mu_a != mu_b, "gv_cg_solve2: outputs must not alias inputs");
@@ -567,6 +586,15 @@ int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
     NEED(c, !ex->ata_mu_b || (ex->ata_mu_b->space == GV_SPACE_M && ex->ata_mu_b != mu_b && ex->ata_mu_b != v_b),
          "gv_cg_solve2x: ata_mu_b is M-space and must not alias v_b / mu_b");
     NEED(c, !ex->ata_mu_b || tau != 0.0, "gv_cg_solve2x: ata_mu_b needs tau != 0");
+    gv_cg_warm nowarm{};
+    if (!wm) wm = &nowarm;
+    NEED(c, !wm->ata_mu_start_a || (mu_start_a && wm->ata_mu_start_a->space == GV_SPACE_M && wm->ata_mu_start_a != mu_a),
+         "gv_cg_solve2w: ata_mu_start_a goes with mu_start_a, is M-space and must not alias mu_a");
+    NEED(c, !wm->ata_mu_start_a || !ex->a_mu_a || (wm->a_mu_start_a && wm->a_mu_start_a->space == GV_SPACE_N),
+         "gv_cg_solve2w: a_mu_a with a known warm start needs a_mu_start_a (N-space)");
+    NEED(c, !wm->ata_mu_a || (wm->ata_mu_a->space == GV_SPACE_M && wm->ata_mu_a != mu_a && wm->ata_mu_a != v_a &&
+                              wm->ata_mu_a != mu_start_a && wm->ata_mu_a != mu_b && wm->ata_mu_a != v_b && tau != 0.0),
+         "gv_cg_solve2w: ata_mu_a is M-space, must not alias the systems' vectors, and needs tau != 0");
     if (ensure_work(c)) return 1;
     if (ensure_w2(c)) return 1;
     for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
@@ -577,6 +605,10 @@ int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
     s[0].r = c->cg_r->d; s[0].z = c->cg_z->d; s[0].p = c->cg_p->d; s[0].d = c->cg_d->d;
     s[0].denoiser = 1; s[0].relres = relres_a;
     s[0].az = ex->a_mu_a ? ex->a_mu_a->d : nullptr;
+    if (wm->ata_mu_start_a) {
+        s[0].ata0 = wm->ata_mu_start_a->d;
+        s[0].amu0 = wm->a_mu_start_a ? wm->a_mu_start_a->d : nullptr;
+    }
     s[1].v = v_b->d; s[1].mu0 = nullptr; s[1].mu = mu_b->d;
     s[1].r = c->cg2_r->d; s[1].z = c->cg2_z->d; s[1].p = c->cg2_p->d; s[1].d = c->cg2_d->d;
     s[1].denoiser = 0; s[1].relres = relres_b;
@@ -587,6 +619,12 @@ int gv_cg_solve2x(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
         double* o = ex->ata_mu_b->d;
         gvk::axpby(c->stream, o, 1.0 / tau, s[1].v, -1.0 / tau, s[1].r, c->M);
         gvk::axpby(c->stream, o, 1.0, o, -gam2 / tau, s[1].mu, c->M);
+        KCHK(c);
+    }
+    if (wm->ata_mu_a) {   // the same identity for solve a (its r is current on every exit: residual rule or iteration cap)
+        double* o = wm->ata_mu_a->d;
+        gvk::axpby(c->stream, o, 1.0 / tau, s[0].v, -1.0 / tau, s[0].r, c->M);
+        gvk::axpby(c->stream, o, 1.0, o, -gam2 / tau, s[0].mu, c->M);
         KCHK(c);
     }
     cg_fill_stats(s[0], st_a);
@@ -737,6 +775,17 @@ struct HalfOp {
 int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b) {
+    return gv_cg_solve_aat2w(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, st_a, st_b, relres_a, relres_b,
+                             aat_mu_a, ata_mu_b, nullptr);
+}
+
+// aat_mu_start_a (N-space, or NULL): A A^T mu_start_a, as the previous call left it in aat_mu_a -- the initial residual of
+// the warm-started N-space solve (denoiserXXT.cpp:76-78) is then formed without its ATx + Ax pair.
+int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
+                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_vec* aat_mu_start_a) {
+    NEED(c, !aat_mu_start_a || (mu_start_a && aat_mu_start_a->space == GV_SPACE_N && aat_mu_start_a != mu_a),
+         "gv_cg_solve_aat2w: aat_mu_start_a goes with mu_start_a, is N-space and must not alias mu_a");
     NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
          "gv_cg_solve_aat2: system a lives in N-space");
     NEED(c, v_b->space == GV_SPACE_M && mu_b->space == GV_SPACE_M && at_mu_a->space == GV_SPACE_M,
@@ -806,7 +855,16 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
             ha.pending = true; ha.stage = 0; ha.one_half = true; ha.src = mu; ha.mid = nullptr; ha.dst = at_mu_a->d;
         };
         gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
-        if (mu_start_a) {
+        if (mu_start_a && aat_mu_start_a) {
+            // r = v - (tau A A^T mu0 + gam2 mu0) from the product the previous solve left (Q' mu0 = v' - r'): no pass
+            MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            gvk::axpby(s, r, 1.0, v_a->d, -tau, aat_mu_start_a->d, n);
+            gvk::axpby(s, r, 1.0, r, -gam2, mu_start_a->d, n);
+            MIX_TRY(a_init_scalars());
+            if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
+            a_phase = 1;
+            if (max_iter > 0) a_post(p, d); else a_finish();
+        } else if (mu_start_a) {
             MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
             a_phase = 0;
             a_post(mu, r);

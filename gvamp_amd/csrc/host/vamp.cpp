@@ -71,7 +71,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, unfrozen, frozen, dvec})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, unfrozen, frozen, dvec})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -163,8 +163,22 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
         ex.ata_mu_b = ata_der;      // A^T A invQ u      (vamp.cpp:913-914)
         have_derived = true;
     }
-    ck(gv_cg_solve2x(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
-                     &ex), "gv_cg_solve2x");
+    gv_cg_warm wm{};
+    if (fuse_solves >= 3 && warm_chain) {
+        // --fuse-solves 3: the warm start of the next iteration is this solve's x2_hat (mu_CG_last, vamp.cpp:1226), and
+        // Q x2_hat = v - r holds for the final residual -- so the opening r = v - Q mu_start of precondCG_solver
+        // (vamp.cpp:1142-1145, one Ax + one ATx) is formed from the product the previous solve left, and A x2_hat keeps
+        // accumulating in place in ax2_der.  8 passes per iteration instead of 10 when the CG runs 4 steps.
+        if (!ata_x2) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_x2), "gv_vec_alloc");
+        wm.ata_mu_a = ata_x2;
+        if (mu_start && have_ata_x2) {
+            wm.ata_mu_start_a = ata_x2;
+            wm.a_mu_start_a = ax2_der;
+        }
+    }
+    ck(gv_cg_solve2w(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
+                     &ex, &wm), "gv_cg_solve2w");
+    have_ata_x2 = wm.ata_mu_a != nullptr;
     if (verbose && rank == 0) {
         for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
         for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
@@ -271,6 +285,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     }
     alpha1 = 0;
     alpha2 = 0;   // read at vamp.cpp:501 before its first assignment (:631); harmless there, 0 here
+    have_ata_x2 = have_aat_prev = false;
+    warm_chain = true;      // the LMMSE solves of this loop warm-start one another (infere_bin_class starts every solve from zero)
     const double sqrtN = sqrt((double)N);
 
     if (gam1_init != -1) {   // restart (vamp.cpp:226-233): r1 file stores r1 / sqrt(N)... and is divided once more
@@ -480,9 +496,13 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             }
             gv_cg_stats sa, sb;
             std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
-            ck(gv_cg_solve_aat2(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, tM,
-                                invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
-                                have_derived ? ata_der : nullptr), "gv_cg_solve_aat2");
+            // --fuse-solves 3: A A^T u of the previous iteration (aat_der, from that solve's final residual) gives the initial
+            // residual of this warm start without the ATx + Ax pair of denoiserXXT.cpp:76-78 (gvamp.h: gv_cg_solve_aat2w)
+            const bool known_start = fuse_solves >= 3 && it > 1 && have_aat_prev;
+            ck(gv_cg_solve_aat2w(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, tM,
+                                 invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
+                                 have_derived ? ata_der : nullptr, known_start ? aat_der : nullptr), "gv_cg_solve_aat2w");
+            have_aat_prev = have_derived;
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
             if (verbose && rank == 0) {
@@ -610,6 +630,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
 std::vector<double> vamp::infere_bin_class(data* dataset) {
     ctx = dataset->get_ctx();
     S = dataset->get_S();
+    warm_chain = false;     // every LMMSE solve of this loop starts from zero (vamp_probit.cpp:497)
     auto newM = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_M, v), "gv_vec_alloc"); };
     auto newN = [&](gv_vec** v) { ck(gv_vec_alloc(ctx, GV_SPACE_N, v), "gv_vec_alloc"); };
     for (gv_vec** v : {&x1_hat, &x1_hat_prev, &x2_hat, &r1, &r2, &bern_vec, &invQ_bern_vec, &vM, &tM}) newM(v);

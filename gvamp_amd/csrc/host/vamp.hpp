@@ -83,6 +83,10 @@ public:
     gv_vec *aat_der = nullptr;        // --use-XXT-denoiser 1: A A^T u from the residual of the N-space solve
     gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
     bool have_derived = false;
+    // --fuse-solves 3: A^T A x2_hat from the final residual of the LMMSE solve; the next iteration's warm start (mu_CG_last =
+    // this x2_hat) forms its initial residual from it instead of applying the operator (gvamp.h: gv_cg_warm)
+    gv_vec* ata_x2 = nullptr;
+    bool have_ata_x2 = false, warm_chain = false, have_aat_prev = false;
     // --use-freeze 1 (vamp.cpp:205-209,:308,:353): markers whose g1d does not enter alpha1 and that are not damped
     int use_freeze = 0;
     std::string freeze_index_file;

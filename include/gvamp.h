@@ -151,6 +151,25 @@ typedef struct gv_cg_extras {
 int gv_cg_solve2x(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                   int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
                   double* relres_a, double* relres_b, const gv_cg_extras* extras);
+/* gv_cg_solve2x whose warm start costs no pass.  precondCG_solver opens with r = v - Q mu_start (vamp.cpp:1142-1145: one Ax
+ * and one ATx); when mu_start_a is the mu_a of the PREVIOUS call, that call's final residual already holds the product:
+ * Q' mu = v' - r'  =>  A^T A mu = (v' - r' - gam2' mu) / tau'.  Every member may be NULL:
+ *   ata_mu_a       (M-space, out): A^T A mu_a of THIS solve from its final residual -- hand it to the next call;
+ *   ata_mu_start_a (M-space, in) : A^T A mu_start_a (the previous call's ata_mu_a; may be the same handle as ata_mu_a).
+ *                                  r = v_a - tau * ata_mu_start_a - gam2 * mu_start_a replaces the operator application;
+ *   a_mu_start_a   (N-space, in) : A mu_start_a, required with ata_mu_start_a when extras->a_mu_a is wanted (its
+ *                                  accumulation starts there; may be the same handle as extras->a_mu_a, i.e. the previous
+ *                                  call's a_mu_a left in place).
+ * An identity of the CG recurrences like a_mu_a / ata_mu_b: equal to the explicit products to rounding, not bit for bit;
+ * the rounding of successive calls adds up (no call re-anchors on an explicit product), ~1e-16 relative per CG step. */
+typedef struct gv_cg_warm {
+    const gv_vec* ata_mu_start_a;
+    const gv_vec* a_mu_start_a;
+    gv_vec* ata_mu_a;
+} gv_cg_warm;
+int gv_cg_solve2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                  int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
+                  double* relres_a, double* relres_b, const gv_cg_extras* extras, const gv_cg_warm* warm);
 
 /* ---- denoiser side (fused element-wise kernels) ------------------------------------------------------
  * vamp::g1 / g1d over a vector (vamp.cpp:805-869; loops :292-310): x1 = g1(r1), sums[0] = sum g1d(r1) (local),
@@ -192,6 +211,12 @@ int gv_cg_solve_aat(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double
 int gv_cg_solve_aat2(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b);
+/* The same with a warm start that costs no pass: aat_mu_start_a (N-space, or NULL) = A A^T mu_start_a as the previous call
+ * left it in aat_mu_a (may be that very handle); r = v_a - tau * aat_mu_start_a - gam2 * mu_start_a then replaces the ATx + Ax
+ * pair of denoiserXXT.cpp:76-78.  Equal to the explicit residual to rounding. */
+int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
+                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_vec* aat_mu_start_a);
 
 /* ---- association tests after the loop (vamp.cpp:761-776) ------------------------------------------------------
  * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,

@@ -1,0 +1,154 @@
+"""--fuse-solves 3: the warm start of the LMMSE solve without its opening operator application.
+
+precondCG_solver starts with r = v - Q mu_start (vamp.cpp:1142-1145: one Ax + one ATx).  mu_start is the solution of the
+previous iteration's solve, whose final residual already holds the product: Q' mu = v' - r'.  gv_cg_solve2w /
+gv_cg_solve_aat2w take that product from the caller; these tests hold them against the explicit warm start (same step counts,
+iterates to rounding, two passes fewer) and whole VAMP runs against --fuse-solves 2 and the oracle."""
+import numpy as np
+import pytest
+
+from gvamp_amd import capi, hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("N,M", [(2000, 1500), (1003, 2049)])
+def test_chained_solves_with_known_products_match_the_explicit_warm_start(N, M, layout):
+    """three solves in a row, each warm-started from the one before with (tau, gam2, v) changing as in a VAMP run: the
+    chain that passes A^T A mu / A mu along must follow the chain that applies the operator"""
+    rng = np.random.default_rng(N + layout)
+    bed = synth.synth_bed(N, M, seed=21, miss_ppm=8000)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(True, layout)
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        du = sh.vecM(u)
+        mu_e, mu_w, mb_e, mb_w = sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()      # explicit / known-product chains
+        start_e, start_w = sh.vecM(), sh.vecM()
+        az_e, az_w, ata_w = sh.vecN(), sh.vecN(), sh.vecM()
+        for k, (tau, gam2) in enumerate([(2.0, 1.35), (1.7, 2.9), (2.4, 0.6)]):
+            dv = sh.vecM(rng.standard_normal(M))
+            warm = k > 0
+            sh.counters(reset=True)
+            (se, re_), (sbe, _) = sh.cg_solve2x(dv, start_e if warm else None, du, tau, gam2, 30, mu_e, mb_e, a_mu_a=az_e)
+            ce = sh.counters()
+            sh.counters(reset=True)
+            (sw, rw), (sbw, _) = sh.cg_solve2x(dv, start_w if warm else None, du, tau, gam2, 30, mu_w, mb_w, a_mu_a=az_w,
+                                               ata_mu_start_a=ata_w if warm else None, a_mu_start_a=az_w if warm else None,
+                                               ata_mu_a=ata_w)
+            cw = sh.counters()
+            assert (sw.iters, sbw.iters, sw.converged) == (se.iters, sbe.iters, se.converged)
+            assert np.allclose(rw, re_, rtol=1e-7)                      # residual traces (values ~1e-5 at the exit)
+            assert rel(mu_w.download(), mu_e.download()) < 1e-11
+            assert rel(mb_w.download(), mb_e.download()) < 1e-11
+            assert rel(az_w.download(), sh.Ax(mu_w.download())) < 1e-11   # A mu keeps accumulating in place across the calls
+            assert rel(ata_w.download(), sh.ATx(sh.Ax(mu_w.download()))) < 1e-9   # (v - r - gam2 mu) / tau: r is 1e-5 |v|
+            # the warm start's operator application is gone: one Ax pass and one ATx pass fewer
+            assert cw["n_ax_pass"] == ce["n_ax_pass"] - (1 if warm else 0)
+            assert cw["n_atx_pass"] == ce["n_atx_pass"] - (1 if warm else 0)
+            start_e.upload(mu_e.download())
+            start_w.upload(mu_w.download())
+            dv.free()
+
+
+def test_known_product_arguments_are_checked():
+    N, M = 400, 300
+    bed = synth.synth_bed(N, M, seed=2)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        v, u, mu, mb, ata, az = sh.vecM(np.ones(M)), sh.vecM(np.ones(M) / np.sqrt(M)), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecN()
+        with pytest.raises(capi.GvError):        # a known product without the start it belongs to
+            sh.cg_solve2x(v, None, u, 2.0, 1.0, 5, mu, mb, ata_mu_start_a=ata)
+        start = sh.vecM(np.zeros(M))
+        with pytest.raises(capi.GvError):        # a_mu_a wanted, A mu_start not given
+            sh.cg_solve2x(v, start, u, 2.0, 1.0, 5, mu, mb, a_mu_a=az, ata_mu_start_a=ata)
+        with pytest.raises(capi.GvError):        # output aliasing the solution
+            sh.cg_solve2x(v, start, u, 2.0, 1.0, 5, mu, mb, ata_mu_a=mu)
+        # and the context still works
+        sh.cg_solve2x(v, start, u, 2.0, 1.0, 5, mu, mb, ata_mu_start_a=ata, ata_mu_a=ata)
+        assert np.all(np.isfinite(mu.download()))
+
+
+def test_xxt_joint_solver_with_a_known_start_product():
+    N, M = 1200, 900
+    rng = np.random.default_rng(5)
+    bed = synth.synth_bed(N, M, seed=31, miss_ppm=5000)
+    npad = 4 * ((N + 3) // 4)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        sh.compute_people_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        du = sh.vecM(u)
+        n_e, n_w, at_e, at_w, m_e, m_w = sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
+        s_e, s_w, aat_w = sh.vecN(), sh.vecN(), sh.vecN()
+        for k, (tau, gam2) in enumerate([(2.0, 1.1), (1.4, 2.2), (2.6, 0.8)]):
+            vn = np.zeros(npad)
+            vn[:N] = rng.standard_normal(N)
+            dvn = sh.vecN(vn)
+            warm = k > 0
+            sh.counters(reset=True)
+            (ae, _), (be, _) = sh.cg_solve_aat2(dvn, s_e if warm else None, du, tau, gam2, 30, n_e, at_e, m_e)
+            ce = sh.counters()
+            sh.counters(reset=True)
+            (aw, _), (bw, _) = sh.cg_solve_aat2(dvn, s_w if warm else None, du, tau, gam2, 30, n_w, at_w, m_w, aat_mu_a=aat_w,
+                                                aat_mu_start_a=aat_w if warm else None)
+            cw = sh.counters()
+            assert (aw.iters, bw.iters) == (ae.iters, be.iters)
+            assert rel(n_w.download(), n_e.download()) < 1e-10
+            assert rel(at_w.download(), at_e.download()) < 1e-10
+            assert rel(m_w.download(), m_e.download()) < 1e-10
+            # (the passes are shared with the M-space solve, half an application out of phase: the two half-applications saved
+            # show as fewer passes only when solve a is the longer chain)
+            assert cw["n_ax_pass"] + cw["n_atx_pass"] <= ce["n_ax_pass"] + ce["n_atx_pass"]
+            assert cw["n_ax"] + cw["n_atx"] == ce["n_ax"] + ce["n_atx"] - (2 if warm else 0)      # vector products: two fewer
+            s_e.upload(n_e.download())
+            s_w.upload(n_w.download())
+            dvn.free()
+
+
+@pytest.mark.parametrize("xxt", [0, 1])
+def test_vamp_runs_at_fuse_3_follow_fuse_2_and_the_oracle(oracle, xxt):
+    N, M = 2000, 3000
+    bed = synth.synth_bed(N, M, seed=44, miss_ppm=5000)
+    beta, y = oracle.sim_phen(bed, N, M, 0.5, 150, 4)
+    probs, vars_ = [0.9, 0.07, 0.03], [0, 1e-3, 1e-2]
+    kw = dict(iterations=6, CG_max_iter=40, rho=0.5, seed=4, true_signal=beta, history=True)
+    if xxt:
+        kw["use_XXT_denoiser"] = 1
+    ref = oracle.infere(bed, N, M, y, probs, vars_, **{k: v for k, v in kw.items() if k != "history"})
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        r2 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=2, **kw)
+        r3 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=3, **kw)
+    assert r3.niter == r2.niter == ref.niter
+    for i, (a, b, o) in enumerate(zip(r2.trace, r3.trace, ref.trace)):
+        assert (b["cg_iters"], b["onsager_iters"], b["L_after"]) == (a["cg_iters"], a["onsager_iters"], a["L_after"])
+        assert b["cg_iters"] == int(o["cg_iters"])
+        for k in ("gam1_denoise", "alpha1", "gam2", "alpha2", "gamw", "gam1_next"):
+            assert abs(a[k] - b[k]) <= 1e-9 * abs(a[k]), (i, k)
+        # the warm start's Ax + ATx are gone as vector products; as PASSES the saving is 0, 1 or 2 -- the opening application of
+        # solve a shared its pass pair with the first step of solve b, so a pair disappears only when a was the longer chain,
+        # and z1 = A x1_hat, which rode in the slot a solve that finished early leaves free, takes a pass of its own when
+        # both solves now finish together
+        passes2, passes3 = a["n_ax_pass"] + a["n_atx_pass"], b["n_ax_pass"] + b["n_atx_pass"]
+        assert passes2 - 2 <= passes3 <= passes2, (i, passes2, passes3)
+        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - (2 if i > 0 else 0), i
+    saved = sum(a["n_ax_pass"] + a["n_atx_pass"] - b["n_ax_pass"] - b["n_atx_pass"] for a, b in zip(r2.trace, r3.trace))
+    assert saved >= (1 if not xxt else 0), saved
+    assert rel(r3.x_est, r2.x_est) < 1e-9
+    assert rel(r3.x_est, ref.x_est) < 1e-7
