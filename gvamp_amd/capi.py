@@ -43,6 +43,10 @@ class CgWarm(C.Structure):
     _fields_ = [("ata_mu_start_a", C.c_void_p), ("a_mu_start_a", C.c_void_p), ("ata_mu_a", C.c_void_p)]
 
 
+class AatWarm(C.Structure):
+    _fields_ = [("aat_mu_start_a", C.c_void_p), ("at_mu_start_a", C.c_void_p), ("accumulate_at_mu_a", C.c_int)]
+
+
 class Counters(C.Structure):
     _fields_ = [("n_ax", C.c_int64), ("n_atx", C.c_int64), ("ms_ax", C.c_double), ("ms_atx", C.c_double),
                 ("ms_allreduce", C.c_double), ("n_ax_kernel", C.c_int64), ("n_atx_kernel", C.c_int64),
@@ -126,7 +130,7 @@ def load():
     L.gv_cg_solve_aat2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, C.POINTER(CgStats),
                                    C.POINTER(CgStats), dp, dp, vp, vp]
     L.gv_cg_solve_aat2w.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, C.POINTER(CgStats),
-                                    C.POINTER(CgStats), dp, dp, vp, vp, vp]
+                                    C.POINTER(CgStats), dp, dp, vp, vp, C.POINTER(AatWarm)]
     L.gv_pvals_loo.argtypes = [vp, vp, vp, vp, dp]
     L.gv_pvals_loco.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp]
     L.gv_pvals_loco_pred.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int), dp, dp]
@@ -406,16 +410,18 @@ class Shard:
         return st, rr[:st.n_relres].copy()
 
     def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None,
-                      aat_mu_start_a=None):
-        """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes;
-        aat_mu_start_a = A A^T mu_start_a known from the previous call (gv_cg_solve_aat2w): no pass for the initial residual."""
+                      aat_mu_start_a=None, at_mu_start_a=None, accumulate_at_mu_a=False):
+        """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes; the last three
+        arguments are gv_aat_warm (gv_cg_solve_aat2w): A A^T mu_start_a / A^T mu_start_a known from the previous call, and
+        A^T mu_a accumulated inside the solve instead of by a closing pass."""
         sa, sb = CgStats(), CgStats()
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
+        wm = AatWarm(aat_mu_start_a.h if aat_mu_start_a is not None else None,
+                     at_mu_start_a.h if at_mu_start_a is not None else None, int(bool(accumulate_at_mu_a)))
         self._ck(self.L.gv_cg_solve_aat2w(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
                                           max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
                                           aat_mu_a.h if aat_mu_a is not None else None,
-                                          ata_mu_b.h if ata_mu_b is not None else None,
-                                          aat_mu_start_a.h if aat_mu_start_a is not None else None))
+                                          ata_mu_b.h if ata_mu_b is not None else None, C.byref(wm)))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def pvals_calc_loco_pred(self, z1, y, x1_hat, chrom):

@@ -1112,11 +1112,13 @@ void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
               double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
-              unsigned long long* flag, unsigned long long seq) {
+              unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m) {
     const int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, partial);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, red);
     hipLaunchKernelGGL(k_aat_ab, dim3(nb), dim3(256), 0, s, st, mu, p, r, d, z, diag, red, n, partial);
+    // A^T mu += alpha A^T p (at_p = the first half of this application), before k_aat_decide may clear ST_ACTIVE
+    if (at_acc && m > 0) hipLaunchKernelGGL(k_axpy_st, dim3(nblk(m, 256)), dim3(256), 0, s, at_acc, at_p, st, m);
     hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, red + 2);
     hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq);
     hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);

@@ -430,10 +430,12 @@ static int cgx_upload_state(gv_ctx* c, int blk, double rz, double normv, int den
 }
 // one CG_solverAAT step (state block 0) after d = A (A^T p) has arrived
 static int aat_step_device(gv_ctx* c, double* mu, double* p, double* r, double* d, double* z, const double* DG, double tau,
-                           double gam2, int max_iter, bool want_rel, CgxStatus* out) {
+                           double gam2, int max_iter, bool want_rel, CgxStatus* out, double* at_acc = nullptr,
+                           const double* at_p = nullptr) {
     const unsigned long long seq = ++c->mbox_seq;
     gvk::aat_step(c->stream, c->cgx_state, mu, p, r, d, z, DG, tau, gam2, c->npad, c->red_partial, c->red_out + 16,
-                  want_rel ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq);
+                  want_rel ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq,
+                  at_acc, at_p, c->M);
     KCHK(c);
     CgxStatus s2[2];
     if (cgx_wait(c, seq, s2)) return 1;
@@ -779,13 +781,23 @@ int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, con
                              aat_mu_a, ata_mu_b, nullptr);
 }
 
-// aat_mu_start_a (N-space, or NULL): A A^T mu_start_a, as the previous call left it in aat_mu_a -- the initial residual of
-// the warm-started N-space solve (denoiserXXT.cpp:76-78) is then formed without its ATx + Ax pair.
+// gv_aat_warm (gvamp.h).  aat_mu_start_a: A A^T mu_start_a, as the previous call left it in aat_mu_a -- the initial residual of
+// the warm-started N-space solve (denoiserXXT.cpp:76-78) is then formed without its ATx + Ax pair.  accumulate_at_mu_a: A^T mu_a
+// is built from the A^T p_k every application starts with (A^T mu_a = A^T mu_start_a + sum_k alpha_k A^T p_k) instead of by a
+// closing ATx pass; A^T mu_start_a comes from at_mu_start_a, or from the explicit opening application, or is 0 for a zero start.
 int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
-                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_vec* aat_mu_start_a) {
+                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_aat_warm* wm) {
+    gv_aat_warm nowarm{};
+    if (!wm) wm = &nowarm;
+    const gv_vec* aat_mu_start_a = wm->aat_mu_start_a;
     NEED(c, !aat_mu_start_a || (mu_start_a && aat_mu_start_a->space == GV_SPACE_N && aat_mu_start_a != mu_a),
          "gv_cg_solve_aat2w: aat_mu_start_a goes with mu_start_a, is N-space and must not alias mu_a");
+    NEED(c, !wm->at_mu_start_a || (wm->accumulate_at_mu_a && mu_start_a && wm->at_mu_start_a->space == GV_SPACE_M),
+         "gv_cg_solve_aat2w: at_mu_start_a goes with mu_start_a and accumulate_at_mu_a, and is M-space");
+    NEED(c, !(wm->accumulate_at_mu_a && aat_mu_start_a && !wm->at_mu_start_a),
+         "gv_cg_solve_aat2w: accumulating A^T mu_a from a start whose opening application is skipped needs at_mu_start_a");
+    double* const at_acc = wm->accumulate_at_mu_a ? at_mu_a->d : nullptr;
     NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
          "gv_cg_solve_aat2: system a lives in N-space");
     NEED(c, v_b->space == GV_SPACE_M && mu_b->space == GV_SPACE_M && at_mu_a->space == GV_SPACE_M,
@@ -851,10 +863,19 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
             ha.pending = true; ha.stage = 0; ha.one_half = false; ha.src = src; ha.mid = MA->d; ha.dst = dst;
         };
         auto a_finish = [&]() {                                // the solve is over: A^T mu_a is the last request
+            if (at_acc) { a_phase = 3; ha.pending = false; return; }   // ... unless it has been accumulated along the way
             a_phase = 2;
             ha.pending = true; ha.stage = 0; ha.one_half = true; ha.src = mu; ha.mid = nullptr; ha.dst = at_mu_a->d;
         };
         gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
+        if (at_acc) {
+            if (wm->at_mu_start_a) {
+                if (wm->at_mu_start_a->d != at_acc)
+                    MIX_HIP(hipMemcpyAsync(at_acc, wm->at_mu_start_a->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+            } else if (!mu_start_a)
+                gvk::fill(s, at_acc, M, 0.0);
+            // (explicit warm start: the first half of its opening application is A^T mu0 -- copied when it arrives, below)
+        }
         if (mu_start_a && aat_mu_start_a) {
             // r = v - (tau A A^T mu0 + gam2 mu0) from the product the previous solve left (Q' mu0 = v' - r'): no pass
             MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
@@ -914,7 +935,12 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
             }
             for (int k = 0; k < nt; k++) {
                 HalfOp* h = todo[k];
-                if (h->stage == 0 && !h->one_half) { h->stage = 1; continue; }     // second half still to come
+                if (h->stage == 0 && !h->one_half) {                               // second half still to come
+                    if (h == &ha && a_phase == 0 && at_acc)                         // A^T mu0 of an explicit warm start
+                        MIX_HIP(hipMemcpyAsync(at_acc, MA->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+                    h->stage = 1;
+                    continue;
+                }
                 h->pending = false;
                 if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
                     sb.wslot = c->w_n->d;
@@ -942,7 +968,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 }
                 if (dev) {                                                         // one CG step (:86-120), scalars on the device
                     CgxStatus stt;
-                    MIX_TRY(aat_step_device(c, mu, p, r, d, z, DG->d, tau, gam2, max_iter, relres_a != nullptr, &stt));
+                    MIX_TRY(aat_step_device(c, mu, p, r, d, z, DG->d, tau, gam2, max_iter, relres_a != nullptr, &stt, at_acc, MA->d));
                     a_iters = (int)stt.iters; a_rel = stt.rel; a_nrel = (int)stt.nrel;
                     if (stt.active == 0.0) { a_conv = (int)stt.conv; a_finish(); }
                     else a_post(p, d);
@@ -957,6 +983,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 MIX_TRY(read_scalars(c, 1, &dp));
                 const double alpha = a_rz / dp;
                 gvk::axpby(s, mu, 1.0, mu, alpha, p, n);
+                if (at_acc) gvk::axpby(s, at_acc, 1.0, at_acc, alpha, MA->d, M);       // A^T mu += alpha A^T p
                 arm_scalars(c);
                 gvk::cg_step_b_diag(s, r, d, alpha, DG->d, z, n, c->red_partial, c->red_out);
                 MIX_TRY(read_scalars(c, 2, sc));

@@ -71,7 +71,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, unfrozen, frozen, dvec})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, at_u, unfrozen, frozen, dvec})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -498,10 +498,20 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
             // --fuse-solves 3: A A^T u of the previous iteration (aat_der, from that solve's final residual) gives the initial
             // residual of this warm start without the ATx + Ax pair of denoiserXXT.cpp:76-78 (gvamp.h: gv_cg_solve_aat2w)
+            // and A^T u (for x2_hat = r2 + gamw A^T u, denoiserXXT.cpp:46-48) is accumulated from the A^T p_k of the solve
+            // instead of taking a closing ATx pass: it lives in at_u across the iterations
             const bool known_start = fuse_solves >= 3 && it > 1 && have_aat_prev;
-            ck(gv_cg_solve_aat2w(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, tM,
+            gv_aat_warm wm{};
+            gv_vec* at_out = tM;
+            if (fuse_solves >= 3) {
+                if (!at_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &at_u), "gv_vec_alloc");
+                at_out = at_u;
+                wm.accumulate_at_mu_a = 1;
+                if (known_start) { wm.aat_mu_start_a = aat_der; wm.at_mu_start_a = at_u; }
+            }
+            ck(gv_cg_solve_aat2w(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, at_out,
                                  invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
-                                 have_derived ? ata_der : nullptr, known_start ? aat_der : nullptr), "gv_cg_solve_aat2w");
+                                 have_derived ? ata_der : nullptr, &wm), "gv_cg_solve_aat2w");
             have_aat_prev = have_derived;
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
@@ -510,7 +520,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
             }
             ck(gv_vec_copy(ctx, mu_CG_last_N, tN2), "gv_vec_copy");
-            ck(gv_vec_axpby(ctx, x2_hat, gamw, tM, 1.0, r2), "gv_vec_axpby");
+            ck(gv_vec_axpby(ctx, x2_hat, gamw, at_out, 1.0, r2), "gv_vec_axpby");
             fused_alpha2 = gam2 * dotM(bern_vec, invQ_bern_vec);
             // A x2_hat = A r2 + gamw A A^T u, the latter from the residual of the N-space solve (no pass)
             if (have_derived) ck(gv_vec_axpby(ctx, ax2_der, 1.0, ax2_der, gamw, aat_der), "gv_vec_axpby");

@@ -211,12 +211,24 @@ int gv_cg_solve_aat(gv_ctx* ctx, const gv_vec* v, const gv_vec* mu_start, double
 int gv_cg_solve_aat2(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b);
-/* The same with a warm start that costs no pass: aat_mu_start_a (N-space, or NULL) = A A^T mu_start_a as the previous call
- * left it in aat_mu_a (may be that very handle); r = v_a - tau * aat_mu_start_a - gam2 * mu_start_a then replaces the ATx + Ax
- * pair of denoiserXXT.cpp:76-78.  Equal to the explicit residual to rounding. */
+/* The same with products the caller already holds.  Every member may be NULL / 0:
+ *   aat_mu_start_a (N-space): A A^T mu_start_a as the previous call left it in aat_mu_a (may be that very handle);
+ *                             r = v_a - tau * aat_mu_start_a - gam2 * mu_start_a then replaces the ATx + Ax pair that opens a
+ *                             warm-started CG_solverAAT (denoiserXXT.cpp:76-78);
+ *   accumulate_at_mu_a      : at_mu_a = A^T mu_a is accumulated from the A^T p_k every operator application starts with
+ *                             (A^T mu_a = A^T mu_start_a + sum_k alpha_k A^T p_k) instead of by a closing ATx pass;
+ *   at_mu_start_a (M-space) : A^T mu_start_a for that sum (the previous call's at_mu_a; may be the same handle as at_mu_a) --
+ *                             required when aat_mu_start_a skips the opening application, taken from that application otherwise,
+ *                             0 for a zero start.
+ * Identities of the recurrences: equal to the explicit products to rounding, not bit for bit. */
+typedef struct gv_aat_warm {
+    const gv_vec* aat_mu_start_a;
+    const gv_vec* at_mu_start_a;
+    int accumulate_at_mu_a;
+} gv_aat_warm;
 int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
-                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_vec* aat_mu_start_a);
+                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_aat_warm* warm);
 
 /* ---- association tests after the loop (vamp.cpp:761-776) ------------------------------------------------------
  * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,

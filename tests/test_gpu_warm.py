@@ -94,6 +94,7 @@ def test_xxt_joint_solver_with_a_known_start_product():
         du = sh.vecM(u)
         n_e, n_w, at_e, at_w, m_e, m_w = sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
         s_e, s_w, aat_w = sh.vecN(), sh.vecN(), sh.vecN()
+        n_c, at_c, m_c, s_c, aat_c = sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecN()
         for k, (tau, gam2) in enumerate([(2.0, 1.1), (1.4, 2.2), (2.6, 0.8)]):
             vn = np.zeros(npad)
             vn[:N] = rng.standard_normal(N)
@@ -106,6 +107,24 @@ def test_xxt_joint_solver_with_a_known_start_product():
             (aw, _), (bw, _) = sh.cg_solve_aat2(dvn, s_w if warm else None, du, tau, gam2, 30, n_w, at_w, m_w, aat_mu_a=aat_w,
                                                 aat_mu_start_a=aat_w if warm else None)
             cw = sh.counters()
+            # third chain: A^T mu_a accumulated inside the solve as well (no closing ATx pass), from the previous call's value
+            sh.counters(reset=True)
+            (ac, _), (bc, _) = sh.cg_solve_aat2(dvn, s_c if warm else None, du, tau, gam2, 30, n_c, at_c, m_c, aat_mu_a=aat_c,
+                                                aat_mu_start_a=aat_c if warm else None, at_mu_start_a=at_c if warm else None,
+                                                accumulate_at_mu_a=True)
+            cc = sh.counters()
+            assert (ac.iters, bc.iters) == (ae.iters, be.iters)
+            assert rel(n_c.download(), n_e.download()) < 1e-10 and rel(m_c.download(), m_e.download()) < 1e-10
+            assert rel(at_c.download(), at_e.download()) < 1e-10
+            assert cc["n_atx"] == cw["n_atx"] - 1                         # the closing A^T mu_a is gone
+            assert cc["n_ax_pass"] + cc["n_atx_pass"] <= cw["n_ax_pass"] + cw["n_atx_pass"]
+            s_c.upload(n_c.download())
+            # and accumulation with an explicit warm start (its opening application delivers A^T mu0)
+            n_x, at_x, m_x = sh.vecN(), sh.vecM(), sh.vecM()
+            sh.cg_solve_aat2(dvn, s_e if warm else None, du, tau, gam2, 30, n_x, at_x, m_x, accumulate_at_mu_a=True)
+            assert rel(at_x.download(), at_e.download()) < 1e-10 and rel(n_x.download(), n_e.download()) < 1e-12
+            for q in (n_x, at_x, m_x):
+                q.free()
             assert (aw.iters, bw.iters) == (ae.iters, be.iters)
             assert rel(n_w.download(), n_e.download()) < 1e-10
             assert rel(at_w.download(), at_e.download()) < 1e-10
@@ -146,9 +165,10 @@ def test_vamp_runs_at_fuse_3_follow_fuse_2_and_the_oracle(oracle, xxt):
         # and z1 = A x1_hat, which rode in the slot a solve that finished early leaves free, takes a pass of its own when
         # both solves now finish together
         passes2, passes3 = a["n_ax_pass"] + a["n_atx_pass"], b["n_ax_pass"] + b["n_atx_pass"]
-        assert passes2 - 2 <= passes3 <= passes2, (i, passes2, passes3)
-        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - (2 if i > 0 else 0), i
+        # (XXT: the closing A^T u of denoiserXXT.cpp:46 is accumulated inside the solve as well -- one more product, every iteration)
+        assert passes2 - (3 if xxt else 2) <= passes3 <= passes2, (i, passes2, passes3)
+        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - (2 if i > 0 else 0) - (1 if xxt else 0), i
     saved = sum(a["n_ax_pass"] + a["n_atx_pass"] - b["n_ax_pass"] - b["n_atx_pass"] for a, b in zip(r2.trace, r3.trace))
-    assert saved >= (1 if not xxt else 0), saved
+    assert saved >= (0 if xxt else 1), saved       # (XXT: nothing to save in passes while the Onsager solve is the longer chain)
     assert rel(r3.x_est, r2.x_est) < 1e-9
     assert rel(r3.x_est, ref.x_est) < 1e-7
