@@ -5,7 +5,10 @@ random tau / gam2 / iteration cap / warm start / rider, and
      iteration counts, product counts and traces, iterates to 1e-12, the rider's product bit for bit;
   B. the same solves on 2-4 in-process marker shards (random cut points, empty shards allowed, exchange overlapped or not)
      against the single shard: same iteration counts, iterates to 1e-9 (the sharded sums add in another order), and the
-     overlapped exchange bit-identical to the one-message form."""
+     overlapped exchange bit-identical to the one-message form;
+  C. (in every run of A and B) a second solve warm-started from the first with another (v, tau, gam2), its opening residual
+     taken from the products the first solve left (gv_cg_solve2w) against the explicit opening application: same step
+     counts, one Ax and one ATx fewer, iterates at the conditioning of the operator."""
 import os
 import sys
 import threading
@@ -65,9 +68,36 @@ def solves(sh, M, S, P):
     st, rr = sh.cg_solve(va, mu0, P["tau"], P["gam2"], P["denoiser"], P["max_iter"], mu)
     c1 = sh.counters(reset=True)
     mu_a, mu_b, ro, amu, ata = sh.vecM(), sh.vecM(), sh.vecN(), sh.vecN(), sh.vecM()
+    ata_a = sh.vecM()
     (sa, ra), (sb, rb) = sh.cg_solve2x(va, mu0, vb, P["tau"], P["gam2"], P["max_iter"], mu_a, mu_b, ride_x=rx,
-                                       ride_out=ro if P["ride"] else None, a_mu_a=amu, ata_mu_b=ata)
+                                       ride_out=ro if P["ride"] else None, a_mu_a=amu, ata_mu_b=ata, ata_mu_a=ata_a)
     c2 = sh.counters(reset=True)
+    # C. the next solve of a VAMP run: warm-started from mu_a with another (v, tau, gam2) -- the opening residual taken from the
+    #    products the solve above left (gv_cg_solve2w) against the opening operator application; collectives included, this is
+    #    what a sharded --fuse-solves 3 run does
+    if True:      # (every rank of a group, an empty shard included: the solves are collective)
+        va2 = sh.vecM(P["va2"][S:S + M])
+        start = sh.vecM(mu_a.download())
+        me, mbe, mw, mbw, amu_e = sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecN()
+        t2, g2 = P["tau"] * 0.8, P["gam2"] * 1.7
+        (se, re_), (sbe, _) = sh.cg_solve2x(va2, start, vb, t2, g2, P["max_iter"], me, mbe, a_mu_a=amu_e)
+        ce = sh.counters(reset=True)
+        (sw, rw), (sbw, _) = sh.cg_solve2x(va2, start, vb, t2, g2, P["max_iter"], mw, mbw, a_mu_a=amu, ata_mu_start_a=ata_a,
+                                           a_mu_start_a=amu, ata_mu_a=ata_a)
+        cw = sh.counters(reset=True)
+        # (rounding differences between two correct CG runs grow with the conditioning of the operator; a run cut off far from
+        # convergence amplifies them without bound: values are compared for converged runs, at a tolerance that follows kappa)
+        kap = 1.0 + t2 / g2 * (1.0 + np.sqrt(sh.Mt / sh.N)) ** 2
+        ctol = min(1e-5, 1e-12 * kap ** 2 + 1e-9)
+        tame = P["max_iter"] >= 8 and se.converged and min(sh.N, sh.Mt) > 130
+        assert (sw.iters, sbw.iters) == (se.iters, sbe.iters) or not tame, ("chained steps", sw.iters, sbw.iters, se.iters, sbe.iters)
+        if tame:
+            assert close(mw.download(), me.download(), ctol), ("chained mu", rel(mw.download(), me.download()), ctol)
+            assert close(amu.download(), amu_e.download(), ctol), ("chained A mu", rel(amu.download(), amu_e.download()), ctol)
+        assert cw["n_ax"] == ce["n_ax"] - 1 and cw["n_atx"] == ce["n_atx"] - 1 or (sw.iters, sbw.iters) != (se.iters, sbe.iters), \
+            ("chained products", cw["n_ax"], ce["n_ax"])
+        for q in (va2, start, me, mbe, mw, mbw, amu_e):
+            q.free()
     keys = ("n_ax", "n_atx", "n_ax_pass", "n_atx_pass")
     x = {}
     if P["xxt"]:       # the N-space solver of --use-XXT-denoiser 1, alone and sharing its passes with the Onsager solve
@@ -144,7 +174,7 @@ def run_case(seed0, k):
     P = dict(tau=float(10.0 ** rng.uniform(-2, 2)), gam2=float(10.0 ** rng.uniform(-3, 2)), denoiser=int(rng.integers(2)),
              max_iter=int(rng.choice([0, 1, 2, 5, 40])), warm=bool(rng.integers(2)), ride=bool(rng.integers(2)),
              va=rng.standard_normal(M), vb=np.sign(rng.standard_normal(M)) / np.sqrt(M), mu0=rng.standard_normal(M) * 0.1,
-             rx=rng.standard_normal(M), xxt=bool(rng.random() < 0.4))
+             rx=rng.standard_normal(M), xxt=bool(rng.random() < 0.4), va2=rng.standard_normal(M))
     n4 = 4 * ((N + 3) // 4)
     P["vn"], P["mn0"] = np.zeros(n4), np.zeros(n4)
     P["vn"][:N] = rng.standard_normal(N) * present
