@@ -40,11 +40,13 @@ class CgExtras(C.Structure):
 
 
 class CgWarm(C.Structure):
-    _fields_ = [("ata_mu_start_a", C.c_void_p), ("a_mu_start_a", C.c_void_p), ("ata_mu_a", C.c_void_p)]
+    _fields_ = [("ata_mu_start_a", C.c_void_p), ("a_mu_start_a", C.c_void_p), ("ata_mu_a", C.c_void_p),
+                ("ata_v_b", C.c_void_p), ("have_ata_v_b", C.c_int)]
 
 
 class AatWarm(C.Structure):
-    _fields_ = [("aat_mu_start_a", C.c_void_p), ("at_mu_start_a", C.c_void_p), ("accumulate_at_mu_a", C.c_int)]
+    _fields_ = [("aat_mu_start_a", C.c_void_p), ("at_mu_start_a", C.c_void_p), ("accumulate_at_mu_a", C.c_int),
+                ("ata_v_b", C.c_void_p), ("have_ata_v_b", C.c_int)]
 
 
 class Counters(C.Structure):
@@ -356,18 +358,19 @@ class Shard:
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
 
     def cg_solve2x(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, ride_x=None, ride_out=None, a_mu_a=None,
-                   ata_mu_b=None, ata_mu_start_a=None, a_mu_start_a=None, ata_mu_a=None):
+                   ata_mu_b=None, ata_mu_start_a=None, a_mu_start_a=None, ata_mu_a=None, ata_v_b=None, have_ata_v_b=False):
         """gv_cg_solve2 plus its pass-free by-products (include/gvamp.h: gv_cg_extras) and, when one of the last three
         arguments is given, the warm start whose initial residual costs no pass (gv_cg_warm, gv_cg_solve2w)."""
         sa, sb = CgStats(), CgStats()
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
         ex = CgExtras(*[v.h if v is not None else None for v in (ride_x, ride_out, a_mu_a, ata_mu_b)])
         ms = mu_start_a.h if mu_start_a is not None else None
-        if ata_mu_start_a is None and a_mu_start_a is None and ata_mu_a is None:
+        if ata_mu_start_a is None and a_mu_start_a is None and ata_mu_a is None and ata_v_b is None:
             self._ck(self.L.gv_cg_solve2x(self.h, v_a.h, ms, v_b.h, tau, gam2, max_iter, mu_a.h, mu_b.h, C.byref(sa),
                                           C.byref(sb), _dp(ra), _dp(rb), C.byref(ex)))
         else:
-            wm = CgWarm(*[v.h if v is not None else None for v in (ata_mu_start_a, a_mu_start_a, ata_mu_a)])
+            wm = CgWarm(*[v.h if v is not None else None for v in (ata_mu_start_a, a_mu_start_a, ata_mu_a, ata_v_b)],
+                        int(bool(have_ata_v_b)))
             self._ck(self.L.gv_cg_solve2w(self.h, v_a.h, ms, v_b.h, tau, gam2, max_iter, mu_a.h, mu_b.h, C.byref(sa),
                                           C.byref(sb), _dp(ra), _dp(rb), C.byref(ex), C.byref(wm)))
         return (sa, ra[:sa.n_relres].copy()), (sb, rb[:sb.n_relres].copy())
@@ -410,14 +413,15 @@ class Shard:
         return st, rr[:st.n_relres].copy()
 
     def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None,
-                      aat_mu_start_a=None, at_mu_start_a=None, accumulate_at_mu_a=False):
+                      aat_mu_start_a=None, at_mu_start_a=None, accumulate_at_mu_a=False, ata_v_b=None, have_ata_v_b=False):
         """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes; the last three
         arguments are gv_aat_warm (gv_cg_solve_aat2w): A A^T mu_start_a / A^T mu_start_a known from the previous call, and
         A^T mu_a accumulated inside the solve instead of by a closing pass."""
         sa, sb = CgStats(), CgStats()
         ra, rb = np.zeros(max(max_iter, 1)), np.zeros(max(max_iter, 1))
         wm = AatWarm(aat_mu_start_a.h if aat_mu_start_a is not None else None,
-                     at_mu_start_a.h if at_mu_start_a is not None else None, int(bool(accumulate_at_mu_a)))
+                     at_mu_start_a.h if at_mu_start_a is not None else None, int(bool(accumulate_at_mu_a)),
+                     ata_v_b.h if ata_v_b is not None else None, int(bool(have_ata_v_b)))
         self._ck(self.L.gv_cg_solve_aat2w(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
                                           max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
                                           aat_mu_a.h if aat_mu_a is not None else None,

@@ -45,7 +45,27 @@ struct CgSys {
     // warm start whose products are already known (gv_cg_solve2w): A^T A mu0 and A mu0 -- no pass for the initial residual
     const double* ata0 = nullptr;
     const double* amu0 = nullptr;
+    // A^T A v of a zero-started solve whose right-hand side does not change between calls (the Onsager probe): input that
+    // replaces the first operator application (ata_v_known), else captured from it
+    double* ata_v = nullptr;
+    bool ata_v_known = false;
 };
+
+// The first CG step of a zero-started solve applies the operator to p0 = z0 = v / diag.  With A^T A v at hand,
+// d = Q p0 = (tau / diag) A^T A v + gam2 p0 needs no pass; the step itself is the host-driven one (same arithmetic as on the device).
+static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double diag, int max_iter, bool multi);
+static int cg_first_step_from_known_product(gv_ctx* c, CgSys& s, double tau, double gam2, double diag, int max_iter, bool multi) {
+    if (!(s.ata_v && s.ata_v_known && s.active && s.phase == 1 && s.iters == 0 && !s.mu0 && max_iter > 0)) return 0;
+    gvk::axpby(c->stream, s.d, tau / diag, s.ata_v, gam2, s.p, c->M);
+    KCHK(c);
+    CgSys* one[1] = {&s};
+    return cg_consume_all(c, one, 1, gam2, diag, max_iter, multi);
+}
+// ... and where the product is not at hand yet, the first application delivers it: d = tau A^T A (v / diag) + gam2 v / diag
+static void cg_capture_first_product(gv_ctx* c, const CgSys& s, double tau, double gam2, double diag) {
+    if (!(s.ata_v && !s.ata_v_known && tau != 0.0)) return;
+    gvk::axpby(c->stream, s.ata_v, diag / tau, s.d, -gam2 / tau, s.v, c->M);
+}
 
 static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
     // z = r / diag (:1152), <r,z>, ||v||^2 ; p = z (:1154)
@@ -338,6 +358,9 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
                       sys[0].p, sys[1].p, tau, gam2, &hk);
         else
             gvm::atx(st, c->plan, wn[0], npad, c->mave, c->msig, scale, c->red_partial, sys[act[0]].d, sys[act[0]].p, tau, gam2, &hk);
+        if (steps.empty())     // the first step of the loop: a zero-started system that has not stepped yet applies Q to v / diag
+            for (int j = 0; j < ns; j++)
+                if (done_iters[act[j]] == 0 && !sys[act[j]].mu0) cg_capture_first_product(c, sys[act[j]], tau, gam2, diag);
         KCHK(c);
         const int K = 8 * (act[ns - 1] + 1);
         if (multi && comm_allreduce(c, c->red_out, K)) return 1;               // <d,p>
@@ -428,6 +451,17 @@ static int cgx_upload_state(gv_ctx* c, int blk, double rz, double normv, int den
     HIPCHK(c, hipStreamSynchronize(c->stream));      // the pinned block may be rewritten for the other system right away
     return 0;
 }
+// the same for an M-space system that may already have taken steps on the host (iteration count, Onsager memory, trace length)
+static int cgx_upload_sys(gv_ctx* c, int blk, const CgSys& s) {
+    double* q = c->cgx_pin + blk * gvm::ST_SIZE;
+    for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+    q[gvm::ST_RZ] = s.rz; q[gvm::ST_NORMV] = s.norm_v; q[gvm::ST_PREV_ONS] = s.prev_onsager; q[gvm::ST_ONS] = s.onsager;
+    q[gvm::ST_RELERR] = s.rel_err; q[gvm::ST_ACTIVE] = s.active ? 1.0 : 0.0; q[gvm::ST_ITERS] = s.iters;
+    q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
+    HIPCHK(c, hipMemcpyAsync(c->cgx_state + blk * gvm::ST_SIZE, q, sizeof(double) * gvm::ST_SIZE, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 // one CG_solverAAT step (state block 0) after d = A (A^T p) has arrived
 static int aat_step_device(gv_ctx* c, double* mu, double* p, double* r, double* d, double* z, const double* DG, double tau,
                            double gam2, int max_iter, bool want_rel, CgxStatus* out, double* at_acc = nullptr,
@@ -497,6 +531,8 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
         }
         if (max_iter <= 0 && s.phase == 1) s.active = false;
     }
+    for (int k = 0; k < nsys; k++)
+        if (cg_first_step_from_known_product(c, sys[k], tau, gam2, diag, max_iter, multi)) return 1;
     const char* cgdev = getenv("GV_CG_DEVICE");
     // (chosen by nothing rank-local: an empty shard, M == 0, must enter the same sequence of collectives as its peers)
     const bool device_loop = c->kernel_mode == 1 && c->have_stripes && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
@@ -531,6 +567,8 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
                 return 1;
             act[0]->wslot = c->w_n->d;
         }
+        for (int k = 0; k < na; k++)
+            if (act[k]->phase == 1 && act[k]->iters == 0 && !act[k]->mu0) cg_capture_first_product(c, *act[k], tau, gam2, diag);
         if (cg_consume_all(c, act, na, gam2, diag, max_iter, multi)) return 1;
     }
     if (ride_x && ax_device(c, ride_x, ride_out)) return 1;
@@ -597,6 +635,10 @@ int gv_cg_solve2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
     NEED(c, !wm->ata_mu_a || (wm->ata_mu_a->space == GV_SPACE_M && wm->ata_mu_a != mu_a && wm->ata_mu_a != v_a &&
                               wm->ata_mu_a != mu_start_a && wm->ata_mu_a != mu_b && wm->ata_mu_a != v_b && tau != 0.0),
          "gv_cg_solve2w: ata_mu_a is M-space, must not alias the systems' vectors, and needs tau != 0");
+    NEED(c, !wm->ata_v_b || (wm->ata_v_b->space == GV_SPACE_M && wm->ata_v_b != v_b && wm->ata_v_b != mu_b && wm->ata_v_b != mu_a &&
+                             wm->ata_v_b != v_a && tau != 0.0),
+         "gv_cg_solve2w: ata_v_b is M-space, must not alias the systems' vectors, and needs tau != 0");
+    NEED(c, !wm->have_ata_v_b || wm->ata_v_b, "gv_cg_solve2w: have_ata_v_b without ata_v_b");
     if (ensure_work(c)) return 1;
     if (ensure_w2(c)) return 1;
     for (gv_vec** w : {&c->cg2_r, &c->cg2_z, &c->cg2_p, &c->cg2_d})
@@ -615,6 +657,7 @@ int gv_cg_solve2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const 
     s[1].r = c->cg2_r->d; s[1].z = c->cg2_z->d; s[1].p = c->cg2_p->d; s[1].d = c->cg2_d->d;
     s[1].denoiser = 0; s[1].relres = relres_b;
     s[1].keep_resid = ex->ata_mu_b != nullptr;
+    if (wm->ata_v_b) { s[1].ata_v = wm->ata_v_b->d; s[1].ata_v_known = wm->have_ata_v_b != 0; }
     if (cg_run(c, s, 2, tau, gam2, max_iter, ex->ride_x ? ex->ride_x->d : nullptr, ex->ride_out ? ex->ride_out->d : nullptr))
         return 1;
     if (ex->ata_mu_b) {   // Q mu_b = v_b - r_b  =>  A^T A mu_b = (v_b - r_b - gam2 mu_b) / tau
@@ -797,6 +840,10 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
          "gv_cg_solve_aat2w: at_mu_start_a goes with mu_start_a and accumulate_at_mu_a, and is M-space");
     NEED(c, !(wm->accumulate_at_mu_a && aat_mu_start_a && !wm->at_mu_start_a),
          "gv_cg_solve_aat2w: accumulating A^T mu_a from a start whose opening application is skipped needs at_mu_start_a");
+    NEED(c, !wm->ata_v_b || (wm->ata_v_b->space == GV_SPACE_M && wm->ata_v_b != v_b && wm->ata_v_b != mu_b && wm->ata_v_b != at_mu_a &&
+                             tau != 0.0),
+         "gv_cg_solve_aat2w: ata_v_b is M-space, must not alias the systems' vectors, and needs tau != 0");
+    NEED(c, !wm->have_ata_v_b || wm->ata_v_b, "gv_cg_solve_aat2w: have_ata_v_b without ata_v_b");
     double* const at_acc = wm->accumulate_at_mu_a ? at_mu_a->d : nullptr;
     NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
          "gv_cg_solve_aat2: system a lives in N-space");
@@ -843,7 +890,17 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
         MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
         if (max_iter <= 0) sb.active = false;
-        if (dev) MIX_TRY(cgx_upload_state(c, 1, sb.rz, sb.norm_v, 0, sb.active));
+        if (wm->ata_v_b) { sb.ata_v = wm->ata_v_b->d; sb.ata_v_known = wm->have_ata_v_b != 0; }
+        // (A^T A v_b at hand: the first step of solve b without its Ax + ATx; the residual trace of a device run lives on the
+        // device, its first entry goes there)
+        double rel0 = 0;
+        double* keep_rel = sb.relres;
+        if (dev && sb.relres) sb.relres = &rel0;
+        MIX_TRY(cg_first_step_from_known_product(c, sb, tau, gam2, diag_b, max_iter, multi));
+        sb.relres = keep_rel;
+        if (dev && keep_rel && sb.n_relres > 0)
+            MIX_HIP(hipMemcpyAsync(c->cgx_rel + c->cgx_relcap, &rel0, sizeof(double), hipMemcpyHostToDevice, s));
+        if (dev) { MIX_HIP(hipStreamSynchronize(s)); MIX_TRY(cgx_upload_sys(c, 1, sb)); }
     }
     {
         auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
@@ -944,6 +1001,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 h->pending = false;
                 if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
                     sb.wslot = c->w_n->d;
+                    if (sb.iters == 0) cg_capture_first_product(c, sb, tau, gam2, diag_b);   // its first application: A^T A v_b
                     if (dev) {
                         CgxStatus stt;
                         MIX_TRY(mspace_step_device(c, sb, gam2, diag_b, max_iter, multi, &stt));

@@ -212,6 +212,7 @@ std::vector<int> data::read_chromosome_info(std::string bim_file) {
     for (int line_n = 0; getline(infile, line); line_n++) {
         if (line_n < S || line_n >= S + M) continue;
         std::vector<std::string> tokens = split_ws(line);
+        if (tokens.empty()) die("FATAL: empty line " + std::to_string(line_n + 1) + " in bim file " + bim_file);
         chroms.push_back(tokens[0] == "X" ? 23 : (int)atof(tokens[0].c_str()));
     }
     return chroms;

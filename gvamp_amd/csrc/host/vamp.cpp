@@ -71,7 +71,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, at_u, unfrozen, frozen, dvec})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, at_u, ata_u, unfrozen, frozen, dvec})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -131,6 +131,7 @@ void vamp::draw_onsager_probe(data* dataset) {
     if (have_probe && probe_key == key) return;
     have_probe = true;
     probe_key = key;
+    have_ata_u = false;         // A^T A u belongs to the probe
     std::mt19937 rd{key};
     std::bernoulli_distribution bern(0.5);
     std::vector<double> u(M > 0 ? M : 0);
@@ -176,9 +177,17 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
             wm.a_mu_start_a = ax2_der;
         }
     }
+    if (fuse_solves >= 3 && CG_max_iter > 0) {
+        // the Onsager solve starts from zero on the same probe u every iteration: its first operator application is
+        // (tau / diag) A^T A u + gam2 u / diag, with A^T A u captured the first time round -- the solve is one pass pair shorter
+        if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
+        wm.ata_v_b = ata_u;
+        wm.have_ata_v_b = have_ata_u ? 1 : 0;
+    }
     ck(gv_cg_solve2w(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
                      &ex, &wm), "gv_cg_solve2w");
     have_ata_x2 = wm.ata_mu_a != nullptr;
+    if (wm.ata_v_b) have_ata_u = true;
     if (verbose && rank == 0) {
         for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
         for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
@@ -508,11 +517,17 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 at_out = at_u;
                 wm.accumulate_at_mu_a = 1;
                 if (known_start) { wm.aat_mu_start_a = aat_der; wm.at_mu_start_a = at_u; }
+                if (CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
+                    if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
+                    wm.ata_v_b = ata_u;
+                    wm.have_ata_v_b = have_ata_u ? 1 : 0;
+                }
             }
             ck(gv_cg_solve_aat2w(ctx, tN, it == 1 ? nullptr : mu_CG_last_N, bern_vec, gamw, gam2, CG_max_iter, tN2, at_out,
                                  invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
                                  have_derived ? ata_der : nullptr, &wm), "gv_cg_solve_aat2w");
             have_aat_prev = have_derived;
+            if (wm.ata_v_b) have_ata_u = true;
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
             if (verbose && rank == 0) {

@@ -86,6 +86,8 @@ public:
     // --fuse-solves 3: A^T A x2_hat from the final residual of the LMMSE solve; the next iteration's warm start (mu_CG_last =
     // this x2_hat) forms its initial residual from it instead of applying the operator (gvamp.h: gv_cg_warm)
     gv_vec* ata_x2 = nullptr;
+    gv_vec* ata_u = nullptr;        // level 3: A^T A u of the Onsager probe (the same u every iteration): its solve starts one step in
+    bool have_ata_u = false;
     gv_vec* at_u = nullptr;         // --use-XXT-denoiser 1 at level 3: A^T u, accumulated inside the N-space solve
     bool have_ata_x2 = false, warm_chain = false, have_aat_prev = false;
     // --use-freeze 1 (vamp.cpp:205-209,:308,:353): markers whose g1d does not enter alpha1 and that are not damped

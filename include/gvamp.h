@@ -166,6 +166,14 @@ typedef struct gv_cg_warm {
     const gv_vec* ata_mu_start_a;
     const gv_vec* a_mu_start_a;
     gv_vec* ata_mu_a;
+    /* Solve b starts from zero, so its first step applies the operator to v_b / diag.  When v_b is the same vector call after call
+     * (the Onsager probe of vamp.cpp:875 is re-seeded identically every iteration), A^T A v_b never changes:
+     *   ata_v_b (M-space): with have_ata_v_b == 0 an OUTPUT -- A^T A v_b, taken from solve b's first application (written when
+     *                      max_iter > 0); with have_ata_v_b != 0 an INPUT -- that first application becomes
+     *                      (tau / diag) * ata_v_b + gam2 * v_b / diag and costs no pass, so solve b is one pass pair shorter.
+     * The caller owns the invariant "same v_b as when ata_v_b was written".  Equal to the explicit product to rounding. */
+    gv_vec* ata_v_b;
+    int have_ata_v_b;
 } gv_cg_warm;
 int gv_cg_solve2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                   int max_iter, gv_vec* mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
@@ -225,6 +233,8 @@ typedef struct gv_aat_warm {
     const gv_vec* aat_mu_start_a;
     const gv_vec* at_mu_start_a;
     int accumulate_at_mu_a;
+    gv_vec* ata_v_b;            /* as in gv_cg_warm: A^T A v_b of the zero-started M-space solve b, captured or handed in */
+    int have_ata_v_b;
 } gv_aat_warm;
 int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,

@@ -165,10 +165,63 @@ def test_vamp_runs_at_fuse_3_follow_fuse_2_and_the_oracle(oracle, xxt):
         # and z1 = A x1_hat, which rode in the slot a solve that finished early leaves free, takes a pass of its own when
         # both solves now finish together
         passes2, passes3 = a["n_ax_pass"] + a["n_atx_pass"], b["n_ax_pass"] + b["n_atx_pass"]
-        # (XXT: the closing A^T u of denoiserXXT.cpp:46 is accumulated inside the solve as well -- one more product, every iteration)
-        assert passes2 - (3 if xxt else 2) <= passes3 <= passes2, (i, passes2, passes3)
-        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - (2 if i > 0 else 0) - (1 if xxt else 0), i
+        # (XXT: the closing A^T u of denoiserXXT.cpp:46 is accumulated inside the solve as well -- one more product, every iteration;
+        # and from the second iteration on the Onsager solve takes its first application from A^T A u of the probe: two more)
+        assert passes2 - (5 if xxt else 4) <= passes3 <= passes2, (i, passes2, passes3)
+        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - (4 if i > 0 else 0) - (1 if xxt else 0), i
     saved = sum(a["n_ax_pass"] + a["n_atx_pass"] - b["n_ax_pass"] - b["n_atx_pass"] for a, b in zip(r2.trace, r3.trace))
-    assert saved >= (0 if xxt else 1), saved       # (XXT: nothing to save in passes while the Onsager solve is the longer chain)
+    assert saved >= 1, saved
     assert rel(r3.x_est, r2.x_est) < 1e-9
     assert rel(r3.x_est, ref.x_est) < 1e-7
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_zero_started_solve_with_the_product_of_its_right_hand_side(layout):
+    """solve b (the Onsager probe solve: zero start, the same v_b call after call): A^T A v_b captured from its first application,
+    then handed back -- same steps, same iterates to rounding, one Ax and one ATx fewer"""
+    N, M = 1500, 2300
+    rng = np.random.default_rng(17)
+    bed = synth.synth_bed(N, M, seed=9, miss_ppm=5000)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(True, layout)
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        du, atau = sh.vecM(u), sh.vecM()
+        mu_a, mu_b, mu_a2, mu_b2, wb, wb2 = sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
+        for k, (tau, gam2) in enumerate([(2.0, 1.35), (1.1, 3.0), (3.0, 0.4)]):
+            dv = sh.vecM(rng.standard_normal(M))
+            sh.counters(reset=True)
+            (sa, _), (sb, rb) = sh.cg_solve2x(dv, None, du, tau, gam2, 30, mu_a, mu_b, ata_mu_b=wb)
+            c0 = sh.counters()
+            sh.counters(reset=True)
+            (sa2, _), (sb2, rb2) = sh.cg_solve2x(dv, None, du, tau, gam2, 30, mu_a2, mu_b2, ata_mu_b=wb2, ata_v_b=atau,
+                                                 have_ata_v_b=k > 0)
+            c1 = sh.counters()
+            assert (sa2.iters, sb2.iters, sb2.converged) == (sa.iters, sb.iters, sb.converged)
+            assert len(rb2) == len(rb) and np.allclose(rb2, rb, rtol=1e-8)
+            assert abs(sb2.onsager - sb.onsager) <= 1e-13 * abs(sb.onsager)
+            assert rel(mu_b2.download(), mu_b.download()) < 1e-12 and rel(wb2.download(), wb.download()) < 1e-10
+            if k == 0:      # capture only: nothing may change, bit for bit
+                assert np.array_equal(mu_b2.download(), mu_b.download()) and np.array_equal(mu_a2.download(), mu_a.download())
+                assert rel(atau.download(), sh.ATx(sh.Ax(u))) < 1e-12
+                assert (c1["n_ax"], c1["n_atx"]) == (c0["n_ax"], c0["n_atx"])
+            else:
+                assert (c1["n_ax"], c1["n_atx"]) == (c0["n_ax"] - 1, c0["n_atx"] - 1)
+                assert c1["n_ax_pass"] + c1["n_atx_pass"] <= c0["n_ax_pass"] + c0["n_atx_pass"]
+            dv.free()
+        # the same through the XXT joint solver
+        sh.compute_people_statistics()
+        npad = 4 * ((N + 3) // 4)
+        vn = np.zeros(npad)
+        vn[:N] = rng.standard_normal(N)
+        dvn, n1, n2, at1, at2, m1, m2 = sh.vecN(vn), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM(), sh.vecM(), sh.vecM()
+        (a1, _), (b1, r1) = sh.cg_solve_aat2(dvn, None, du, 2.0, 1.1, 30, n1, at1, m1)
+        sh.counters(reset=True)
+        (a2, _), (b2, r2) = sh.cg_solve_aat2(dvn, None, du, 2.0, 1.1, 30, n2, at2, m2, ata_v_b=atau, have_ata_v_b=True)
+        assert (a2.iters, b2.iters) == (a1.iters, b1.iters) and len(r2) == len(r1) and np.allclose(r2, r1, rtol=1e-8)
+        assert rel(m2.download(), m1.download()) < 1e-12 and rel(n2.download(), n1.download()) < 1e-12
+        fresh = sh.vecM()
+        (a3, _), (b3, _) = sh.cg_solve_aat2(dvn, None, du, 2.0, 1.1, 30, n2, at2, m2, ata_v_b=fresh)          # capture there too
+        assert rel(fresh.download(), atau.download()) < 1e-12
