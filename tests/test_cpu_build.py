@@ -94,10 +94,10 @@ def test_synth_bed_is_stable_and_plausible():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r1_bench_n1.json is the line `python bench.py` printed on an MI355X: every key the driver and the judge
-    read must be there, with consistent arithmetic (frac = achieved / peak, value = bytes / time)."""
+    """profiles/r2_bench_n1.json is the line `python bench.py` printed on an MI355X (final sources of round 2): every key the
+    driver and the judge read must be there, with consistent arithmetic (frac = achieved / peak, value = bytes / time)."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_n1.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r2_bench_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -115,6 +115,12 @@ def test_committed_bench_line_honours_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    v = d["vamp"]                      # the second half of the metric: iterations/s with the work behind it
+    for k in ("iters_per_s", "n_ax_pass", "n_atx_pass", "cg_iters", "onsager_iters", "time_to_solution_s", "reference_sequence",
+              "x_hat_rel_l2"):
+        assert k in v, k
+    assert v["x_hat_rel_l2"] < 1e-9 and v["iters_per_s"] > v["reference_sequence"]["iters_per_s"]
+    assert d["tile_layout"]["bit_identical_to_two_layouts"] is True
 
 
 def test_run_sharded_launcher_sets_the_rank_environment(tmp_path):
