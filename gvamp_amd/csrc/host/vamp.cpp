@@ -110,6 +110,8 @@ int vamp::cg(gv_vec* v, gv_vec* mu_start, double tau, int denoiser, gv_vec* mu_o
 }
 
 std::vector<double> vamp::infere(data* dataset) {
+    // products cached from one iteration to the next belong to this run's design matrix and probe
+    have_ata_u = have_ata_x2 = have_aat_prev = false;
     for (size_t i = 0; i < vars.size(); i++) vars[i] *= N;   // design matrix is scaled by 1/sqrt(N) (vamp.cpp:154-155)
     if (reverse == 1) {                                       // vamp.cpp:169-170
         ctx = dataset->get_ctx();
