@@ -41,10 +41,11 @@ def parse():
     ap.add_argument("--no-tile-leg", action="store_true", help="skip the closing measurement of the one-layout (tile) kernels")
     ap.add_argument("--layout", type=int, default=1, help="resident re-encoding of kernel mode 1: 1 = two stripe sets "
                     "(2 x M*N/4 bytes), 2 = one tile layout (M*N/4 bytes)")
-    ap.add_argument("--fuse-solves", type=int, default=3,
+    ap.add_argument("--fuse-solves", type=int, default=4,
                     help="0 = the reference's sequence of matvecs, 1 = LMMSE and Onsager CG share passes (bit-identical), "
                          "2 = also z1 rides in a free slot and A x2_hat / A^T A invQ u come out of the CG recurrences, "
-                         "3 = also the warm start's initial residual comes from the previous solve (no Ax + ATx for it)")
+                         "3 = also the warm start's initial residual comes from the previous solve (no Ax + ATx for it), "
+                         "4 = also the Onsager solve's first step comes from A^T A u of the probe, computed once")
     return ap.parse_args()
 
 

@@ -179,8 +179,8 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
             wm.a_mu_start_a = ax2_der;
         }
     }
-    if (fuse_solves >= 3 && CG_max_iter > 0) {
-        // the Onsager solve starts from zero on the same probe u every iteration: its first operator application is
+    if (fuse_solves >= 4 && CG_max_iter > 0) {
+        // --fuse-solves 4: the Onsager solve starts from zero on the same probe u every iteration: its first operator application is
         // (tau / diag) A^T A u + gam2 u / diag, with A^T A u captured the first time round -- the solve is one pass pair shorter
         if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
         wm.ata_v_b = ata_u;
@@ -519,7 +519,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 at_out = at_u;
                 wm.accumulate_at_mu_a = 1;
                 if (known_start) { wm.aat_mu_start_a = aat_der; wm.at_mu_start_a = at_u; }
-                if (CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
+                if (fuse_solves >= 4 && CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
                     if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
                     wm.ata_v_b = ata_u;
                     wm.have_ata_v_b = have_ata_u ? 1 : 0;

@@ -73,13 +73,13 @@ def pvals_row(N, M):
 
 def main():
     rows = [
-        vamp_row("config 2: linear N=100k x M=500k, CG-max-iter 50, fuse-solves 3", 100000, 500000, 5, fuse_solves=3),
-        vamp_row("one shard of the 8-GPU headline job on its own: N=400k x M=125k (no exchange), fuse-solves 3", 400000, 125000, 6,
-                 fuse_solves=3),
-        vamp_row("config 4: probit N=100k x M=500k, fuse-solves 3", 100000, 500000, 5, fuse_solves=3, model="bin_class",
+        vamp_row("config 2: linear N=100k x M=500k, CG-max-iter 50, fuse-solves 4", 100000, 500000, 5, fuse_solves=4),
+        vamp_row("one shard of the 8-GPU headline job on its own: N=400k x M=125k (no exchange), fuse-solves 4", 400000, 125000, 6,
+                 fuse_solves=4),
+        vamp_row("config 4: probit N=100k x M=500k, fuse-solves 4", 100000, 500000, 5, fuse_solves=4, model="bin_class",
                  gam1=1e-8, gamw=1.0),
-        vamp_row("config 5: --use-XXT-denoiser 1 (matrix-free N-space CG) N=50k x M=200k, fuse-solves 3", 50000, 200000, 4,
-                 use_XXT_denoiser=1, raw_rows=True, fuse_solves=3),
+        vamp_row("config 5: --use-XXT-denoiser 1 (matrix-free N-space CG) N=50k x M=200k, fuse-solves 4", 50000, 200000, 4,
+                 use_XXT_denoiser=1, raw_rows=True, fuse_solves=4),
         vamp_row("config 5 as the reference sequences it (fuse-solves 0)", 50000, 200000, 4, use_XXT_denoiser=1,
                  raw_rows=True, fuse_solves=0),
         pvals_row(400000, 1000000),

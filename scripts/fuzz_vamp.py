@@ -1,7 +1,7 @@
 """Randomised full VAMP runs against the oracle (development; run on a GPU box):   python scripts/fuzz_vamp.py [cases] [seed]
 Per case: a random small shard (N, M around tile / block boundaries), missing genotypes, a random prior (2-5 components),
 h2, rho, CG cap, 3-5 iterations; model linear / linear with --use-XXT-denoiser 1 / probit; kernel family (fp64 on raw rows, or
-fixed point on two stripe sets / the tile layout); --fuse-solves 0 / 1 / 2 / 3.  Against the oracle's run of the same
+fixed point on two stripe sets / the tile layout); --fuse-solves 0 ... 4.  Against the oracle's run of the same
 configuration: x_hat to the north-star tolerance 1e-5 (relative l2), per-iteration CG and Onsager step counts, prior after
 EM.  Between fuse levels and layouts of the product: fixed-point layouts bit-identical, fuse levels to 1e-9."""
 import os
@@ -49,7 +49,7 @@ def run_sharded(N, M, bed, cuts, layout, y, beta, probs, vars_, kw, extra, overl
                 sh.upload_bed(bed[S * mb:(S + Ms) * mb])
                 sh.comm_init_local(group, nr, rank)
                 sh.set_overlap(overlap)
-                out[rank] = hostapi.infere_linear(sh, y, probs, vars_, true_signal=beta[S:S + Ms], fuse_solves=2 + (group & 1), rank=rank,
+                out[rank] = hostapi.infere_linear(sh, y, probs, vars_, true_signal=beta[S:S + Ms], fuse_solves=2 + (group % 3), rank=rank,
                                                   **kw, **extra)
         except Exception as e:   # noqa: BLE001
             errors.append((rank, repr(e)))
@@ -110,7 +110,7 @@ def run_case(seed0, k):
             if y is None:
                 beta, yy = hostapi.sim_phen(sh, h2, CV, sseed)
                 y = (yy > 0).astype(float) if model == "probit" else yy
-            for fuse in ((0, 1, 2, 3) if mode == 1 and layout == 1 else (2, 3) if mode == 1 else (0,)):
+            for fuse in ((0, 1, 2, 3, 4) if mode == 1 and layout == 1 else (2, 4) if mode == 1 else (0,)):
                 runs[(mode, layout, fuse)] = hostapi.infere_linear(sh, y, probs, vars_, true_signal=beta, fuse_solves=fuse,
                                                                    **kw, **extra)
     ref = oracle.infere(bed, N, M, y, probs, vars_, true_signal=beta, **kw, **extra)
@@ -135,11 +135,11 @@ def run_case(seed0, k):
                  (o["cg_iters"], o["onsager_iters"], o["L_after"]))
             assert np.isclose(t["gamw"], o["gamw"], rtol=1e-5), ("gamw", key, it, info, t["gamw"], o["gamw"])
     assert np.array_equal(runs[(1, 1, 2)].x_est, runs[(1, 2, 2)].x_est), ("layouts differ", info)
-    assert np.array_equal(runs[(1, 1, 3)].x_est, runs[(1, 2, 3)].x_est), ("layouts differ at fuse 3", info)
-    for fuse in (1, 2, 3):
-        # levels 1 and 2 leave the Onsager solve bit-identical (alpha2 to the last bit); level 3 takes its first operator
+    assert np.array_equal(runs[(1, 1, 4)].x_est, runs[(1, 2, 4)].x_est), ("layouts differ at fuse 4", info)
+    for fuse in (1, 2, 3, 4):
+        # levels 1 to 3 leave the Onsager solve bit-identical (alpha2 to the last bit); level 4 takes its first operator
         # application from A^T A u of the probe, a rounding-level change of alpha2 that the run amplifies as above
-        tol_f = 1e-8 if fuse < 3 else max(1e-8, 1e-15 * amp)
+        tol_f = 1e-8 if fuse < 4 else max(1e-8, 1e-15 * amp)
         e = rel(runs[(1, 1, fuse)].x_est, base.x_est)
         assert e < tol_f, ("fuse level", fuse, info, e, tol_f)
     if rng.random() < 0.5:     # marker shards as divide_work cuts them (the Onsager probe is seeded per shard: utilities.cpp:259-291)

@@ -85,7 +85,7 @@ WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode,fuse", [(1, 2), (1, 3), (1, 0), (0, 1)])
+@pytest.mark.parametrize("mode,fuse", [(1, 2), (1, 4), (1, 0), (0, 1)])
 def test_two_processes_one_gpu_over_gloo_vs_real_reference_np2(tmp_path, oracle, mode, fuse):
     """Product code, two processes, gloo transport: compared with what the REAL reference wrote at mpirun -np 2 (survey
     probe) and with the oracle's 2-shard run."""

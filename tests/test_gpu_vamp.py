@@ -153,7 +153,7 @@ def test_unknown_flag_and_missing_bed_are_fatal():
     assert r.returncode != 0 and "no bed file" in r.stdout
 
 
-@pytest.mark.parametrize("nshards,mode,fuse", [(2, 1, 1), (8, 1, 1), (2, 0, 1), (2, 1, 2), (8, 1, 2), (4, 1, 0), (2, 1, 3), (8, 1, 3)])
+@pytest.mark.parametrize("nshards,mode,fuse", [(2, 1, 1), (8, 1, 1), (2, 0, 1), (2, 1, 2), (8, 1, 2), (4, 1, 0), (2, 1, 3), (8, 1, 4)])
 def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode, fuse):
     """Marker-sharded VAMP exactly as the reference shards over MPI ranks (divide_work, one N-vector all-reduce per
     Ax, Hutchinson probe seeded seed + S): `nshards` contexts on this GPU joined by the in-process communicator,
@@ -251,7 +251,7 @@ def test_unbuilt_variants_are_refused_loudly(tmp_path):
     assert r.returncode != 0 and "--red" in r.stdout and "not built" in r.stdout
 
 
-@pytest.mark.parametrize("fuse", [1, 2, 3])
+@pytest.mark.parametrize("fuse", [1, 2, 3, 4])
 def test_long_run_stays_on_the_oracle(oracle, fuse):
     """20 iterations (the tests above stop at 3-6): the product must not drift away from the oracle over a long run --
     in particular the CG by-products of --fuse-solves 2, which replace explicit products by recurrences."""
