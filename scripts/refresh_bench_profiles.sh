@@ -8,6 +8,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench -- py
 cp $O/stats2/bench_kernel_stats.csv $O/r2_bench_fullrun_kernel_stats.csv 2>/dev/null || cp $(ls $O/stats2/*/*kernel_stats.csv | head -1) $O/r2_bench_fullrun_kernel_stats.csv
 rm -rf $O/stats $O/stats2 $O/tune_cache
 ls -la $O; head -c 600 $O/r2_bench_n1.json
-python3 scripts/bench_rows.py > $O/r2_rows.json 2>$O/rows.err
-GV_LAYOUT=2 python3 scripts/bench_rows.py > $O/r2_rows_tile.json 2>$O/rows_tile.err
 ls -la $O
