@@ -373,6 +373,17 @@ def main():
                 dist.all_reduce(tt)
                 num, den = float(tt[0]), float(tt[1])
             out["vamp"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
+            if a.fuse_solves >= 4:
+                # level 4 is the only level that touches alpha2: the level below it, which is what the
+                # drivers default to, measured beside it with its own distance from the reference sequence
+                r3, v3 = vamp_leg(3)
+                num3 = float(np.linalg.norm(r3.x_est - r0.x_est)) ** 2
+                if world > 1:
+                    tt = torch.tensor([num3], dtype=torch.float64)
+                    dist.all_reduce(tt)
+                    num3 = float(tt[0])
+                out["vamp"]["level_3"] = {k: v3[k] for k in ("iters_per_s", "seconds_per_iter", "n_ax_pass", "n_atx_pass")}
+                out["vamp"]["level_3"]["x_hat_rel_l2"] = float(np.sqrt(num3 / den)) if den > 0 else None
     # ---- a harder setting beside it: block-correlated genotypes (LD), where the CG of the LMMSE step runs tens of steps -------
     if a.vamp_iterations > 0 and a.ld_block > 0:
         from gvamp_amd import hostapi
