@@ -156,3 +156,34 @@ def test_bench_never_downgrades_the_gpu_count():
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
         r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
         assert r.returncode == 3 and "GPU" in r.stderr and not r.stdout.strip()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """the by-value / by-pointer structs of include/gvamp.h as ctypes declares them (gvamp_amd/capi.py): same sizes and field
+    offsets as the C compiler gives them -- a field added to the header and forgotten in the binding shows up here, without a GPU"""
+    import ctypes as C
+    import subprocess
+    from gvamp_amd import capi
+    src = tmp_path / "sizes.c"
+    src.write_text("""
+#include <stddef.h>
+#include <stdio.h>
+#include "gvamp.h"
+int main(void) {
+    printf("gv_cg_stats %zu %zu %zu\\n", sizeof(gv_cg_stats), offsetof(gv_cg_stats, rel_res), offsetof(gv_cg_stats, n_relres));
+    printf("gv_cg_extras %zu %zu %zu\\n", sizeof(gv_cg_extras), offsetof(gv_cg_extras, a_mu_a), offsetof(gv_cg_extras, ata_mu_b));
+    printf("gv_cg_warm %zu %zu %zu\\n", sizeof(gv_cg_warm), offsetof(gv_cg_warm, ata_v_b), offsetof(gv_cg_warm, have_ata_v_b));
+    printf("gv_aat_warm %zu %zu %zu\\n", sizeof(gv_aat_warm), offsetof(gv_aat_warm, accumulate_at_mu_a), offsetof(gv_aat_warm, have_ata_v_b));
+    return 0;
+}
+""")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = {l.split()[0]: tuple(int(x) for x in l.split()[1:]) for l in subprocess.check_output([str(exe)], text=True).splitlines()}
+    want = {
+        "gv_cg_stats": (C.sizeof(capi.CgStats), capi.CgStats.rel_res.offset, capi.CgStats.n_relres.offset),
+        "gv_cg_extras": (C.sizeof(capi.CgExtras), capi.CgExtras.a_mu_a.offset, capi.CgExtras.ata_mu_b.offset),
+        "gv_cg_warm": (C.sizeof(capi.CgWarm), capi.CgWarm.ata_v_b.offset, capi.CgWarm.have_ata_v_b.offset),
+        "gv_aat_warm": (C.sizeof(capi.AatWarm), capi.AatWarm.accumulate_at_mu_a.offset, capi.AatWarm.have_ata_v_b.offset),
+    }
+    assert got == want
