@@ -9,8 +9,7 @@ run() {  # name N M iters fuse xxt
   python3 scripts/trace_gaps.py $f -60 > $O/$1_gaps.txt 2>&1
   cp $f $O/$1_kernel_trace.csv; rm -rf $O/$1
 }
-run cfg5 50000 200000 5 2 1
-run shard125k 400000 125000 5 2 0
-run cfg2 100000 500000 5 2 0
-python3 scripts/bench_rows.py > $O/rows.json 2>$O/rows.err
+run cfg5 50000 200000 5 4 1
+run shard125k 400000 125000 5 4 0
+run cfg2 100000 500000 5 4 0
 ls -la $O
