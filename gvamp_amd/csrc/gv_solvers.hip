@@ -844,6 +844,14 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                              tau != 0.0),
          "gv_cg_solve_aat2w: ata_v_b is M-space, must not alias the systems' vectors, and needs tau != 0");
     NEED(c, !wm->have_ata_v_b || wm->ata_v_b, "gv_cg_solve_aat2w: have_ata_v_b without ata_v_b");
+    NEED(c, (wm->pre_x == nullptr) == (wm->pre_out == nullptr) && (wm->ride_x == nullptr) == (wm->ride_out == nullptr),
+         "gv_cg_solve_aat2w: pre_x / pre_out and ride_x / ride_out go together");
+    NEED(c, !wm->pre_x || (wm->pre_x->space == GV_SPACE_M && wm->pre_out->space == GV_SPACE_N && wm->pre_out != v_a &&
+                           wm->pre_out != mu_a && wm->pre_out != aat_mu_a),
+         "gv_cg_solve_aat2w: pre_x is M-space, pre_out N-space and neither v_a, mu_a nor aat_mu_a");
+    NEED(c, !wm->ride_x || (wm->ride_x->space == GV_SPACE_M && wm->ride_out->space == GV_SPACE_N && wm->ride_out != v_a &&
+                            wm->ride_out != mu_a && wm->ride_out != aat_mu_a && wm->ride_out != wm->pre_out),
+         "gv_cg_solve_aat2w: ride_x is M-space, ride_out N-space and none of the solver's N-space vectors");
     double* const at_acc = wm->accumulate_at_mu_a ? at_mu_a->d : nullptr;
     NEED(c, v_a->space == GV_SPACE_N && mu_a->space == GV_SPACE_N && (!mu_start_a || mu_start_a->space == GV_SPACE_N),
          "gv_cg_solve_aat2: system a lives in N-space");
@@ -933,27 +941,38 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 gvk::fill(s, at_acc, M, 0.0);
             // (explicit warm start: the first half of its opening application is A^T mu0 -- copied when it arrives, below)
         }
-        if (mu_start_a && aat_mu_start_a) {
-            // r = v - (tau A A^T mu0 + gam2 mu0) from the product the previous solve left (Q' mu0 = v' - r'): no pass
-            MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            gvk::axpby(s, r, 1.0, v_a->d, -tau, aat_mu_start_a->d, n);
-            gvk::axpby(s, r, 1.0, r, -gam2, mu_start_a->d, n);
-            MIX_TRY(a_init_scalars());
-            if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
-            a_phase = 1;
-            if (max_iter > 0) a_post(p, d); else a_finish();
-        } else if (mu_start_a) {
-            MIX_HIP(hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            a_phase = 0;
-            a_post(mu, r);
-        } else {
-            gvk::fill(s, mu, n, 0.0);
-            MIX_HIP(hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-            MIX_TRY(a_init_scalars());
-            if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
-            a_phase = 1;
-            if (max_iter > 0) a_post(p, d); else a_finish();
-        }
+        // solve a starts here -- at once, or (gv_aat_warm.pre_x) when the pass that completes its right-hand side has come back
+        auto a_start = [&]() -> int {
+            if (mu_start_a && aat_mu_start_a) {
+                // r = v - (tau A A^T mu0 + gam2 mu0) from the product the previous solve left (Q' mu0 = v' - r'): no pass
+                if (hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                gvk::axpby(s, r, 1.0, v_a->d, -tau, aat_mu_start_a->d, n);
+                gvk::axpby(s, r, 1.0, r, -gam2, mu_start_a->d, n);
+                if (a_init_scalars()) return 1;
+                if (dev && cgx_upload_state(c, 0, a_rz, a_vn2, 1, true)) return 1;
+                a_phase = 1;
+                if (max_iter > 0) a_post(p, d); else a_finish();
+            } else if (mu_start_a) {
+                if (hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                a_phase = 0;
+                a_post(mu, r);
+            } else {
+                gvk::fill(s, mu, n, 0.0);
+                if (hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                if (a_init_scalars()) return 1;
+                if (dev && cgx_upload_state(c, 0, a_rz, a_vn2, 1, true)) return 1;
+                a_phase = 1;
+                if (max_iter > 0) a_post(p, d); else a_finish();
+            }
+            return 0;
+        };
+        // gv_aat_warm.pre_x: v_a <- v_a - A pre_x first (v_a = y - A r2 of denoiserXXT.cpp:40-42, the A r2 taken in the pass
+        // that also carries the first half-application of solve b, so that the two solves run in phase from the start);
+        // gv_aat_warm.ride_x: ride_out = A ride_x (z1 = A x1_hat of vamp.cpp:429) in whatever Ax pass has a slot free
+        HalfOp hr, hz;
+        if (wm->pre_x) { hr.pending = true; hr.first = 0; hr.one_half = true; hr.src = wm->pre_x->d; hr.dst = wm->pre_out->d; }
+        else if (a_start()) { rc = fail(c, "gv_cg_solve_aat2w: starting solve a failed"); goto done; }
+        if (wm->ride_x) { hz.pending = true; hz.first = 0; hz.one_half = true; hz.src = wm->ride_x->d; hz.dst = wm->ride_out->d; }
         auto b_post = [&]() {
             hb.pending = sb.active;
             hb.stage = 0; hb.one_half = false; hb.src = sb.req; hb.mid = c->w_n->d; hb.dst = sb.res;
@@ -963,12 +982,12 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         for (;;) {
             HalfOp* todo[2];
             int nt = 0;
-            if (ha.pending && hb.pending) {
-                if (ha.kind() == hb.kind()) { todo[nt++] = &ha; todo[nt++] = &hb; }
-                else todo[nt++] = &ha;             // out of phase: one single pass puts them in phase
-            } else if (ha.pending) todo[nt++] = &ha;
-            else if (hb.pending) todo[nt++] = &hb;
-            else break;
+            // up to two pending half-applications of the same kind share a pass.  Priority: the right-hand side of solve a,
+            // solve a, solve b, the rider (which only ever fills a slot that would have stayed empty, or closes the call)
+            HalfOp* cand[4] = {&hr, &ha, &hb, &hz};
+            for (HalfOp* h : cand)
+                if (h->pending && (nt == 0 || (nt == 1 && h->kind() == todo[0]->kind()))) todo[nt++] = h;
+            if (nt == 0) break;
             // system b's second half is the ATx of lmmse_mult: its tau * . + gam2 * req epilogue is fused as in gv_cg_solve
             auto addx = [&](const HalfOp* h) -> const double* { return (h == &hb && h->stage == 1) ? sb.req : nullptr; };
             // device scalars: system b's slot of the pass advances its search direction on the way in (Ax half) and leaves
@@ -999,6 +1018,12 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                     continue;
                 }
                 h->pending = false;
+                if (h == &hz) continue;                                            // the rider's product is in place
+                if (h == &hr) {                                                    // v_a = y - A r2 is complete: solve a can start
+                    gvk::axpby(s, const_cast<double*>(v_a->d), 1.0, v_a->d, -1.0, hr.dst, n);
+                    MIX_TRY(a_start());
+                    continue;
+                }
                 if (h == &hb) {                                                    // Q_B req complete (epilogue fused above)
                     sb.wslot = c->w_n->d;
                     if (sb.iters == 0) cg_capture_first_product(c, sb, tau, gam2, diag_b);   // its first application: A^T A v_b

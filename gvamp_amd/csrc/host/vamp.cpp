@@ -491,14 +491,22 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             // (gamw A A^T + gam2 I) u = y - A r2 ; x2 = r2 + gamw A^T u ; alpha2 from (gamw A^T A + gam2 I) w = probe
             if (!mu_CG_last_N) ck(gv_vec_alloc(ctx, GV_SPACE_N, &mu_CG_last_N), "gv_vec_alloc");
             if (!ax2_der) ck(gv_vec_alloc(ctx, GV_SPACE_N, &ax2_der), "gv_vec_alloc");
-            ck(gv_ax2_dev(ctx, x1_hat, r2, z1, ax2_der), "gv_ax2_dev");   // z1 = A x1_hat (:429) and A r2, one pass
-            {
+            // level 4: A r2 and z1 are taken inside the joint solve (gv_aat_warm.pre_x / ride_x) -- A r2 in the pass that carries
+            // the first half-application of the Onsager solve, so that the two solves run in phase, z1 in a free slot
+            const bool inside = fuse_solves >= 4;
+            auto z1_outputs = [&]() {
                 double tz = now_s();
                 z1_outputs_a();
                 t_io += now_s() - tz;
                 z1_outputs_b();
+            };
+            if (inside)
+                ck(gv_vec_copy(ctx, tN, y), "gv_vec_copy");                // the solver turns it into y - A r2
+            else {
+                ck(gv_ax2_dev(ctx, x1_hat, r2, z1, ax2_der), "gv_ax2_dev");   // z1 = A x1_hat (:429) and A r2, one pass
+                z1_outputs();
+                ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, ax2_der), "gv_vec_axpby");
             }
-            ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, ax2_der), "gv_vec_axpby");
             draw_onsager_probe(dataset);
             have_derived = fuse_solves >= 2;
             if (have_derived) {
@@ -519,6 +527,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 at_out = at_u;
                 wm.accumulate_at_mu_a = 1;
                 if (known_start) { wm.aat_mu_start_a = aat_der; wm.at_mu_start_a = at_u; }
+                if (inside) { wm.pre_x = r2; wm.pre_out = ax2_der; wm.ride_x = x1_hat; wm.ride_out = z1; }
                 if (fuse_solves >= 4 && CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
                     if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
                     wm.ata_v_b = ata_u;
@@ -530,6 +539,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                                  have_derived ? ata_der : nullptr, &wm), "gv_cg_solve_aat2w");
             have_aat_prev = have_derived;
             if (wm.ata_v_b) have_ata_u = true;
+            if (inside) z1_outputs();
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
             if (verbose && rank == 0) {

@@ -235,6 +235,15 @@ typedef struct gv_aat_warm {
     int accumulate_at_mu_a;
     gv_vec* ata_v_b;            /* as in gv_cg_warm: A^T A v_b of the zero-started M-space solve b, captured or handed in */
     int have_ata_v_b;
+    /* pre_x / pre_out: the right-hand side of solve a is completed inside the call -- pre_out = A pre_x, then v_a <- v_a - pre_out
+     * (v_a is UPDATED IN PLACE although the prototype says const): v = y - A r2 of denoiserXXT.cpp:40-42 with v_a = y, pre_x = r2.
+     * That Ax shares its pass with the first half-application of solve b, which puts the two solves in phase from the start
+     * (one pass fewer than forming v_a outside).  ride_x / ride_out: ride_out = A ride_x for an M-vector unrelated to the solves
+     * (z1 = A x1_hat, vamp.cpp:429), taken in an Ax pass that has a slot free, else by a pass of its own at the end. */
+    const gv_vec* pre_x;
+    gv_vec* pre_out;
+    const gv_vec* ride_x;
+    gv_vec* ride_out;
 } gv_aat_warm;
 int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,

@@ -227,3 +227,53 @@ def test_zero_started_solve_with_the_product_of_its_right_hand_side(layout):
         fresh = sh.vecM()
         (a3, _), (b3, _) = sh.cg_solve_aat2(dvn, None, du, 2.0, 1.1, 30, n2, at2, m2, ata_v_b=fresh)          # capture there too
         assert rel(fresh.download(), atau.download()) < 1e-12
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_xxt_joint_solver_completes_its_right_hand_side_and_carries_a_rider(layout):
+    """gv_aat_warm.pre_x / ride_x: v_a = y - A r2 formed inside the call (the A r2 in the pass of solve b's first half-application)
+    and z1 = A x1_hat in a free slot -- every output bit-identical to forming them outside, in fewer passes"""
+    N, M = 1400, 1100
+    rng = np.random.default_rng(23)
+    bed = synth.synth_bed(N, M, seed=13, miss_ppm=5000)
+    npad = 4 * ((N + 3) // 4)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    yv = np.zeros(npad)
+    yv[:N] = rng.standard_normal(N)
+    r2, x1 = rng.standard_normal(M) * 0.05, rng.standard_normal(M) * 0.05
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(True, layout)
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        sh.compute_people_statistics()
+        sh.set_kernel_mode(1)
+        sh.compute_markers_statistics()
+        du, dr2, dx1, dy = sh.vecM(u), sh.vecM(r2), sh.vecM(x1), sh.vecN(yv)
+        # outside: one two-vector Ax for z1 and A r2, then the joint solve
+        z1_e, ar2_e, v_e = sh.vecN(), sh.vecN(), sh.vecN()
+        n_e, at_e, m_e = sh.vecN(), sh.vecM(), sh.vecM()
+        sh.counters(reset=True)
+        sh.ax2_dev(dx1, dr2, z1_e, ar2_e)
+        v_e.upload(yv - ar2_e.download())
+        (ae, rae), (be, rbe) = sh.cg_solve_aat2(v_e, None, du, 2.0, 1.1, 30, n_e, at_e, m_e)
+        ce = sh.counters()
+        # inside
+        z1_w, ar2_w, v_w = sh.vecN(), sh.vecN(), sh.vecN(yv)
+        n_w, at_w, m_w = sh.vecN(), sh.vecM(), sh.vecM()
+        sh.counters(reset=True)
+        (aw, raw), (bw, rbw) = sh.cg_solve_aat2(v_w, None, du, 2.0, 1.1, 30, n_w, at_w, m_w, pre_x=dr2, pre_out=ar2_w, ride_x=dx1,
+                                                ride_out=z1_w)
+        cw = sh.counters()
+        assert (aw.iters, bw.iters) == (ae.iters, be.iters)
+        assert np.array_equal(raw, rae) and np.array_equal(rbw, rbe)
+        for a, b in ((z1_w, z1_e), (ar2_w, ar2_e), (n_w, n_e), (at_w, at_e), (m_w, m_e)):
+            assert np.array_equal(a.download(), b.download())
+        assert np.array_equal(v_w.download(), yv - ar2_e.download())          # v_a was completed in place
+        assert (cw["n_ax"], cw["n_atx"]) == (ce["n_ax"], ce["n_atx"])            # the same products ...
+        assert cw["n_ax_pass"] + cw["n_atx_pass"] <= ce["n_ax_pass"] + ce["n_atx_pass"]     # ... in no more passes
+        # with a solve b that does not run at all the two extra products still come out (they share one pass)
+        z1_0, ar2_0, v_0 = sh.vecN(), sh.vecN(), sh.vecN(yv)
+        sh.cg_solve_aat2(v_0, None, du, 2.0, 1.1, 0, n_w, at_w, m_w, pre_x=dr2, pre_out=ar2_0, ride_x=dx1, ride_out=z1_0)
+        assert np.array_equal(z1_0.download(), z1_e.download()) and np.array_equal(ar2_0.download(), ar2_e.download())
+        with pytest.raises(capi.GvError):
+            sh.cg_solve_aat2(v_0, None, du, 2.0, 1.1, 5, n_w, at_w, m_w, pre_x=dr2)          # pre_x without pre_out
