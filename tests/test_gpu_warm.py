@@ -277,3 +277,32 @@ def test_xxt_joint_solver_completes_its_right_hand_side_and_carries_a_rider(layo
         assert np.array_equal(z1_0.download(), z1_e.download()) and np.array_equal(ar2_0.download(), ar2_e.download())
         with pytest.raises(capi.GvError):
             sh.cg_solve_aat2(v_0, None, du, 2.0, 1.1, 5, n_w, at_w, m_w, pre_x=dr2)          # pre_x without pre_out
+
+
+@pytest.mark.parametrize("xxt", [0, 1])
+@pytest.mark.parametrize("variant", ["fp64 kernels", "host-driven CG"])
+def test_level_4_on_the_other_code_paths(oracle, monkeypatch, variant, xxt):
+    """the identities of levels 3 / 4 do not depend on the fixed-point family or on the device-resident loop: the same runs through
+    the fp64 VALU kernels (kernel mode 0: host-driven CG, raw rows) and through GV_CG_DEVICE=0 must follow level 0 and the oracle"""
+    N, M = 1200, 1700
+    bed = synth.synth_bed(N, M, seed=52, miss_ppm=5000)
+    beta, y = oracle.sim_phen(bed, N, M, 0.5, 90, 6)
+    probs, vars_ = [0.9, 0.07, 0.03], [0, 1e-3, 1e-2]
+    kw = dict(iterations=5, CG_max_iter=40, rho=0.5, seed=6, true_signal=beta, history=False)
+    if xxt:
+        kw["use_XXT_denoiser"] = 1
+    ref = oracle.infere(bed, N, M, y, probs, vars_, **{k: v for k, v in kw.items() if k != "history"})
+    if variant == "host-driven CG":
+        monkeypatch.setenv("GV_CG_DEVICE", "0")
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_kernel_mode(0 if variant == "fp64 kernels" else 1)
+        sh.compute_markers_statistics()
+        r0 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=0, **kw)
+        r4 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=4, **kw)
+    assert r4.niter == r0.niter == ref.niter
+    for a, b, o in zip(r0.trace, r4.trace, ref.trace):
+        assert (b["cg_iters"], b["onsager_iters"], b["L_after"]) == (a["cg_iters"], a["onsager_iters"], a["L_after"])
+        assert b["cg_iters"] == int(o["cg_iters"])
+    assert sum(t["n_ax"] + t["n_atx"] for t in r4.trace) < sum(t["n_ax"] + t["n_atx"] for t in r0.trace)
+    assert rel(r4.x_est, r0.x_est) < 1e-8 and rel(r4.x_est, ref.x_est) < 1e-7
