@@ -26,15 +26,15 @@
     X(unsigned int, store_pvals, 0)                                                                                   \
     /* [ext] --device (default: LOCAL_RANK or 0), --kernel-mode 0|1 (default 1: i8 MFMA), --synth-seed S (on-device   \
        synthetic .bed when there is no --bed-file), --synth-miss-ppm, --diagnostics 1 (the 3 print-only Ax of         \
-       vamp.cpp:646-681), --store-iterates 0 (skip the per-iteration .bin/.csv dumps), --fuse-solves (default 3): 0 the reference\
+       vamp.cpp:646-681), --store-iterates 0 (skip the per-iteration .bin/.csv dumps), --fuse-solves (default 4): 0 the reference\
        sequence; 1 the LMMSE and Onsager CG solves share their passes (bit-identical); 2 also z1 = A x1_hat rides in  \
        a free slot and A x2_hat, A^T A invQ u come out of the CG recurrences (rounding-level); 3 also the warm start's \
        initial residual comes from the previous solve's final residual (no pass); 4 also the Onsager solve's first  \
-       step comes from A^T A u of the probe, computed once (alpha2 changes at rounding level); --resident-layout 1|2|3: \
+       step comes from A^T A u of the probe, computed once (rounding-level, like 2 and 3); --resident-layout 1|2|3:    \
        kernel mode 1 keeps two stripe sets (2 x M N / 4 bytes) or one tile layout (M N / 4 bytes) in HBM, same bits; \
        3 (default) = two stripe sets if they fit the free HBM, else the tile layout */                                         \
     X(int, device, -1) X(int, kernel_mode, 1) X(long, synth_seed, -1) X(unsigned int, synth_miss_ppm, 5000)          \
-    X(int, diagnostics, 0) X(int, store_iterates, 1) X(int, fuse_solves, 3) X(int, resident_layout, 3)
+    X(int, diagnostics, 0) X(int, store_iterates, 1) X(int, fuse_solves, 4) X(int, resident_layout, 3)
 
 class Options {
 public:

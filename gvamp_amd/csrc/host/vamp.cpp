@@ -141,6 +141,15 @@ void vamp::draw_onsager_probe(data* dataset) {
     ck(gv_vec_upload(ctx, bern_vec, u.data()), "gv_vec_upload");
 }
 
+// A^T A u was captured as (diag / tau) d - (gam2 / tau) u from the first operator application of an Onsager solve: a difference
+// that loses log10(gam2 / (tau |A^T A u|)) digits.  It is kept for the following iterations only if that loss is below three
+// digits; otherwise the next solve captures it again.  (At the usual start, gam1 = 1e-8, gam2 / tau of the first iteration is in the
+// thousands: a product kept from there left x_hat 4e-13 from the reference sequence instead of 5e-15.)
+bool vamp::probe_product_is_usable(double tau, double gam2_) {
+    const double nrm = sqrt(dotM(ata_u, ata_u));         // |u| = 1
+    return std::isfinite(nrm) && gam2_ <= 1e3 * tau * nrm;
+}
+
 double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
     draw_onsager_probe(dataset);
     cg(bern_vec, nullptr, tau, 0, invQ_bern_vec, iters);
@@ -189,7 +198,7 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
     ck(gv_cg_solve2w(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
                      &ex, &wm), "gv_cg_solve2w");
     have_ata_x2 = wm.ata_mu_a != nullptr;
-    if (wm.ata_v_b) have_ata_u = true;
+    if (wm.ata_v_b && !have_ata_u) have_ata_u = probe_product_is_usable(tau, gam2);
     if (verbose && rank == 0) {
         for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
         for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
@@ -538,7 +547,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                                  invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
                                  have_derived ? ata_der : nullptr, &wm), "gv_cg_solve_aat2w");
             have_aat_prev = have_derived;
-            if (wm.ata_v_b) have_ata_u = true;
+            if (wm.ata_v_b && !have_ata_u) have_ata_u = probe_product_is_usable(gamw, gam2);
             if (inside) z1_outputs();
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;

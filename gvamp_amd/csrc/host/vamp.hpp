@@ -76,7 +76,8 @@ public:
     std::vector<double> infere_linear(data* dataset);    // vamp.cpp:190-803
     std::vector<double> infere_bin_class(data* dataset); // vamp_probit.cpp:20-658
     double g2d_onsager(double gam2, double tau, data* dataset, int* iters);   // vamp.cpp:871-889
-    void draw_onsager_probe(data* dataset);                                   // vamp.cpp:875-882 (host RNG)
+    void draw_onsager_probe(data* dataset);
+    bool probe_product_is_usable(double tau, double gam2);                    // level 4: is the captured A^T A u accurate enough to keep?                                   // vamp.cpp:875-882 (host RNG)
     // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2
     double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
                         gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);

@@ -170,7 +170,10 @@ def test_vamp_runs_at_fuse_3_and_4_follow_fuse_2_and_the_oracle(oracle, xxt, lev
         # and from the second iteration on the Onsager solve takes its first application from A^T A u of the probe: two more)
         fewer = (2 if i > 0 else 0) + (1 if xxt else 0) + (2 if level >= 4 and i > 0 else 0)
         assert passes2 - fewer <= passes3 <= passes2, (i, passes2, passes3)
-        assert b["n_ax"] + b["n_atx"] == a["n_ax"] + a["n_atx"] - fewer, i
+        # (level 4 keeps A^T A u from the first iteration whose gam2 / tau lets it be captured without cancellation: the first or
+        # the second -- so the second iteration may still apply the operator for the Onsager solve's first step)
+        ok = {fewer, fewer - 2} if (level >= 4 and i == 1) else {fewer}
+        assert a["n_ax"] + a["n_atx"] - (b["n_ax"] + b["n_atx"]) in ok, (i, fewer)
     saved = sum(a["n_ax_pass"] + a["n_atx_pass"] - b["n_ax_pass"] - b["n_atx_pass"] for a, b in zip(r2.trace, r3.trace))
     assert saved >= (1 if (level >= 4 or not xxt) else 0), saved
     assert rel(r3.x_est, r2.x_est) < 1e-9
