@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--ld-block", type=int, default=64, help="second VAMP setting: markers per LD block (0 = skip that leg)")
     ap.add_argument("--ld-ppm", type=int, default=900000, help="second VAMP setting: within-block copy probability, 1e-6")
     ap.add_argument("--no-tile-leg", action="store_true", help="skip the closing measurement of the one-layout (tile) kernels")
-    ap.add_argument("--layout", type=int, default=1, help="resident re-encoding of kernel mode 1: 1 = two stripe sets "
+    ap.add_argument("--layout", type=int, default=0, help="resident re-encoding of kernel mode 1: 0 = leave the library's default "
+                    "(auto: two stripe sets when they fit the free HBM, else the tile layout), 1 = two stripe sets "
                     "(2 x M*N/4 bytes), 2 = one tile layout (M*N/4 bytes)")
     ap.add_argument("--fuse-solves", type=int, default=4,
                     help="0 = the reference's sequence of matvecs, 1 = LMMSE and Onsager CG share passes (bit-identical), "
@@ -203,16 +204,21 @@ def main():
     N, Mt = a.N, a.Mt
     M, S = divide_work(Mt, world, rank)
     sh = capi.Shard(N, M, Mt=Mt, S=S, device=local_rank)
-    if a.mode == 1:
+    # The default run configures NOTHING: what is measured is what a binding that only calls gv_create / gv_set_dims /
+    # gv_upload_bed / gv_ax / gv_atx gets -- kernel mode 1, no raw rows, layout picked at ingest.
+    engine_defaults = a.mode == 1 and a.layout == 0
+    if a.mode == 1 and a.layout != 0:
         sh.set_layout(False, a.layout)     # no raw rows resident: 2 x M*N/4 bytes (two stripe sets) or M*N/4 (tile layout)
-    else:
+    elif a.mode == 0:
         sh.set_layout(True, False)
-    sh.set_kernel_mode(a.mode)
+        sh.set_kernel_mode(0)
+    assert sh.get_kernel_mode() == a.mode
     t0 = time.time()
     sh.synth_bed(a.seed, 5000)
     sh.compute_markers_statistics()
     t_ingest = time.time() - t0
     t_alloc, t_fill = sh.ingest_info()      # hipMalloc of the resident layouts (driver: page mapping / wipe) vs generating them
+    layout = sh.get_layout()                # 1 two stripe sets, 2 tile layout, 0 none (kernel mode 0)
     if world > 1 or force_dist:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -250,6 +256,21 @@ def main():
     cnt = sh.counters()
     sh.set_timing(0)
     d_host = d.download()            # (after the timed region) the operator's output, compared with the tile-layout leg below
+    # PCIe-inclusive rate through the host-pointer entry points gv_ax / gv_atx (data::Ax / data::ATx as the reference's vamp.cpp
+    # calls them: the M- or N-vector crosses PCIe each way).  Outside the timed region; never `value`.
+    hx = np.ascontiguousarray(rng_p)
+    hp = np.zeros(4 * ((N + 3) // 4))
+    hp[:N] = np.random.default_rng(8).standard_normal(N)
+    sh.Ax(hx); sh.ATx(hp)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        sh.Ax(hx)
+    t_hax = (time.perf_counter() - t1) / 5
+    t1 = time.perf_counter()
+    for _ in range(5):
+        sh.ATx(hp)
+    t_hatx = (time.perf_counter() - t1) / 5
+    sh.counters(reset=True)
 
     job_bytes = 2 * alg_bytes(N, Mt)
     value = job_bytes * a.steps / dt / 1e9
@@ -260,7 +281,7 @@ def main():
     ax_gbps = shard_bytes / (ms_ax * 1e-3) / 1e9 if ms_ax > 0 else 0.0
     atx_gbps = shard_bytes / (ms_atx * 1e-3) / 1e9 if ms_atx > 0 else 0.0
     dec = sh.decomp()
-    if a.mode == 1 and a.layout == 2:     # template arguments: <DIR, MODE, balanced decomposition, device-CG instantiation>
+    if a.mode == 1 and layout == 2:     # template arguments: <DIR, MODE, balanced decomposition, device-CG instantiation>
         kname = "k_mfma_tile<1, 3, %s, false> (Ax)" % ("true" if "balanced_cells" in dec["ax"] else "false")
     elif a.mode == 1:                     # <MODE, balanced decomposition, device-CG instantiation>
         kname = "k_mfma_matvec<1, %s, false> (Ax)" % ("true" if "balanced_cells" in dec["ax"] else "false")
@@ -289,8 +310,10 @@ def main():
         "config": {"workload": "N=%d x Mt=%d 2-bit genotype matrix, step = lmmse_mult = Ax + N-vector all-reduce + ATx "
                                "(vamp.cpp:1074-1118)" % (N, Mt),
                    "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
-                   "resident_layout": ("fp64 raw rows" if a.mode == 0 else "two stripe sets, 2 x M*N/4 bytes" if a.layout == 1
+                   "resident_layout": ("fp64 raw rows" if a.mode == 0 else "two stripe sets, 2 x M*N/4 bytes" if layout == 1
                                        else "one tile layout, M*N/4 bytes"),
+                   "engine": ("library defaults (no gv_set_kernel_mode / gv_set_layout call)" if engine_defaults
+                              else "--mode %d --layout %d" % (a.mode, a.layout)),
                    "ingest_s": round(t_ingest, 2), "ingest_alloc_s": round(t_alloc, 2), "ingest_fill_s": round(t_fill, 2),
                    "tune_s": round(tune_s, 3), "tune_source": tune_src},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
@@ -302,6 +325,11 @@ def main():
                      "copy_GBps_read_plus_write": round(sh.copy_bandwidth(1 << 30, 10), 1)},
         "kernels": {"ax": {"avg_ms": round(ms_ax, 4), "GBps": round(ax_gbps, 1), "launches": cnt["n_ax_kernel"]},
                     "atx": {"avg_ms": round(ms_atx, 4), "GBps": round(atx_gbps, 1), "launches": cnt["n_atx_kernel"]}},
+        # the same two products through gv_ax / gv_atx on HOST pointers (this rank's shard; pageable numpy buffers, vectors over
+        # PCIe both ways, for sharded jobs the all-reduce inside): algorithmic bytes / wall time per call
+        "hostptr_GBps": round(2 * shard_bytes / (t_hax + t_hatx) / 1e9, 1),
+        "hostptr": {"ax_ms": round(t_hax * 1e3, 3), "atx_ms": round(t_hatx * 1e3, 3),
+                    "ax_GBps": round(shard_bytes / t_hax / 1e9, 1), "atx_GBps": round(shard_bytes / t_hatx / 1e9, 1)},
     }
     # what each rank ran: shard, picked decompositions, kernel and exchange times of the timed region (HIP events)
     mine = {"rank": rank, "markers": M, "first_marker": S, "ms_ax_kernel": round(ms_ax, 4), "ms_atx_kernel": round(ms_atx, 4),
@@ -374,8 +402,8 @@ def main():
                 num, den = float(tt[0]), float(tt[1])
             out["vamp"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
             if a.fuse_solves >= 4:
-                # level 4 is the only level that touches alpha2: the level below it, which is what the
-                # drivers default to, measured beside it with its own distance from the reference sequence
+                # level 4 (the default of the drivers and of this bench) is the only level that touches alpha2 (DESIGN.md section
+                # 5): the level below it is measured beside it, with its own distance from the reference sequence
                 r3, v3 = vamp_leg(3)
                 num3 = float(np.linalg.norm(r3.x_est - r0.x_est)) ** 2
                 if world > 1:
@@ -394,12 +422,15 @@ def main():
         t_ld_ingest = time.perf_counter() - t1
         CV = max(1, Mt // 100)
         beta, y = hostapi.sim_phen(sh, 0.5, CV, 1, rank=rank)
-        barrier()
-        t1 = time.perf_counter()
-        r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5, seed=1,
-                                  gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank, fuse_solves=a.fuse_solves)
-        sh.synchronize()
-        t_total = time.perf_counter() - t1
+        def ld_run(fuse):
+            barrier()
+            t1 = time.perf_counter()
+            r = hostapi.infere_linear(sh, y, None, None, iterations=a.vamp_iterations, CG_max_iter=a.CG_max_iter, rho=0.5, seed=1,
+                                      gam1=1e-8, gamw=2.0, true_signal=beta, history=False, rank=rank, fuse_solves=fuse)
+            sh.synchronize()
+            return r, time.perf_counter() - t1
+
+        r, t_total = ld_run(a.fuse_solves)
         its = r.trace
         tail = its[1:] if len(its) > 1 else its
         tot = sum(t["seconds"] for t in tail)
@@ -418,6 +449,28 @@ def main():
             "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its],
             "pass_GBps": round(npass * alg_bytes(N, Mt) / tot / 1e9, 1) if tot > 0 else None,
             "R2_lmmse": [round(t["R2_lmmse"], 5) for t in its], "ingest_s": round(t_ld_ingest, 2)}
+        if a.fuse_solves != 0:
+            # the same run issuing the reference's own sequence of products (level 0): the by-products of levels 2-4 must leave
+            # the CG / Onsager / merge counts where they were and x_hat within rounding (tests/test_gpu_ld.py holds the same
+            # against the oracle at sizes it can run)
+            r0, t0_total = ld_run(0)
+            num = float(np.linalg.norm(r.x_est - r0.x_est)) ** 2
+            den = float(np.linalg.norm(r0.x_est)) ** 2
+            if world > 1:
+                tt = torch.tensor([num, den], dtype=torch.float64)
+                dist.all_reduce(tt)
+                num, den = float(tt[0]), float(tt[1])
+            tail0 = r0.trace[1:] if len(r0.trace) > 1 else r0.trace
+            tot0 = sum(t["seconds"] for t in tail0)
+            out["vamp_ld"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
+            out["vamp_ld"]["counts_equal_reference_sequence"] = bool(
+                len(r.trace) == len(r0.trace) and all(t["cg_iters"] == u["cg_iters"] and t["onsager_iters"] == u["onsager_iters"]
+                                                      and t["L_after"] == u["L_after"] and t["revar_rounds"] == u["revar_rounds"]
+                                                      for t, u in zip(r.trace, r0.trace)))
+            out["vamp_ld"]["reference_sequence"] = {
+                "iters_per_s": round(len(tail0) / tot0, 4) if tot0 > 0 else None,
+                "n_ax_pass": [t["n_ax_pass"] for t in r0.trace], "n_atx_pass": [t["n_atx_pass"] for t in r0.trace],
+                "cg_iters": [t["cg_iters"] for t in r0.trace], "onsager_iters": [t["onsager_iters"] for t in r0.trace]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(N, a.seed, a.cpu_markers, local_rank)
         if "vamp" in out and len(out["vamp"]["n_ax"]) > 1:
@@ -432,7 +485,7 @@ def main():
     sh.close()
     # ---- the same operator on ONE resident layout (gv_set_layout(.., 2): M*N/4 bytes instead of 2 x M*N/4), measured in the same
     # process on the same box, and checked bit for bit against the two-layout result above --------------------------------
-    if a.mode == 1 and a.layout == 1 and not a.no_tile_leg:
+    if a.mode == 1 and layout == 1 and not a.no_tile_leg:
         barrier()
         with capi.Shard(N, M, Mt=Mt, S=S, device=local_rank) as st:
             st.set_layout(False, 2)

@@ -12,6 +12,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
 
 
+def kernel_src_hash():
+    """sha256 of the streaming-kernel sources (what a persisted tuning pick and a PMC profile belong to; bench.py and
+    scripts/pmc_summary.py compute the same)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gv_mfma.hip", "gv_mfma.h"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _newer(dst, srcs):
     if not os.path.exists(dst):
         return True
@@ -30,7 +41,7 @@ def build_lib(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         if force or _newer(o, deps):
-            cmd = ["hipcc"] + FLAGS + ["-c", s, "-o", o]
+            cmd = ["hipcc"] + FLAGS + ['-DGV_KERNEL_SRC_HASH="%s"' % kernel_src_hash()[:16], "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

@@ -21,7 +21,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -141,6 +141,7 @@ def load():
     L.gv_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     L.gv_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.gv_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    L.gv_comm_share.argtypes = [vp, vp]
     L.gv_set_overlap.argtypes = [vp, C.c_int]
     L.gv_comm_rank.argtypes = [vp]
     L.gv_comm_size.argtypes = [vp]
@@ -207,7 +208,11 @@ class Shard:
     """One marker shard resident on one GPU: the device side of the reference's `class data`
     (data.hpp:93-140).  Method names follow the reference (Ax, ATx, compute_markers_statistics...)."""
 
-    def __init__(self, N, M, Mt=None, S=0, device=0):
+    def __init__(self, N, M, Mt=None, S=0, device=0, anchor=False):
+        """Nothing but gv_create + gv_set_dims: the context keeps the C ABI's defaults (kernel mode 1, no raw rows, layout
+        picked at ingest).  anchor=True opts into the parity-anchor set-up of the tests that compare the two kernel families or
+        read the rows back: raw rows + two stripe sets resident, fp64 VALU family selected (gv_set_layout(1, 1),
+        gv_set_kernel_mode(0))."""
         self.L = load()
         h = C.c_void_p()
         if self.L.gv_create(device, C.byref(h)):
@@ -216,6 +221,9 @@ class Shard:
         self.N, self.M, self.Mt, self.S = N, M, (M if Mt is None else Mt), S
         self._ck(self.L.gv_set_dims(h, N, M, self.Mt, S))
         self.mbytes = self.L.gv_mbytes(h)
+        if anchor:
+            self.set_layout(True, 1)
+            self.set_kernel_mode(0)
 
     def _ck(self, rc):
         if rc:
@@ -273,6 +281,9 @@ class Shard:
 
     def set_kernel_mode(self, mode):
         self._ck(self.L.gv_set_kernel_mode(self.h, mode))
+
+    def get_kernel_mode(self):
+        return self.L.gv_get_kernel_mode(self.h)
 
     # ---- host-signature matvecs (data::Ax / data::ATx) ---------------------------------------------------
     def Ax(self, x):
@@ -477,6 +488,12 @@ class Shard:
                 return 1
         self._cb_keep = ALLREDUCE_FN(_cb)          # keep the trampoline alive as long as the context
         self._ck(self.L.gv_comm_init_callback(self.h, nranks, rank, self._cb_keep, None))
+
+    def comm_share(self, owner):
+        """gv_comm_share: join the communicator another Shard of this process already holds"""
+        self._ck(self.L.gv_comm_share(self.h, owner.h))
+        if getattr(owner, "_cb_keep", None) is not None:
+            self._cb_keep = owner._cb_keep
 
     def set_overlap(self, tiles):
         self._ck(self.L.gv_set_overlap(self.h, tiles))

@@ -1,5 +1,6 @@
 // gv_capi.hip -- the C ABI of include/gvamp.h over the gfx950 kernels.  No CPU fallback anywhere: every
 // compute entry point launches HIP kernels on the context's stream or fails.
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -235,34 +236,58 @@ int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream) {
     return 0;
 }
 
-// Host <-> device transfers of whole vectors through a pinned staging buffer (4 MiB pieces): a pageable user buffer costs
-// an 8 MB device-to-host copy ~5 ms on this runtime, the staged one ~0.5 ms.  Both return with the data in place.
+// Host <-> device transfers of whole vectors (the std::vector<double> arguments and results of data::Ax / data::ATx,
+// data.hpp:117-121) through a ring of pinned staging slots: a pageable user buffer costs an 8 MB copy ~5 ms on this runtime,
+// a pinned one ~0.15 ms.  XFER_SLOTS slots of XFER_PIECE bytes, one event each; the host memcpy of piece k + 1 overlaps the DMA
+// of piece k, in either direction, so a 4 MB vector costs max(memcpy, DMA) + one piece instead of their sum.  Both return
+// with the data in place.
+constexpr size_t XFER_PIECE = (size_t)512 << 10;
+constexpr int XFER_SLOTS = 16;
 int xfer_stage(gv_ctx* c) {
-    if (!c->xfer_pin) HIPCHK(c, hipHostMalloc(&c->xfer_pin, (size_t)4 << 20));
+    if (!c->xfer_pin) {
+        HIPCHK(c, hipHostMalloc(&c->xfer_pin, XFER_PIECE * XFER_SLOTS));
+        for (int i = 0; i < XFER_SLOTS; i++) HIPCHK(c, hipEventCreateWithFlags(&c->xfer_ev[i], hipEventDisableTiming));
+    }
     return 0;
+}
+// the copy recorded by ev has left / filled its slot (polling: an interrupt-driven wait costs more than the copy of a piece)
+static inline hipError_t xfer_wait(hipEvent_t ev) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
 }
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes) {
     if (xfer_stage(c)) return 1;
-    const size_t piece = (size_t)4 << 20;
-    for (size_t off = 0; off < nbytes; off += piece) {
-        const size_t n = nbytes - off < piece ? nbytes - off : piece;
-        HIPCHK(c, hipMemcpyAsync(c->xfer_pin, (const char*)src_dev + off, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        memcpy((char*)dst + off, c->xfer_pin, n);
+    const size_t np = (nbytes + XFER_PIECE - 1) / XFER_PIECE;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
+        hipError_t e = hipMemcpyAsync((char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE, (const char*)src_dev + off, n,
+                                      hipMemcpyDeviceToHost, c->stream);
+        return e != hipSuccess ? e : hipEventRecord(c->xfer_ev[k % XFER_SLOTS], c->stream);
+    };
+    for (size_t k = 0; k < np && k < (size_t)XFER_SLOTS; k++) HIPCHK(c, issue(k));
+    for (size_t k = 0; k < np; k++) {
+        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
+        HIPCHK(c, xfer_wait(c->xfer_ev[k % XFER_SLOTS]));
+        memcpy((char*)dst + off, (char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE, n);
+        if (k + XFER_SLOTS < np) HIPCHK(c, issue(k + XFER_SLOTS));
     }
-    if (nbytes == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (np == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes) {
     if (xfer_stage(c)) return 1;
-    const size_t piece = (size_t)4 << 20;
-    for (size_t off = 0; off < nbytes; off += piece) {
-        const size_t n = nbytes - off < piece ? nbytes - off : piece;
-        HIPCHK(c, hipStreamSynchronize(c->stream));       // the previous piece has left the staging buffer
-        memcpy(c->xfer_pin, (const char*)src + off, n);
-        HIPCHK(c, hipMemcpyAsync((char*)dst_dev + off, c->xfer_pin, n, hipMemcpyHostToDevice, c->stream));
+    const size_t np = (nbytes + XFER_PIECE - 1) / XFER_PIECE;
+    for (size_t k = 0; k < np; k++) {
+        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
+        char* slot = (char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE;
+        if (k >= (size_t)XFER_SLOTS) HIPCHK(c, xfer_wait(c->xfer_ev[k % XFER_SLOTS]));    // piece k - SLOTS has left this slot
+        memcpy(slot, (const char*)src + off, n);
+        HIPCHK(c, hipMemcpyAsync((char*)dst_dev + off, slot, n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->xfer_ev[k % XFER_SLOTS], c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the slots are free again and the data is in place
     return 0;
 }
 
@@ -299,7 +324,10 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
 // accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
-constexpr int GV_TUNE_VERSION = 3;   // bump when the streaming kernel or the candidate set changes shape
+constexpr int GV_TUNE_VERSION = 4;   // bump when the candidate set or the line format changes shape
+#ifndef GV_KERNEL_SRC_HASH
+#error "build with -DGV_KERNEL_SRC_HASH=\"...\" (gvamp_amd/build.py computes it from the streaming-kernel sources)"
+#endif
 static std::string tune_cache_file() {
     const char* on = getenv("GV_TUNE_CACHE");
     if (on && atoi(on) == 0) return std::string();
@@ -315,8 +343,10 @@ static std::string tune_key(gv_ctx* c) {
     if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
     // the device is identified by ISA target and CU count (the marketing name is not stable: it reads empty under rocprofv3)
     char buf[256];
-    snprintf(buf, sizeof(buf), "v%d|%s|%d|%lld|%lld|L%d|", GV_TUNE_VERSION, pr.gcnArchName, pr.multiProcessorCount,
-             (long long)c->N, (long long)c->M, c->plan.layout);
+    // GV_KERNEL_SRC_HASH (gvamp_amd/build.py: sha256 of gv_mfma.hip + gv_mfma.h) ties a line to the kernels it was measured on: a
+    // pick made for other kernel sources is never read back
+    snprintf(buf, sizeof(buf), "v%d|%s|%s|%d|%lld|%lld|L%d|", GV_TUNE_VERSION, GV_KERNEL_SRC_HASH, pr.gcnArchName,
+             pr.multiProcessorCount, (long long)c->N, (long long)c->M, c->plan.layout);
     return buf;
 }
 // is decomposition d admissible for side (0: ATx / stripes_m, 1: Ax / stripes_n) of this context?
@@ -521,9 +551,13 @@ int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double*
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_chunk, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     }
-    const int64_t nq = (pl.nrg_n + 3) / 4;
+    // The slices are cut from N alone, in units of 1024 individuals -- a whole number of row-group quads in either resident
+    // layout (4 x 4 x 64 rows on two stripe sets, 4 x 256 rows on the tile layout): the ranks of one job may hold different
+    // layouts (gv_set_layout(.., 3) decides per rank from its free HBM) and must still exchange the same ranges.
+    const int64_t nu = (c->N + 1023) / 1024;
     int T = c->overlap_tiles;
-    if (T > nq) T = (int)nq;
+    if (T > nu) T = (int)nu;
+    const int64_t gpu_ = 1024 / pl.rows_n;      // row groups per unit: 16 or 4
     const bool empty = c->M == 0;      // an empty shard sends zeros through the same sequence of slice messages
     if (empty) {
         gvk::fill(c->stream, outa, c->npad, 0.0);
@@ -531,12 +565,14 @@ int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double*
     } else
         gvm::ax_prep(c->stream, pl, xa, nv == 2 ? xb : nullptr, c->mave, c->msig, c->red_partial, cg);
     for (int t = 0; t < T; t++) {
-        const int64_t rg0 = 4 * (nq * t / T), rg1 = t == T - 1 ? pl.nrg_n : 4 * (nq * (t + 1) / T);
-        if (!empty) gvm::ax_rows(c->stream, pl, nv, rg0, rg1, c->mask2, c->npad, 1.0, outa, nv == 2 ? outb : nullptr, cg);
+        const int64_t u0 = nu * t / T, u1 = nu * (t + 1) / T;
+        int64_t rg0 = u0 * gpu_, rg1 = t == T - 1 ? pl.nrg_n : u1 * gpu_;
+        if (rg0 > pl.nrg_n) rg0 = pl.nrg_n;
+        if (rg1 > pl.nrg_n) rg1 = pl.nrg_n;
+        if (!empty && rg1 > rg0) gvm::ax_rows(c->stream, pl, nv, rg0, rg1, c->mask2, c->npad, 1.0, outa, nv == 2 ? outb : nullptr, cg);
         KCHK(c);
-        const int64_t n0 = rg0 * pl.rows_n;
-        int64_t cnt = (rg1 - rg0) * pl.rows_n;
-        if (n0 + cnt > c->npad) cnt = c->npad - n0;
+        const int64_t n0 = u0 * 1024;
+        const int64_t cnt = (t == T - 1 ? c->npad : u1 * 1024) - n0;    // the last slice takes the pad tail (zeros) along
         if (cnt <= 0) continue;
         HIPCHK(c, hipEventRecord(c->ev_chunk, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_chunk, 0));
@@ -552,7 +588,7 @@ int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double*
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return 0;
 }
-bool use_overlap(const gv_ctx* c) {   // nothing rank-local in here: every rank of a job must cut the same slices
+bool use_overlap(const gv_ctx* c) {   // nothing rank-local in here (have_stripes: every rank holds SOME re-encoded layout, whichever)
     return c->overlap_tiles > 1 && is_multi(c) && c->kernel_mode == 1 && c->have_stripes;
 }
 
@@ -582,7 +618,7 @@ int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg) {
         KCHK(c);
         t.stop();
     } else {
-        NEED(c, c->have_raw, "Ax: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
+        NEED(c, c->have_raw, "Ax: kernel mode 0 needs the raw row layout (not the default: gv_set_layout(ctx, 1, ..) before ingest)");
         Timer t(c, &c->cnt.ms_ax);
         gvk::ax_table(c->stream, x, c->mave, c->msig, c->M, c->t3);
         gv_ctx::EvRec* er = ev_next(c, 0);
@@ -627,7 +663,7 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
         c->plan.ev1 = er ? er->b : nullptr;
         gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2, cg);
     } else {
-        NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (gv_set_layout before ingest)");
+        NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (not the default: gv_set_layout(ctx, 1, ..) before ingest)");
         gv_ctx::EvRec* er = ev_next(c, 1);
         if (er) (void)hipEventRecord(er->a, c->stream);
         gvk::atx_f64(c->stream, c->bed, c->M, c->pitch, p, c->mave, c->msig, 1.0 / sqrt((double)c->N), out);
@@ -938,7 +974,8 @@ void gv_destroy(gv_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     std::lock_guard<std::mutex> life(g_lifecycle_mu);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_keep.reset();          // ncclCommDestroy if this was the last context sharing the communicator
     free_dataset(c);
     while (!c->live_vecs.empty()) vec_del(c, *c->live_vecs.begin());   // vectors the caller never gave back
     if (c->red_partial) (void)hipFree(c->red_partial);
@@ -947,6 +984,7 @@ void gv_destroy(gv_ctx* c) {
     if (c->mbox) (void)hipHostFree(c->mbox);
     if (c->pub_counter) (void)hipFree(c->pub_counter);
     if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
+    for (hipEvent_t e : c->xfer_ev) if (e) (void)hipEventDestroy(e);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -999,17 +1037,20 @@ int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 // have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
 // nbytes of the file at `off` into the pinned staging buffer, by GV_IO_THREADS (default 4) concurrent pread streams: one
 // thread copying out of the page cache moves ~9 GB/s, a fraction of what the PCIe link takes
-static bool read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
+// returns 0 ok, -1 end of file before nbytes were read, else the errno of the failing pread (EINTR is retried)
+static int read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
     int nt = 4;
     if (const char* e = getenv("GV_IO_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 32 ? 32 : atoi(e));
     if (nbytes < ((size_t)8 << 20)) nt = 1;
-    std::vector<char> ok(nt, 1);
+    std::vector<int> st(nt, 0);
     auto work = [&](int t) {
         const size_t lo = nbytes * (size_t)t / (size_t)nt, hi = nbytes * (size_t)(t + 1) / (size_t)nt;
         size_t done = lo;
         while (done < hi) {
             const ssize_t r = pread(fd, dst + done, hi - done, (off_t)(off + (int64_t)done));
-            if (r <= 0) { ok[t] = 0; return; }
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) { st[t] = errno ? errno : EIO; return; }
+            if (r == 0) { st[t] = -1; return; }
             done += (size_t)r;
         }
     };
@@ -1017,8 +1058,9 @@ static bool read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
     for (int t = 1; t < nt; t++) th.emplace_back(work, t);
     work(0);
     for (std::thread& x : th) x.join();
-    for (char o : ok) if (!o) return false;
-    return true;
+    for (int v : st) if (v > 0) return v;      // a real I/O error wins over a short file
+    for (int v : st) if (v) return v;
+    return 0;
 }
 
 static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed, uint32_t miss_thr, FILE* file = nullptr,
@@ -1032,7 +1074,11 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     if (c->want_raw && !c->bed) HIPCHK(c, hipMalloc(&c->bed, (size_t)(M > 0 ? M : 1) * P));
     if (!c->want_raw && c->bed) { (void)hipFree(c->bed); c->bed = nullptr; }
     const auto t_in0 = std::chrono::steady_clock::now();
-    if (c->want_auto && c->want_stripes && !(pl.tiles || pl.stripes_m)) {
+    if (c->want_auto && c->want_stripes && (pl.tiles || pl.stripes_m)) {
+        // a re-ingest on a context whose layout auto already picked keeps that pick: tearing a tile layout down to try two
+        // stripe sets again would fail at exactly the sizes auto exists for
+        c->want_tile = pl.layout == 1;
+    } else if (c->want_auto && c->want_stripes) {
         // gv_set_layout(.., 3): two stripe sets (the faster ATx, by 2-5 %) when they fit the free HBM with room for the
         // vectors and scratch, else the one tile layout (half the bytes)
         size_t free_b = 0, total_b = 0;
@@ -1085,12 +1131,16 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     hipEvent_t stage_free[2] = {nullptr, nullptr};
     // File source: two pinned staging buffers, so that reading chunk k + 1 from the file system overlaps the PCIe copy and the
     // re-encoding kernels of chunk k (the stream serialises the device side; an event per buffer says when its copy has left)
-    for (int b = 0; b < 2 && file; b++) {
-        HIPCHK(c, hipHostMalloc(&stage[b], (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * c->mbytes));
-        HIPCHK(c, hipEventCreateWithFlags(&stage_free[b], hipEventDisableTiming));
-    }
-    if (!c->want_raw) HIPCHK(c, hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P));
     int rc = 0;
+    for (int b = 0; b < 2 && file && !rc; b++) {
+        hipError_t e = hipHostMalloc(&stage[b], (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * c->mbytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&stage_free[b], hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(c, "ingest: no pinned staging buffer: %s", hipGetErrorString(e));
+    }
+    if (!c->want_raw && !rc) {
+        const hipError_t e = hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P);
+        if (e != hipSuccess) rc = fail(c, "ingest: no room for the chunk buffer: %s", hipGetErrorString(e));
+    }
     int64_t chunk = 0;
     for (int64_t m0 = 0; m0 < M && !rc; m0 += CH, chunk++) {
         const int64_t mc = M - m0 < CH ? M - m0 : CH;
@@ -1103,8 +1153,10 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage[sb];
             if (file) {
                 if (chunk >= 2) e = hipEventSynchronize(stage_free[sb]);      // the copy of chunk - 2 has left this buffer
-                if (e == hipSuccess && !read_slab(fileno(file), file_off + (int64_t)m0 * c->mbytes, stage[sb], (size_t)mc * c->mbytes)) {
-                    rc = fail(c, "ingest: short read on the .bed file at marker %lld", (long long)(c->S + m0));
+                const int io = e == hipSuccess ? read_slab(fileno(file), file_off + (int64_t)m0 * c->mbytes, stage[sb], (size_t)mc * c->mbytes) : 0;
+                if (io) {
+                    rc = io < 0 ? fail(c, "ingest: the .bed file ends before marker %lld is complete (short file)", (long long)(c->S + m0 + mc - 1))
+                                : fail(c, "ingest: reading the .bed file at marker %lld failed: %s", (long long)(c->S + m0), strerror(io));
                     break;
                 }
             }
@@ -1186,7 +1238,7 @@ int gv_synth_bed_ld(gv_ctx* c, uint64_t seed, uint32_t miss_ppm, uint32_t ld_blo
 }
 
 int gv_download_bed(gv_ctx* c, uint8_t* bed, size_t nbytes) {
-    NEED(c, c->have_raw, "gv_download_bed: the raw row layout is not resident (gv_set_layout)");
+    NEED(c, c->have_raw, "gv_download_bed: the raw row layout is not resident (not the default: call gv_set_layout(ctx, 1, stripes) before the ingest)");
     NEED(c, nbytes == (size_t)c->M * (size_t)c->mbytes, "gv_download_bed: nbytes != M * ceil(N/4)");
     if (c->M > 0)
         HIPCHK(c, hipMemcpy2DAsync(bed, c->mbytes, c->bed, c->pitch, c->mbytes, c->M, hipMemcpyDeviceToHost, c->stream));
@@ -1555,6 +1607,31 @@ int gv_allreduce_host(gv_ctx* c, double* buf, int n) {
 }
 
 // ---- communicator ---------------------------------------------------------------------------------------------
+// the context lets go of whatever communicator it holds (the RCCL one is destroyed when its last sharer does)
+static void comm_drop(gv_ctx* c) {
+    c->comm = nullptr;
+    c->comm_keep.reset();
+    c->local = nullptr;
+    c->local_keep.reset();
+    c->cb = nullptr;
+    c->cb_user = nullptr;
+    c->rank = 0;
+    c->nranks = 1;
+}
+int gv_comm_share(gv_ctx* c, const gv_ctx* owner) {
+    NEED(c, owner != nullptr && owner != c, "gv_comm_share: owner is NULL or the context itself");
+    NEED(c, owner->device == c->device || !owner->comm, "gv_comm_share: an RCCL communicator belongs to its device");
+    comm_drop(c);
+    c->comm = owner->comm;
+    c->comm_keep = owner->comm_keep;
+    c->local = owner->local;
+    c->local_keep = owner->local_keep;
+    c->cb = owner->cb;
+    c->cb_user = owner->cb_user;
+    c->rank = owner->rank;
+    c->nranks = owner->nranks;
+    return 0;
+}
 int gv_comm_unique_id(void* id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     ncclUniqueId id;
@@ -1566,20 +1643,16 @@ int gv_comm_unique_id(void* id128) {
 int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init: bad rank / nranks");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->comm) {
-        (void)ncclCommDestroy(c->comm);
-        c->comm = nullptr;
-    }
-    c->local = nullptr;
-    c->local_keep.reset();
-    c->cb = nullptr;
-    c->cb_user = nullptr;
+    comm_drop(c);
     c->rank = rank;
     c->nranks = nranks;
     if (nranks == 1 && !id128) return 0;
     ncclUniqueId id;
     memcpy(&id, id128, 128);
-    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
+    c->comm = comm;
+    c->comm_keep = std::shared_ptr<void>(comm, [](void* p) { (void)ncclCommDestroy(static_cast<ncclComm_t>(p)); });
     // self-test: a 4-double SUM all-reduce on the context's stream must give nranks * (rank-independent value)
     double probe[4] = {1.0, 2.0, 3.0, 4.0};
     memcpy(c->host_pin, probe, sizeof(probe));
@@ -1593,10 +1666,7 @@ int gv_comm_init(gv_ctx* c, int nranks, int rank, const void* id128) {
 }
 int gv_comm_init_local(gv_ctx* c, int group, int nranks, int rank) {
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init_local: bad rank / nranks");
-    if (c->comm) {
-        (void)ncclCommDestroy(c->comm);
-        c->comm = nullptr;
-    }
+    comm_drop(c);
     std::lock_guard<std::mutex> lk(g_groups_mu);
     std::shared_ptr<LocalGroup>& g = g_groups[group];
     if (!g || g->n != nranks) {
@@ -1615,12 +1685,7 @@ int gv_comm_init_local(gv_ctx* c, int group, int nranks, int rank) {
 int gv_comm_init_callback(gv_ctx* c, int nranks, int rank, gv_allreduce_fn fn, void* user) {
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "gv_comm_init_callback: bad rank / nranks");
     NEED(c, fn != nullptr, "gv_comm_init_callback: fn is NULL");
-    if (c->comm) {
-        (void)ncclCommDestroy(c->comm);
-        c->comm = nullptr;
-    }
-    c->local = nullptr;
-    c->local_keep.reset();
+    comm_drop(c);
     c->cb = fn;
     c->cb_user = user;
     c->rank = rank;

@@ -39,9 +39,12 @@ struct gv_ctx {
     uint32_t* counts = nullptr;     // 3*M: present individuals with a = 2, 1, 0 per marker (marker statistics)
     double alpha_scale = 1.0;       // of the last gv_marker_stats
     bool have_stats = false;
-    int kernel_mode = 0;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
-    bool want_raw = true, want_stripes = true;   // layouts built at ingest (gv_set_layout)
-    bool want_auto = false;                      // gv_set_layout(.., 3): want_tile is decided at ingest from the free HBM
+    // Defaults = the engine bench.py measures: i8 MFMA kernels on a re-encoded layout picked at ingest, no raw rows resident.
+    // The fp64 VALU family (parity anchor) and the raw rows (gv_download_bed) are opt-in: gv_set_kernel_mode(ctx, 0),
+    // gv_set_layout(ctx, 1, ..).
+    int kernel_mode = 1;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
+    bool want_raw = false, want_stripes = true;  // layouts built at ingest (gv_set_layout)
+    bool want_auto = true;                       // gv_set_layout(.., 3): want_tile is decided at ingest from the free HBM
     bool want_tile = false;                      // the MFMA family's layout: false = two stripe sets, true = one tile layout
     bool have_raw = false, have_stripes = false;
     gvm::Plan plan;
@@ -70,7 +73,8 @@ struct gv_ctx {
     unsigned int* pub_counter = nullptr;
     bool pub_armed = false;
     unsigned long long pub_seq = 0;
-    void* xfer_pin = nullptr;      // 4 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
+    void* xfer_pin = nullptr;      // pinned staging ring of the whole-vector host transfers (to_host / to_device): 16 x 512 KiB
+    hipEvent_t xfer_ev[16] = {};   // one event per slot
     // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` / rider flags, residual traces
     // (2 x cgx_relcap doubles), a pinned staging block for the initial states
     double* cgx_state = nullptr;
@@ -86,6 +90,7 @@ struct gv_ctx {
 
     // communicator ---------------------------------------------------------------------------------
     ncclComm_t comm = nullptr;
+    std::shared_ptr<void> comm_keep;       // owns comm: ncclCommDestroy when the last context sharing it lets go (gv_comm_share)
     int rank = 0, nranks = 1;
     void* local = nullptr;                 // in-process test communicator (gv_comm_init_local)
     std::shared_ptr<void> local_keep;

@@ -14,6 +14,9 @@
 #include <sys/stat.h>
 #include <ctime>
 
+#include <unistd.h>
+
+#include "shm_comm.hpp"
 #include "utilities.hpp"
 
 namespace {
@@ -57,39 +60,76 @@ void data::open_device(int device, int kernel_mode) {
     if (kernel_mode == 0 && rank == 0)
         std::cerr << "WARNING: --kernel-mode 0 selects the fp64 VALU kernels (parity anchor, 4-9 % of the HBM roofline): "
                      "expect Ax / ATx 10-20x slower than the default --kernel-mode 1" << std::endl;
-    const int nranks = gv_env_nranks();
-    if (nranks > 1) {
-        // one process per GPU: rank 0 publishes the RCCL unique id through a file next to the outputs
-        const char* rdv = getenv("GVAMP_RENDEZVOUS");
-        std::string path = rdv ? rdv : "/tmp/gvamp_rccl_id";
-        path += "." + std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
-        unsigned char id[128];
-        if (rank == 0) {
-            ck(nullptr, gv_comm_unique_id(id), "gv_comm_unique_id");
-            std::string tmp = path + ".tmp";
-            FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, 128, f) != 128) die("FATAL: cannot write " + tmp);
-            fclose(f);
-            rename(tmp.c_str(), path.c_str());
-        } else {
-            // a file left behind by a run that died before rank 0 removed it must not be taken for this run's id: only a
-            // file written after this process started (minus a launch skew of 30 s) counts
-            const time_t born = time(nullptr) - 30;
-            FILE* f = nullptr;
-            for (int tries = 0; tries < 6000 && !f; tries++) {
-                struct stat sb;
-                if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= born) f = fopen(path.c_str(), "rb");
-                if (!f) {
-                    struct timespec ts = {0, 10000000};
-                    nanosleep(&ts, nullptr);
-                }
-            }
-            if (!f || fread(id, 1, 128, f) != 128) die("FATAL: cannot read " + path);
-            fclose(f);
-        }
-        ck(ctx, gv_comm_init(ctx, nranks, rank, id), "gv_comm_init");
-        if (rank == 0) remove(path.c_str());
+    if (gv_env_nranks() > 1) {
+        gv_ctx* world = gv_host_world(device);          // the process's one communicator (MPI_COMM_WORLD of the reference)
+        ck(ctx, gv_comm_share(ctx, world), "gv_comm_share");
     }
+}
+
+// ---- the process's communicator ------------------------------------------------------------------------------------------
+// The reference has ONE MPI_COMM_WORLD per process however many `data` objects it builds (main_real --run-mode both: a training
+// and a test set).  Here a small context that holds no data owns the communicator -- RCCL over xGMI by default, the shared-
+// memory host transport with GVAMP_COMM=host -- and every data object's context joins it (gv_comm_share): one rendezvous per
+// process, so a rendezvous file can never be read by a later object of the same run.
+namespace {
+gv_ctx* g_world = nullptr;
+gvh_shm_comm* g_shm = nullptr;
+}
+gv_ctx* gv_host_world(int device) {
+    if (g_world) return g_world;
+    const int rank = gv_env_rank(), nranks = gv_env_nranks();
+    if (device < 0) device = gv_env_local_rank();
+    if (gv_create(device, &g_world)) die(std::string("FATAL: ") + gv_last_error(nullptr));
+    const char* kind = getenv("GVAMP_COMM");
+    if (kind && (!strcmp(kind, "host") || !strcmp(kind, "shm"))) {
+        // ranks are processes of one node meeting in shared memory (shm_comm.hpp): device -> host, sum, host -> device per message
+        std::string err;
+        g_shm = gvh_shm_open_impl(gvh_shm_default_name(), nranks, rank, (size_t)1 << 20, err);
+        if (!g_shm) die("FATAL: " + err);
+        ck(g_world, gv_comm_init_callback(g_world, nranks, rank, gvh_shm_allreduce, g_shm), "gv_comm_init_callback");
+        return g_world;
+    }
+    if (kind && strcmp(kind, "rccl") != 0) die(std::string("FATAL: GVAMP_COMM must be rccl (default) or host, not ") + kind);
+    // one process per GPU: rank 0 publishes the RCCL unique id through a file.  Its name is private to the job: the launcher's
+    // $GVAMP_RENDEZVOUS, else /tmp/gvamp_rccl_id.<MASTER_PORT>.<pid of the launcher> (all ranks are children of one launcher)
+    const char* rdv = getenv("GVAMP_RENDEZVOUS");
+    std::string path = rdv ? rdv : "/tmp/gvamp_rccl_id";
+    path += "." + std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    if (!rdv) path += "." + std::to_string((long)getppid());
+    unsigned char id[128];
+    if (rank == 0) {
+        ck(nullptr, gv_comm_unique_id(id), "gv_comm_unique_id");
+        std::string tmp = path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, 128, f) != 128) die("FATAL: cannot write " + tmp);
+        fclose(f);
+        rename(tmp.c_str(), path.c_str());
+    } else {
+        // a file left behind by a run that died before rank 0 removed it must not be taken for this run's id: only a
+        // file written after this process started (minus a launch skew of 30 s) counts
+        const time_t born = time(nullptr) - 30;
+        FILE* f = nullptr;
+        for (int tries = 0; tries < 6000 && !f; tries++) {
+            struct stat sb;
+            if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= born) f = fopen(path.c_str(), "rb");
+            if (!f) {
+                struct timespec ts = {0, 10000000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+        if (!f || fread(id, 1, 128, f) != 128) die("FATAL: cannot read " + path);
+        fclose(f);
+    }
+    ck(g_world, gv_comm_init(g_world, nranks, rank, id), "gv_comm_init");   // returns after a collective: every rank has the id
+    if (rank == 0) remove(path.c_str());
+    return g_world;
+}
+// MPI_Finalize of the drivers: after the last data / vamp object is gone
+void gv_host_finalize() {
+    if (g_world) gv_destroy(g_world);
+    g_world = nullptr;
+    if (g_shm) gvh_shm_close_impl(g_shm);
+    g_shm = nullptr;
 }
 
 void data::push_mask() { ck(ctx, gv_set_mask(ctx, mask4.data(), nonas), "gv_set_mask"); }

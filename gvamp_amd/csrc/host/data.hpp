@@ -7,6 +7,11 @@
 
 #include "gvamp.h"
 
+// the process's one communicator (RCCL, or the shared-memory host transport with GVAMP_COMM=host), created at first use by the
+// first data object of a sharded run; gv_host_finalize() is the drivers' MPI_Finalize
+gv_ctx* gv_host_world(int device);
+void gv_host_finalize();
+
 class data {
 private:
     std::string phenfp, bedfp, bimfp, type_data = "bed";

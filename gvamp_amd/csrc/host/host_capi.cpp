@@ -4,11 +4,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <stdexcept>
 #include <string>
 
 #include "data.hpp"
 #include "gvamp_host.h"
 #include "utilities.hpp"
+#include "shm_comm.hpp"
 #include "vamp.hpp"
 
 // Exceptions of the host classes (the reference lets them terminate the program, e.g. initialize_prior's
@@ -70,6 +72,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     opt.set_use_XXT_denoiser(o->use_XXT_denoiser);
     opt.set_probit_var(o->probit_var);
     opt.set_fuse_solves(o->fuse_solves);
+    if (o->reanchor_every >= 0) opt.set_reanchor_every(o->reanchor_every);
     if (o->freeze_index_file && o->freeze_index_file[0]) opt.set_freeze(o->freeze_index_file);
     if (o->C > 0 && o->covs) {
         opt.set_C((unsigned int)o->C);
@@ -118,5 +121,15 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
     return 0;
     GVH_CATCH
 }
+
+int gvh_shm_open(const char* name, int nranks, int rank, size_t cap_doubles, gvh_shm_comm** out) {
+    GVH_TRY
+    std::string err;
+    *out = gvh_shm_open_impl(name ? std::string(name) : gvh_shm_default_name(), nranks, rank, cap_doubles, err);
+    if (!*out) throw std::runtime_error(err);
+    return 0;
+    GVH_CATCH
+}
+void gvh_shm_close(gvh_shm_comm* comm) { gvh_shm_close_impl(comm); }
 
 }  // extern "C"

@@ -209,5 +209,6 @@ int main(int argc, char** argv) {
         std::cout << "FATAL: unknown --run-mode \"" << mode << "\"" << std::endl;
         return EXIT_FAILURE;
     }
+    gv_host_finalize();      // the process's communicator, after the last data object (MPI_Finalize of the reference)
     return 0;
 }

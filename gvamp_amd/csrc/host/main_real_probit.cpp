@@ -130,5 +130,6 @@ int main(int argc, char** argv) {
         std::cout << "FATAL: --run-mode " << mode << " is not a mode of main_real_probit (infere | test | both)" << std::endl;
         return EXIT_FAILURE;
     }
+    gv_host_finalize();      // the process's communicator, after the last data object (MPI_Finalize of the reference)
     return 0;
 }

@@ -117,6 +117,7 @@ void Options::read_command_line_options(int argc, char** argv) {
     H["--diagnostics"] = [&](const char* a) { diagnostics = atoi(a); };
     H["--store-iterates"] = [&](const char* a) { store_iterates = atoi(a); };
     H["--fuse-solves"] = [&](const char* a) { fuse_solves = atoi(a); };
+    H["--reanchor-every"] = [&](const char* a) { reanchor_every = atoi(a) < 0 ? 0 : atoi(a); };
     H["--resident-layout"] = [&](const char* a) {      // read by data::open_device (every data object of the run)
         resident_layout = atoi(a);
         setenv("GVAMP_RESIDENT_LAYOUT", a, 1);

@@ -32,9 +32,12 @@
        initial residual comes from the previous solve's final residual (no pass); 4 also the Onsager solve's first  \
        step comes from A^T A u of the probe, computed once (rounding-level, like 2 and 3); --resident-layout 1|2|3:    \
        kernel mode 1 keeps two stripe sets (2 x M N / 4 bytes) or one tile layout (M N / 4 bytes) in HBM, same bits; \
-       3 (default) = two stripe sets if they fit the free HBM, else the tile layout */                                         \
+       3 (default) = two stripe sets if they fit the free HBM, else the tile layout; --reanchor-every K (default 10, 0 =  \
+       never): at --fuse-solves 3 / 4 every K-th iteration applies the operator to the warm start explicitly and captures \
+       A^T A u afresh, so the products chained from CG residuals never run unanchored for more than K iterations */       \
     X(int, device, -1) X(int, kernel_mode, 1) X(long, synth_seed, -1) X(unsigned int, synth_miss_ppm, 5000)          \
-    X(int, diagnostics, 0) X(int, store_iterates, 1) X(int, fuse_solves, 4) X(int, resident_layout, 3)
+    X(int, diagnostics, 0) X(int, store_iterates, 1) X(int, fuse_solves, 4) X(int, resident_layout, 3)              \
+    X(int, reanchor_every, 10)
 
 class Options {
 public:
@@ -70,6 +73,7 @@ public:
     }
     void set_use_XXT_denoiser(unsigned int v) { use_XXT_denoiser = v; }
     void set_fuse_solves(int v) { fuse_solves = v; }
+    void set_reanchor_every(int v) { reanchor_every = v; }
     void set_C(unsigned int v) { C = v; }
     void set_freeze(const std::string& file) { use_freeze = 1; freeze_index_file = file; }
 

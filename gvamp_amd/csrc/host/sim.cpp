@@ -98,5 +98,6 @@ int main(int argc, char** argv) {
     }
     delete dataset;
     if (synth_ctx) gv_destroy(synth_ctx);
+    gv_host_finalize();      // the process's communicator, after the last data object (MPI_Finalize of the reference)
     return 0;
 }

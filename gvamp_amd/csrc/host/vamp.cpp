@@ -42,6 +42,7 @@ void vamp::common_init(const Options& opt) {
     diagnostics = opt.get_diagnostics();
     store_iterates = opt.get_store_iterates();
     fuse_solves = opt.get_fuse_solves();
+    reanchor_every = opt.get_reanchor_every();
     if (opt.get_redglob() != 0) {   // vamp.cpp:57,:594: CG on a sub-range of individuals (cross-validation variants)
         std::cout << "FATAL: --red " << opt.get_redglob() << " (sub-range CG / cross-validation) is not built" << std::endl;
         exit(EXIT_FAILURE);
@@ -183,7 +184,9 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
         // accumulating in place in ax2_der.  8 passes per iteration instead of 10 when the CG runs 4 steps.
         if (!ata_x2) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_x2), "gv_vec_alloc");
         wm.ata_mu_a = ata_x2;
-        if (mu_start && have_ata_x2) {
+        // every reanchor_every-th iteration the opening residual is formed by an explicit operator application (as at level 2):
+        // A^T A x2_hat and A x2_hat restart from exact products, so their rounding never chains over more than that many solves
+        if (mu_start && have_ata_x2 && !reanchor_now()) {
             wm.ata_mu_start_a = ata_x2;
             wm.a_mu_start_a = ax2_der;
         }
@@ -192,6 +195,7 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
         // --fuse-solves 4: the Onsager solve starts from zero on the same probe u every iteration: its first operator application is
         // (tau / diag) A^T A u + gam2 u / diag, with A^T A u captured the first time round -- the solve is one pass pair shorter
         if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
+        if (reanchor_now()) have_ata_u = false;     // captured afresh from this iteration's explicit first application
         wm.ata_v_b = ata_u;
         wm.have_ata_v_b = have_ata_u ? 1 : 0;
     }
@@ -351,6 +355,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         return now_s();
     };
     for (int it = 1; it <= max_iter; it++) {
+        cur_it = it;
         const double t_start = now_s();
         double t_io = 0;
         const double t_denoising = tick();
@@ -528,7 +533,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             // residual of this warm start without the ATx + Ax pair of denoiserXXT.cpp:76-78 (gvamp.h: gv_cg_solve_aat2w)
             // and A^T u (for x2_hat = r2 + gamw A^T u, denoiserXXT.cpp:46-48) is accumulated from the A^T p_k of the solve
             // instead of taking a closing ATx pass: it lives in at_u across the iterations
-            const bool known_start = fuse_solves >= 3 && it > 1 && have_aat_prev;
+            const bool known_start = fuse_solves >= 3 && it > 1 && have_aat_prev && !reanchor_now();
             gv_aat_warm wm{};
             gv_vec* at_out = tM;
             if (fuse_solves >= 3) {
@@ -539,6 +544,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 if (inside) { wm.pre_x = r2; wm.pre_out = ax2_der; wm.ride_x = x1_hat; wm.ride_out = z1; }
                 if (fuse_solves >= 4 && CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
                     if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
+                    if (reanchor_now()) have_ata_u = false;
                     wm.ata_v_b = ata_u;
                     wm.have_ata_v_b = have_ata_u ? 1 : 0;
                 }

@@ -35,7 +35,11 @@ private:
     int store_pvals = 0, use_lmmse_damp = 0, reverse = 0;
     double gam1_init = -1, gamw_init = 0;
     std::string r1_init_file, estimate_file;
-    int diagnostics = 0, store_iterates = 1, verbose = 1, fuse_solves = 1;
+    int diagnostics = 0, store_iterates = 1, verbose = 1;
+    int fuse_solves = 4;        // = Options' default (options.hpp); every constructor overwrites it from the Options it is given
+    int reanchor_every = 10;    // levels 3 / 4: iterations between explicit re-anchors of the chained products (0 = never)
+    int cur_it = 0;             // iteration infere_linear is in (read by fused_solves)
+    bool reanchor_now() const { return reanchor_every > 0 && cur_it > 1 && cur_it % reanchor_every == 0; }
     double probit_var = 1;   // options.hpp:124
     // covariates of the probit model (--C > 0, --cov-file): effects fitted once in iteration 1 (vamp_probit.cpp:110-126)
     std::vector<double> cov_eff;                                                          // vamp.hpp:24

@@ -24,7 +24,7 @@ class Opts(C.Structure):
                 ("verbose", C.c_int), ("diagnostics", C.c_int), ("alpha_scale", C.c_double), ("use_XXT_denoiser", C.c_int),
                 ("bin_class", C.c_int), ("probit_var", C.c_double), ("fuse_solves", C.c_int),
                 ("C", C.c_int), ("covs", C.POINTER(C.c_double)), ("cov_eff_out", C.POINTER(C.c_double)),
-                ("freeze_index_file", C.c_char_p)]
+                ("freeze_index_file", C.c_char_p), ("reanchor_every", C.c_int)]
 
 
 class Iter(C.Structure):
@@ -72,7 +72,10 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
                   stop_criteria_thr=1e-4, rho=0.15, learn_vars=1, seed=1, use_lmmse_damp=0, gam1=1e-8, gamw=2.0,
                   true_signal=None, out_prefix=None, verbose=0, diagnostics=0, alpha_scale=1.0, mask4=None,
                   nonas=None, history=True, rank=0, use_XXT_denoiser=0, model="linear", probit_var=1.0, fuse_solves=1,
-                  covs=None, freeze_index_file=None):
+                  covs=None, freeze_index_file=None, reanchor_every=-1):
+    """vamp::infere on the resident shard.  fuse_solves defaults to 1 HERE -- the level whose products are bit-identical to the
+    reference's own sequence, which is what most parity tests want to compare against; the drivers (gvamp_sim, gvamp_main_real,
+    options.hpp), the vamp class and bench.py default to 4.  reanchor_every < 0 keeps the drivers' default (10)."""
     L = load()
     y = np.ascontiguousarray(y, dtype=np.float64)
     o = Opts()
@@ -91,6 +94,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     o.use_XXT_denoiser = use_XXT_denoiser
     o.bin_class, o.probit_var = int(model == "bin_class"), probit_var
     o.fuse_solves = fuse_solves
+    o.reanchor_every = reanchor_every
     o.freeze_index_file = freeze_index_file.encode() if freeze_index_file else None
     cov_eff = None
     if covs is not None:

@@ -55,6 +55,8 @@ int gv_synth_bed(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm);
  * probability ld_ppm / 1e6, the block's per-individual latent draw instead of its own -- block-correlated columns, as real
  * genotypes have them (the LMMSE CG then needs tens of steps instead of 4-5).  ld_block = 0: gv_synth_bed. */
 int gv_synth_bed_ld(gv_ctx* ctx, uint64_t seed, uint32_t miss_ppm, uint32_t ld_block, uint32_t ld_ppm);
+/* The PLINK rows back from HBM: only when the raw row layout is resident, i.e. gv_set_layout(ctx, 1, ..) was called before
+ * the ingest (not the default). */
 int gv_download_bed(gv_ctx* ctx, uint8_t* bed, size_t nbytes);
 /* mask4: mbytes nibbles (data.hpp:36; bit k of mask4[j] = individual 4j+k has a phenotype and 4j+k < N);
  * NULL = every individual present (vector-phenotype ctor, data.cpp:86-100).  nonas: data.cpp:100/:150. */
@@ -74,11 +76,14 @@ int gv_atx(gv_ctx* ctx, const double* p, double* out);
  *   0 none, 1 two stripe sets (marker-major for ATx, individual-major for Ax: 2 x M*N/4 bytes resident),
  *   2 ONE tile layout that serves both products (M*N/4 bytes resident; bit-identical results),
  *   3 auto: two stripe sets when they fit the free HBM at ingest (their ATx is 2-5 % faster), else the tile layout.
- * Default: raw rows + two stripe sets.  With raw_rows = 0 the rows stream through a chunk buffer and only the re-encoded
- * layout stays resident. */
+ * Default: raw_rows = 0, stripes = 3 -- what bench.py measures and what a binding that never calls this gets (INTEGRATION.md
+ * section B): the rows stream through a chunk buffer at ingest and only the re-encoded layout stays resident, so a 100 GB
+ * shard occupies 200 GB (or 100 GB) of HBM, not 300.  raw_rows = 1 is needed by kernel mode 0 and gv_download_bed only. */
 int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
 int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0 none, 1 two stripe sets, 2 tile layout */
-/* kernel family for Ax/ATx: 0 = fp64 VALU kernels (parity anchor), 1 = i8 MFMA fixed-point kernels. */
+/* kernel family for Ax/ATx: 1 (default) = i8 MFMA fixed-point kernels on the re-encoded layout (0.8 of the HBM roofline,
+ * results within 2e-14 of fp64 sums, bit-reproducible); 0 = fp64 VALU kernels on the raw rows (parity anchor, 4-9 % of the
+ * roofline; needs gv_set_layout(ctx, 1, ..) before ingest). */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);
 int gv_get_kernel_mode(const gv_ctx* ctx);
 
@@ -286,6 +291,11 @@ int gv_comm_init_local(gv_ctx* ctx, int group, int nranks, int rank);
  * (torch.distributed gloo).  Slower than RCCL (two PCIe hops per message); the sums must be identical on every rank. */
 typedef int (*gv_allreduce_fn)(void* user, double* buf, size_t n);
 int gv_comm_init_callback(gv_ctx* ctx, int nranks, int rank, gv_allreduce_fn fn, void* user);
+/* One communicator per process: ctx joins the communicator `owner` already holds (RCCL, in-process or callback) instead of
+ * building another one -- a process that keeps several `data` objects (main_real --run-mode both: a training and a test set)
+ * has ONE MPI_COMM_WORLD in the reference, too.  The communicator lives until the last context sharing it is destroyed; both
+ * contexts must be driven from the same host thread (their collectives are issued in program order). */
+int gv_comm_share(gv_ctx* ctx, const gv_ctx* owner);
 /* Overlap of the N-vector exchange of data::Ax with the decode (kernel mode 1, sharded jobs): tiles > 1 cuts the product into
  * that many chunks of individuals and all-reduces each slice on a side HIP stream while the next chunk decodes; 0 / 1 = one
  * message after the whole pass (default; also set by the environment variable GV_OVERLAP).  Bit-identical results. */

@@ -32,6 +32,7 @@ typedef struct {                 /* the knobs vamp reads from Options (options.h
     const double* covs;           /* N x C row-major (the rows of --cov-file), or NULL */
     double* cov_eff_out;          /* C fitted covariate effects (vamp::get_cov_eff), or NULL */
     const char* freeze_index_file; /* --use-freeze 1 --freeze-index-file <text file, one value per global marker>, or NULL */
+    int reanchor_every;           /* --reanchor-every K (levels 3 / 4); < 0 = the drivers' default (10), 0 = never */
 } gvh_opts;
 
 typedef struct {
@@ -56,6 +57,15 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
                       const unsigned char* mask4, int nonas, const double* true_signal, double* x_est,
                       gvh_iter* iters, int iters_cap, int* n_iters, double* x1_hist, double* x2_hist, double* r1_hist,
                       double* probs_out, double* vars_out, int* L_out);
+
+/* ---- host transport: the ranks of one node as processes meeting in POSIX shared memory (gvamp_amd/csrc/host/shm_comm.hpp) -----
+ * What GVAMP_COMM=host selects in the drivers; exported so that tests and a reference-side binding can plug the same sums
+ * into gv_comm_init_callback (gvh_shm_allreduce has the signature of gv_allreduce_fn, user = the communicator).
+ * name: "/something" shared by the ranks of one job (NULL: derived from $GVAMP_RENDEZVOUS or MASTER_PORT + the launcher's pid). */
+typedef struct gvh_shm_comm gvh_shm_comm;
+int gvh_shm_open(const char* name, int nranks, int rank, size_t cap_doubles, gvh_shm_comm** out);
+int gvh_shm_allreduce(void* comm, double* buf, size_t n);
+void gvh_shm_close(gvh_shm_comm* comm);
 
 #ifdef __cplusplus
 }

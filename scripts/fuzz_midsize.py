@@ -34,7 +34,7 @@ def main():
             m4 = np.zeros(mb, dtype=np.uint8)
             idx = np.nonzero(present)[0]
             np.bitwise_or.at(m4, idx >> 2, (1 << (idx & 3)).astype(np.uint8))
-            with capi.Shard(N, M, Mt=S + M, S=S) as sh:
+            with capi.Shard(N, M, Mt=S + M, S=S, anchor=True) as sh:
                 sh.synth_bed(int(rng.integers(1, 10**6)), miss)
                 if fna > 0 or N % 4:
                     sh.set_mask(m4, int(present.sum()))

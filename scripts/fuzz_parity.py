@@ -63,7 +63,7 @@ def one_case(rng, idx, tol=1e-5, verbose=False):
     for n in np.nonzero(present)[0]:
         m4[n >> 2] |= 1 << (n & 3)
     nonas = int(present.sum())
-    with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+    with capi.Shard(N, M, Mt=Mt, S=S, anchor=True) as sh:      # both kernel families are compared below
         sh.upload_bed(bed)
         if use_mask:
             sh.set_mask(m4, nonas)

@@ -65,6 +65,8 @@ def run_case(seed0, k):
         with capi.Shard(N, M) as sh:
             if mode == 1:
                 sh.set_layout(False, layout)
+            else:
+                sh.set_layout(True, False)       # the fp64 family reads the raw rows (not resident by default)
             sh.set_kernel_mode(mode)
             sh.upload_bed(bed)
             sh.set_mask(m4, nonas)

@@ -42,6 +42,36 @@ def test_libgvamp_host_exports(built):
         assert hasattr(L, n), n
 
 
+def test_integration_section_b_is_the_compiled_binding(built):
+    """INTEGRATION.md section B and tests/binding/data_binding.cpp (between its BEGIN / END markers) are the same text, the
+    binding library was built from it, and the text calls none of the entry points that select an engine: what a maintainer
+    pastes is what tests/test_gpu_binding.py runs, on the library's defaults."""
+    src = open(os.path.join(ROOT, "tests", "binding", "data_binding.cpp")).read()
+    b0, b1 = "// ---- BEGIN INTEGRATION.md section B ----\n", "// ---- END INTEGRATION.md section B ----"
+    block = src[src.index(b0) + len(b0):src.index(b1)]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## B. Bind the C ABI"):doc.index("## C. Python")]
+    code = sec[sec.index("```cpp\n") + 7:]
+    code = code[:code.index("```")]
+    assert code == block
+    called = set(re.findall(r"\b(gv_[a-z0-9_]+)\s*\(", re.sub(r"//.*", "", block)))
+    assert called == {"gv_create", "gv_set_dims", "gv_set_mask", "gv_upload_bed", "gv_last_error", "gv_comm_unique_id",
+                      "gv_comm_init", "gv_comm_init_callback", "gv_marker_stats", "gv_get_marker_stats", "gv_ax", "gv_atx",
+                      "gv_destroy"}, called
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "binding", "libgvbinding.so"))
+    for n in ("bh_create", "bh_destroy", "bh_ax", "bh_atx", "bh_stats", "bh_time_ax", "bh_time_atx", "bh_kernel_mode",
+              "bh_layout", "bh_set_transport"):
+        assert hasattr(lib, n), n
+
+
+def test_defaults_of_the_c_abi_are_the_measured_engine():
+    """gv_internal.h: a context nobody configured runs the i8 MFMA family on a re-encoded layout picked at ingest and keeps no raw
+    rows (round 2 defaulted to the fp64 family and 300 GB resident at the headline)."""
+    txt = open(os.path.join(ROOT, "gvamp_amd", "csrc", "gv_internal.h")).read()
+    assert re.search(r"int kernel_mode = 1;", txt)
+    assert re.search(r"bool want_raw = false, want_stripes = true;", txt) and re.search(r"bool want_auto = true;", txt)
+
+
 def test_no_cpu_fallback(built):
     """Without a HIP device the product fails loudly (with a GPU present it simply works)."""
     from gvamp_amd import capi

@@ -143,7 +143,7 @@ def test_kernel_families_agree_on_a_vamp_run_at_scale():
     """A whole VAMP run (N=100k x M=200k, 5 GB shard) on the fp64 VALU family and on the i8 MFMA fixed-point family:
     same CG / EM counts, estimates equal to the ~1e-9 that iteration 1's cancellation leaves."""
     N, M = 100000, 200000
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=True) as sh:
         sh.synth_bed(77, 5000)
         sh.compute_markers_statistics()
         beta, y = hostapi.sim_phen(sh, 0.5, 2000, 3)
@@ -187,7 +187,7 @@ def test_config5_xxt_run_properties():
     """BASELINE config 5 (--use-XXT-denoiser 1, N=50k; M=200k): the joint N-space / Onsager solver against the reference
     sequence, and the Woodbury agreement with the M-space LMMSE path (two CG tolerances, 1e-4 / 1e-5)."""
     N, M = 50000, 200000
-    with capi.Shard(N, M) as sh:                       # people statistics: fp64 on the raw rows vs fixed point on the stripes
+    with capi.Shard(N, M, anchor=True) as sh:          # people statistics: fp64 on the raw rows vs fixed point on the stripes
         sh.synth_bed(616161, 5000)
         sh.compute_markers_statistics()
         p0 = sh.compute_people_statistics()

@@ -40,7 +40,7 @@ CASES = [
 def test_stats_ax_atx_vs_oracle(oracle, N, M, miss, fna):
     rng = np.random.default_rng(N + M)
     bed = synth.synth_bed(N, M, seed=99, miss_ppm=miss)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=True) as sh:      # raw rows resident too, fp64 VALU family first
         sh.upload_bed(bed)
         assert np.array_equal(sh.download_bed(), bed)
         if fna > 0 or N % 4:
@@ -102,15 +102,17 @@ def test_mfma_fixed_point_dynamic_range(oracle, scale):
         assert np.all(sh.Ax(np.zeros(M)) == 0) and np.all(sh.ATx(np.zeros(p.size)) == 0)
 
 
-def test_monomorphic_and_all_missing_markers(oracle):
-    """Guards of data.cpp:462-483: sumb == 0 -> mave 0; sumsqr == 0 -> msig 1."""
+@pytest.mark.parametrize("anchor", [False, True])
+def test_monomorphic_and_all_missing_markers(oracle, anchor):
+    """Guards of data.cpp:462-483: sumb == 0 -> mave 0; sumsqr == 0 -> msig 1 (statistics from the re-encoded layout of the
+    default engine, and from the raw rows of the fp64 family)."""
     N, M = 64, 4
     bed = synth.synth_bed(N, M, seed=5, miss_ppm=0).reshape(M, N // 4).copy()
     bed[0, :] = 0x55   # every genotype missing
     bed[1, :] = 0xFF   # all homozygous a = 0
     bed[2, :] = 0x00   # all a = 2
     bed = bed.reshape(-1)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=anchor) as sh:
         sh.upload_bed(bed)
         sh.compute_markers_statistics()
         mave, msig = sh.marker_stats()
@@ -121,10 +123,11 @@ def test_monomorphic_and_all_missing_markers(oracle):
         assert rel(sh.Ax(x), oracle.ax(bed, N, M, o_mave, o_msig, x)) < TOL
 
 
-def test_alpha_scale(oracle):
+@pytest.mark.parametrize("anchor", [False, True])
+def test_alpha_scale(oracle, anchor):
     N, M = 400, 50
     bed = synth.synth_bed(N, M, seed=6)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=anchor) as sh:
         sh.upload_bed(bed)
         sh.compute_markers_statistics(alpha_scale=0.3)
         _, msig = sh.marker_stats()
@@ -135,7 +138,7 @@ def test_alpha_scale(oracle):
 def test_synth_bed_device_matches_host():
     for N, M, S in ((2000, 100, 0), (1003, 17, 5), (33, 9, 1000)):
         host = synth.synth_bed(N, M, seed=1234, miss_ppm=5000, S=S)
-        with capi.Shard(N, M, Mt=S + M + 3, S=S) as sh:
+        with capi.Shard(N, M, Mt=S + M + 3, S=S, anchor=True) as sh:
             sh.synth_bed(1234, 5000)
             assert np.array_equal(sh.download_bed(), host)
 
@@ -158,8 +161,9 @@ def test_linearity_and_adjoint_at_scale():
         assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs), 1.0)
 
 
+@pytest.mark.parametrize("anchor", [False, True])
 @pytest.mark.parametrize("denoiser", [1, 0])
-def test_cg_solve_vs_oracle(oracle, denoiser):
+def test_cg_solve_vs_oracle(oracle, denoiser, anchor):
     N, M = 2000, 1500
     rng = np.random.default_rng(3)
     bed = synth.synth_bed(N, M, seed=11)
@@ -167,7 +171,7 @@ def test_cg_solve_vs_oracle(oracle, denoiser):
     mu0 = 0.1 * rng.standard_normal(M) if denoiser == 1 else None
     tau, gam2 = 2.0, 1.35
     o_mu, o_rr = oracle.cg_solve(bed, N, M, v, mu0, tau, gam2, denoiser, 25)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=anchor) as sh:
         sh.upload_bed(bed)
         sh.compute_markers_statistics()
         dv, dmu = sh.vecM(v), sh.vecM()
@@ -261,7 +265,7 @@ def test_kernel_families_agree_at_scale():
     """5 GB shard (row offsets beyond 2^32 bytes): fp64 VALU family vs i8 MFMA fixed point, and the adjoint identity."""
     N, M = 100000, 200000
     rng = np.random.default_rng(12)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=True) as sh:
         sh.synth_bed(4242, 5000)
         sh.compute_markers_statistics()
         x, p = rng.standard_normal(M), rng.standard_normal(N)

@@ -62,7 +62,7 @@ WORKER = textwrap.dedent("""
         calls[0] += 1
         dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
     beta = np.fromfile(%(beta)r)
-    with capi.Shard(N, M, Mt=Mt, S=S, device=0) as sh:
+    with capi.Shard(N, M, Mt=Mt, S=S, device=0, anchor=(%(mode)d == 0)) as sh:
         sh.upload_bed(raw[S * mb:(S + M) * mb])
         sh.set_kernel_mode(%(mode)d)
         sh.comm_init_callback(world, rank, allreduce)

@@ -52,7 +52,7 @@ def test_probit_run_vs_oracle(oracle, mode):
     bed, beta, y = make_case_control(oracle, N, M, 11)
     kw = dict(iterations=6, CG_max_iter=30, rho=0.5, seed=3, gam1=1e-8, gamw=1.0, model="bin_class")
     ref = oracle.infere(bed, N, M, y, PROBS, VARS, **kw)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=(mode == 0)) as sh:
         sh.upload_bed(bed)
         sh.set_kernel_mode(mode)
         r = hostapi.infere_linear(sh, y, PROBS, VARS, **kw)

@@ -30,7 +30,7 @@ def test_sim_run_vs_oracle(oracle, mode):
     beta, y = oracle.sim_phen(bed, N, M, 0.5, 500, 7, nthreads=4)
     ref = oracle.infere(bed, N, M, y, PROBS, VARS, iterations=4, CG_max_iter=25, rho=0.5, seed=7, gam1=1e-8, gamw=2.0,
                         true_signal=beta)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=(mode == 0)) as sh:
         sh.upload_bed(bed)
         sh.set_kernel_mode(mode)
         b2, y2 = hostapi.sim_phen(sh, 0.5, 500, 7)
@@ -76,7 +76,7 @@ def test_na_phenotypes_and_ragged_N_vs_oracle(oracle):
     for n in np.nonzero(~is_na)[0]:
         m4[n >> 2] |= 1 << (n & 3)
     for mode in (0, 1):
-        with capi.Shard(N, M) as sh:
+        with capi.Shard(N, M, anchor=(mode == 0)) as sh:
             sh.upload_bed(bed)
             sh.set_kernel_mode(mode)
             r = hostapi.infere_linear(sh, y, PROBS, VARS, iterations=3, CG_max_iter=20, rho=0.5, seed=3, gam1=1e-6,
@@ -165,7 +165,7 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode, fuse
     mb = N // 4
     beta = np.fromfile(os.path.join(G, "sim_beta_true.bin"))
     # y as sim.cpp makes it: A (beta sqrt(N)) + noise, from a single-shard context
-    with capi.Shard(N, Mt) as sh:
+    with capi.Shard(N, Mt, anchor=(mode == 0)) as sh:
         sh.upload_bed(raw)
         sh.set_kernel_mode(mode)
         b, y = hostapi.sim_phen(sh, 0.5, 500, 7)
@@ -178,7 +178,7 @@ def test_sharded_run_vs_real_reference_mpi_outputs(tmp_path, nshards, mode, fuse
             size, modu = divmod(Mt, nshards)
             M = size + 1 if rank < modu else size
             S = sum(size + 1 if r < modu else size for r in range(rank))
-            with capi.Shard(N, M, Mt=Mt, S=S) as sh:
+            with capi.Shard(N, M, Mt=Mt, S=S, anchor=(mode == 0)) as sh:
                 sh.upload_bed(raw[S * mb:(S + M) * mb])
                 sh.set_kernel_mode(mode)
                 sh.comm_init_local(group, nshards, rank)

@@ -297,7 +297,7 @@ def test_level_4_on_the_other_code_paths(oracle, monkeypatch, variant, xxt):
     ref = oracle.infere(bed, N, M, y, probs, vars_, **{k: v for k, v in kw.items() if k != "history"})
     if variant == "host-driven CG":
         monkeypatch.setenv("GV_CG_DEVICE", "0")
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=(variant == "fp64 kernels")) as sh:
         sh.upload_bed(bed)
         sh.set_kernel_mode(0 if variant == "fp64 kernels" else 1)
         sh.compute_markers_statistics()

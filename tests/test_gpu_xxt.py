@@ -45,7 +45,7 @@ def test_people_statistics_from_stripes(oracle, N, M, miss):
         m4[n >> 2] |= 1 << (n & 3)
     nonas = int(present.sum())
     o = oracle.people_stats(bed, N, M, mask4=m4, nonas=nonas)
-    with capi.Shard(N, M) as sh:          # both layouts: mode 0 reads the raw rows, mode 1 the stripes
+    with capi.Shard(N, M, anchor=True) as sh:          # both layouts: mode 0 reads the raw rows, mode 1 the stripes
         sh.upload_bed(bed)
         sh.set_mask(m4, nonas)
         sh.compute_markers_statistics()
@@ -76,7 +76,7 @@ def test_xxt_run_vs_oracle(oracle, mode, fuse):
     ref = oracle.infere(bed, N, M, y, PROBS, VARS, iterations=3, CG_max_iter=40, rho=0.5, seed=3, true_signal=beta,
                         use_XXT_denoiser=1)
     std = oracle.infere(bed, N, M, y, PROBS, VARS, iterations=3, CG_max_iter=40, rho=0.5, seed=3, true_signal=beta)
-    with capi.Shard(N, M) as sh:
+    with capi.Shard(N, M, anchor=(mode == 0)) as sh:
         sh.upload_bed(bed)
         sh.set_kernel_mode(mode)
         r = hostapi.infere_linear(sh, y, PROBS, VARS, iterations=3, CG_max_iter=40, rho=0.5, seed=3, true_signal=beta,
