@@ -104,6 +104,7 @@ int gvh_infere_linear(gv_ctx* ctx, const gvh_opts* o, int N, int M, int Mt, int 
         t.cg_iters = s.cg_iters; t.onsager_iters = s.onsager_iters; t.revar_rounds = s.revar_rounds; t.L_after = s.L_after;
         t.beta1 = s.beta1; t.tau2 = s.tau2; t.tau1_next = s.tau1_next;
         t.n_ax = s.n_ax; t.n_atx = s.n_atx; t.n_ax_pass = s.n_ax_pass; t.n_atx_pass = s.n_atx_pass; t.seconds = s.seconds; t.seconds_io = s.seconds_io;
+        t.probe_product = s.probe_product;
     }
     auto dump = [&](const std::vector<std::vector<double>>& h, double* dst) {
         if (!dst) return;

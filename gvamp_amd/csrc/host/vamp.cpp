@@ -202,7 +202,11 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
     ck(gv_cg_solve2w(ctx, v, mu_start, bern_vec, tau, gam2, CG_max_iter, x2_hat, invQ_bern_vec, &sa, &sb, ra.data(), rb.data(),
                      &ex, &wm), "gv_cg_solve2w");
     have_ata_x2 = wm.ata_mu_a != nullptr;
-    if (wm.ata_v_b && !have_ata_u) have_ata_u = probe_product_is_usable(tau, gam2);
+    probe_product_state = !wm.ata_v_b ? 0 : 3;
+    if (wm.ata_v_b && !have_ata_u) {
+        have_ata_u = probe_product_is_usable(tau, gam2);
+        probe_product_state = have_ata_u ? 1 : 2;
+    }
     if (verbose && rank == 0) {
         for (int i = 0; i < sa.n_relres; i++) printf("[CG] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, ra[i]);
         for (int i = 0; i < sb.n_relres; i++) printf("[CG onsager] it = %d: ||r_it|| / ||RHS|| = %.10g\n", i, rb[i]);
@@ -356,6 +360,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     };
     for (int it = 1; it <= max_iter; it++) {
         cur_it = it;
+        probe_product_state = 0;
         const double t_start = now_s();
         double t_io = 0;
         const double t_denoising = tick();
@@ -553,7 +558,11 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                                  invQ_bern_vec, &sa, &sb, ra.data(), rb.data(), have_derived ? aat_der : nullptr,
                                  have_derived ? ata_der : nullptr, &wm), "gv_cg_solve_aat2w");
             have_aat_prev = have_derived;
-            if (wm.ata_v_b && !have_ata_u) have_ata_u = probe_product_is_usable(gamw, gam2);
+            probe_product_state = !wm.ata_v_b ? 0 : 3;
+            if (wm.ata_v_b && !have_ata_u) {
+                have_ata_u = probe_product_is_usable(gamw, gam2);
+                probe_product_state = have_ata_u ? 1 : 2;
+            }
             if (inside) z1_outputs();
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
@@ -625,6 +634,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         if (verbose && rank == 0) std::cout << "lmmse step took " << tick() - t_lmmse << " seconds." << std::endl;
 
         st.L_after = (int)probs.size();
+        st.probe_product = probe_product_state;
         gv_counters c1;
         gv_get_counters(ctx, &c1);
         st.n_ax = (long)(c1.n_ax - c0.n_ax);

@@ -16,6 +16,9 @@ struct vamp_iter_stats {     // one row per VAMP iteration (what the reference p
     long n_ax_pass, n_atx_pass;       // passes over the genotype shard (two-vector kernels share a pass)
     double beta1, tau2, tau1_next;   // bin_class only
     double seconds, seconds_io;
+    // --fuse-solves 4: what happened to A^T A u of the Onsager probe in this iteration: 0 not in play, 1 captured from the solve's
+    // first application and kept, 2 captured but not kept (cancellation, vamp::probe_product_is_usable), 3 the kept product used
+    int probe_product;
 };
 
 class vamp {
@@ -39,6 +42,7 @@ private:
     int fuse_solves = 4;        // = Options' default (options.hpp); every constructor overwrites it from the Options it is given
     int reanchor_every = 10;    // levels 3 / 4: iterations between explicit re-anchors of the chained products (0 = never)
     int cur_it = 0;             // iteration infere_linear is in (read by fused_solves)
+    int probe_product_state = 0;   // vamp_iter_stats::probe_product of the solve just made
     bool reanchor_now() const { return reanchor_every > 0 && cur_it > 1 && cur_it % reanchor_every == 0; }
     double probit_var = 1;   // options.hpp:124
     // covariates of the probit model (--C > 0, --cov-file): effects fitted once in iteration 1 (vamp_probit.cpp:110-126)

@@ -32,7 +32,7 @@ class Iter(C.Structure):
                [("cg_iters", C.c_int), ("onsager_iters", C.c_int), ("revar_rounds", C.c_int), ("L_after", C.c_int),
                 ("n_ax", C.c_long), ("n_atx", C.c_long), ("n_ax_pass", C.c_long), ("n_atx_pass", C.c_long),
                 ("beta1", C.c_double), ("tau2", C.c_double),
-                ("tau1_next", C.c_double), ("seconds", C.c_double), ("seconds_io", C.c_double)]
+                ("tau1_next", C.c_double), ("seconds", C.c_double), ("seconds_io", C.c_double), ("probe_product", C.c_int)]
 
 
 def load():
@@ -123,7 +123,7 @@ def infere_linear(shard, y, probs, vars_, *, iterations=1, CG_max_iter=60, EM_ma
     for i in range(n.value):
         t = {f: getattr(iters[i], f) for f in ITER_FIELDS}
         for f in ("cg_iters", "onsager_iters", "revar_rounds", "L_after", "n_ax", "n_atx", "seconds", "seconds_io",
-                  "beta1", "tau2", "tau1_next", "n_ax_pass", "n_atx_pass"):
+                  "beta1", "tau2", "tau1_next", "n_ax_pass", "n_atx_pass", "probe_product"):
             t[f] = getattr(iters[i], f)
         r.trace.append(t)
     if history:

@@ -42,6 +42,8 @@ typedef struct {
     long n_ax_pass, n_atx_pass;    /* passes over the genotype shard */
     double beta1, tau2, tau1_next; /* bin_class only */
     double seconds, seconds_io;   /* compute wall time of the iteration, and time spent writing / copying iterates */
+    int probe_product;            /* --fuse-solves 4: A^T A u of the Onsager probe this iteration: 0 not in play, 1 captured and kept,
+                                   * 2 captured but dropped by the cancellation rule, 3 the kept product used */
 } gvh_iter;
 
 /* sim.cpp data recipe on a resident shard: beta_out[M] (this rank's slice), y_out[N] (identical on every rank) */

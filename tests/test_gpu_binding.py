@@ -151,11 +151,11 @@ def _check_big(oracle, d, bed, N, M, rng, nsub=1500):
     x = np.zeros(M)
     x[m0:m0 + nsub] = rng.standard_normal(nsub)
     z = d.Ax(x)
-    assert rel(z, oracle.ax(sub, N, nsub, o_mave, o_msig, x[m0:m0 + nsub])) < 1e-12
+    assert rel(z, oracle.ax(sub, N, nsub, o_mave, o_msig, x[m0:m0 + nsub])) < 1e-11     # fp64 sums of the oracle at N = 400k: 2e-12
     p = np.zeros(4 * mb)
     p[:N] = rng.standard_normal(N)
     w = d.ATx(p)
-    assert rel(w[m0:m0 + nsub], oracle.atx(sub, N, nsub, o_mave, o_msig, p)) < 1e-12
+    assert rel(w[m0:m0 + nsub], oracle.atx(sub, N, nsub, o_mave, o_msig, p)) < 1e-11
     xf = rng.standard_normal(M)
     lhs, rhs = float(d.Ax(xf) @ p), float(xf @ w)
     assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), abs(rhs), 1.0)
@@ -178,7 +178,17 @@ def test_section_b_binding_at_config2_size_runs_the_measured_engine(oracle):
         t_atx = min(d.L.bh_time_atx(d.h, capi._dp(p), 20) for _ in range(3))
         rate = 2 * alg_bytes(N, M) / (t_ax + t_atx) / 1e9
         print("config-2 binding: Ax %.3f ms, ATx %.3f ms per call through the class -> %.0f GB/s" % (t_ax * 1e3, t_atx * 1e3, rate))
+        _report("binding_config2", {"N": N, "M": M, "ax_ms": t_ax * 1e3, "atx_ms": t_atx * 1e3, "GBps": rate, "layout": d.engine()[1]})
         assert rate >= 5500.0, (t_ax, t_atx, rate)
+
+
+def _report(name, obj):
+    """measured rates of the size tests, kept when the run has a gpurun_out/ to leave them in (profiles/ quotes them)"""
+    import json
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(obj, f)
 
 
 def _mem_available_gb():
@@ -206,6 +216,7 @@ def test_section_b_binding_holds_the_headline_shard(oracle):
         x = rng.standard_normal(M)
         t_ax = d.L.bh_time_ax(d.h, capi._dp(x), 5)
         print("headline binding: Ax %.2f ms per call -> %.0f GB/s" % (t_ax * 1e3, alg_bytes(N, M) / t_ax / 1e9))
+        _report("binding_headline", {"N": N, "M": M, "ax_ms": t_ax * 1e3, "GBps": alg_bytes(N, M) / t_ax / 1e9, "layout": d.engine()[1]})
         assert alg_bytes(N, M) / t_ax / 1e9 >= 5500.0
 
 
