@@ -58,7 +58,8 @@ class Counters(C.Structure):
 
 
 class DecompInfo(C.Structure):
-    _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int)]
+    _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int),
+                ("whole_quads", C.c_int64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
@@ -528,8 +529,8 @@ class Shard:
         d = (DecompInfo * 4)()
         self._ck(self.L.gv_get_decomp(self.h, d))
         names = ("atx", "atx2", "ax", "ax2")
-        return {n: ({"balanced_cells": int(x.balanced_cells)} if x.balanced_cells > 0 else
-                    {"ks": x.ks, "taper": round(float(x.taper), 2)}) | {"prio": x.prio, "tuned": bool(x.tuned)}
+        return {n: (({"balanced_cells": int(x.balanced_cells)} | ({"whole_quads": int(x.whole_quads)} if x.whole_quads > 0 else {}))
+                    if x.balanced_cells > 0 else {"ks": x.ks, "taper": round(float(x.taper), 2)}) | {"prio": x.prio, "tuned": bool(x.tuned)}
                 for n, x in zip(names, d)}
 
     def synchronize(self):

@@ -1,5 +1,6 @@
 // gv_capi.hip -- the C ABI of include/gvamp.h over the gfx950 kernels.  No CPU fallback anywhere: every
 // compute entry point launches HIP kernels on the context's stream or fails.
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -237,57 +238,113 @@ int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream) {
 }
 
 // Host <-> device transfers of whole vectors (the std::vector<double> arguments and results of data::Ax / data::ATx,
-// data.hpp:117-121) through a ring of pinned staging slots: a pageable user buffer costs an 8 MB copy ~5 ms on this runtime,
-// a pinned one ~0.15 ms.  XFER_SLOTS slots of XFER_PIECE bytes, one event each; the host memcpy of piece k + 1 overlaps the DMA
-// of piece k, in either direction, so a 4 MB vector costs max(memcpy, DMA) + one piece instead of their sum.  Both return
-// with the data in place.
-constexpr size_t XFER_PIECE = (size_t)512 << 10;
-constexpr int XFER_SLOTS = 16;
+// data.hpp:117-121) through a pinned staging buffer of XFER_BYTES: a pageable user buffer costs an 8 MB copy ~5 ms on this
+// runtime, a pinned one ~0.15 ms.  What is left is the host's own memcpy between the caller's buffer and the staging buffer --
+// 4 MB take ~0.33 ms on one core, 15 % of a 2 ms matvec at config-2 size -- so that copy is shared among a few helper threads
+// (CopyPool: GV_XFER_THREADS helpers, default 3, 0 = none; they sleep between calls and spin briefly after one).
+// Both functions return with the data in place.
+constexpr size_t XFER_BYTES = (size_t)8 << 20;
+namespace {
+class CopyPool {
+    struct Job { char* dst; const char* src; size_t n; };
+    std::vector<std::thread> th;
+    std::vector<Job> jobs;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<unsigned long> gen{0};
+    std::atomic<int> pending{0};
+    bool stop = false;
+    pid_t owner = 0;
+    void work(int id) {
+        unsigned long seen = 0;
+        for (;;) {
+            // spin a little for the next job (back-to-back matvecs), then sleep
+            bool got = false;
+            for (int i = 0; i < 2000 && !got; i++) {
+                got = gen.load(std::memory_order_acquire) != seen;
+#if defined(__x86_64__)
+                if (!got) __builtin_ia32_pause();
+#endif
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen.load(std::memory_order_acquire) != seen; });
+                if (stop) return;
+            }
+            seen = gen.load(std::memory_order_acquire);
+            if (stop) return;
+            const Job j = jobs[id];
+            if (j.n) memcpy(j.dst, j.src, j.n);
+            pending.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+public:
+    static CopyPool& get() {
+        static CopyPool* p = new CopyPool();      // leaked on purpose: no destructor order games at process exit
+        return *p;
+    }
+    CopyPool() {
+        int n = 3;
+        if (const char* e = getenv("GV_XFER_THREADS")) n = atoi(e) < 0 ? 0 : (atoi(e) > 15 ? 15 : atoi(e));
+        owner = getpid();
+        jobs.assign(n, Job{nullptr, nullptr, 0});
+        for (int i = 0; i < n; i++) th.emplace_back(&CopyPool::work, this, i);
+    }
+    // dst <- src, n bytes, shared among the caller and the helpers (below 256 KiB, or in a forked child whose helpers did not
+    // survive the fork, the caller copies alone).  Calls are serialised by copy_mu: contexts of several threads share the pool.
+    std::mutex copy_mu;
+    void copy(void* dst, const void* src, size_t n) {
+        const int nh = (int)th.size();
+        if (nh == 0 || n < ((size_t)256 << 10) || getpid() != owner) { memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> one(copy_mu);
+        const size_t parts = (size_t)nh + 1, per = ((n / parts) + 63) & ~(size_t)63;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int i = 0; i < nh; i++) {
+                const size_t off = per * (size_t)(i + 1);
+                const size_t len = off >= n ? 0 : (i == nh - 1 ? n - off : (off + per > n ? n - off : per));
+                jobs[i] = Job{(char*)dst + off, (const char*)src + off, len};
+            }
+            pending.store(nh, std::memory_order_release);
+            gen.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+        memcpy(dst, src, per < n ? per : n);
+        while (pending.load(std::memory_order_acquire) != 0) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+};
+}  // namespace
 int xfer_stage(gv_ctx* c) {
-    if (!c->xfer_pin) {
-        HIPCHK(c, hipHostMalloc(&c->xfer_pin, XFER_PIECE * XFER_SLOTS));
-        for (int i = 0; i < XFER_SLOTS; i++) HIPCHK(c, hipEventCreateWithFlags(&c->xfer_ev[i], hipEventDisableTiming));
-    }
+    if (!c->xfer_pin) HIPCHK(c, hipHostMalloc(&c->xfer_pin, XFER_BYTES));
     return 0;
-}
-// the copy recorded by ev has left / filled its slot (polling: an interrupt-driven wait costs more than the copy of a piece)
-static inline hipError_t xfer_wait(hipEvent_t ev) {
-    for (;;) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-    }
 }
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes) {
     if (xfer_stage(c)) return 1;
-    const size_t np = (nbytes + XFER_PIECE - 1) / XFER_PIECE;
-    auto issue = [&](size_t k) -> hipError_t {
-        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
-        hipError_t e = hipMemcpyAsync((char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE, (const char*)src_dev + off, n,
-                                      hipMemcpyDeviceToHost, c->stream);
-        return e != hipSuccess ? e : hipEventRecord(c->xfer_ev[k % XFER_SLOTS], c->stream);
-    };
-    for (size_t k = 0; k < np && k < (size_t)XFER_SLOTS; k++) HIPCHK(c, issue(k));
-    for (size_t k = 0; k < np; k++) {
-        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
-        HIPCHK(c, xfer_wait(c->xfer_ev[k % XFER_SLOTS]));
-        memcpy((char*)dst + off, (char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE, n);
-        if (k + XFER_SLOTS < np) HIPCHK(c, issue(k + XFER_SLOTS));
+    for (size_t off = 0; off < nbytes; off += XFER_BYTES) {
+        const size_t n = nbytes - off < XFER_BYTES ? nbytes - off : XFER_BYTES;
+        HIPCHK(c, hipMemcpyAsync(c->xfer_pin, (const char*)src_dev + off, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CopyPool::get().copy((char*)dst + off, c->xfer_pin, n);
     }
-    if (np == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nbytes == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes) {
+// sync = false: returns once the caller's buffer has been read (its bytes are in the staging buffer or on their way); the
+// copy to the device is ordered on the context's stream like any kernel.  The next to_host / to_device synchronises the stream
+// before it touches the staging buffer again.
+int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes, bool sync) {
     if (xfer_stage(c)) return 1;
-    const size_t np = (nbytes + XFER_PIECE - 1) / XFER_PIECE;
-    for (size_t k = 0; k < np; k++) {
-        const size_t off = k * XFER_PIECE, n = nbytes - off < XFER_PIECE ? nbytes - off : XFER_PIECE;
-        char* slot = (char*)c->xfer_pin + (k % XFER_SLOTS) * XFER_PIECE;
-        if (k >= (size_t)XFER_SLOTS) HIPCHK(c, xfer_wait(c->xfer_ev[k % XFER_SLOTS]));    // piece k - SLOTS has left this slot
-        memcpy(slot, (const char*)src + off, n);
-        HIPCHK(c, hipMemcpyAsync((char*)dst_dev + off, slot, n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipEventRecord(c->xfer_ev[k % XFER_SLOTS], c->stream));
+    for (size_t off = 0; off < nbytes; off += XFER_BYTES) {
+        const size_t n = nbytes - off < XFER_BYTES ? nbytes - off : XFER_BYTES;
+        HIPCHK(c, hipStreamSynchronize(c->stream));       // whatever used the staging buffer last has left it
+        CopyPool::get().copy(c->xfer_pin, (const char*)src + off, n);
+        HIPCHK(c, hipMemcpyAsync((char*)dst_dev + off, c->xfer_pin, n, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // the slots are free again and the data is in place
+    if (sync) HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -324,7 +381,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
 // accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
-constexpr int GV_TUNE_VERSION = 4;   // bump when the candidate set or the line format changes shape
+constexpr int GV_TUNE_VERSION = 5;   // bump when the candidate set or the line format changes shape
 #ifndef GV_KERNEL_SRC_HASH
 #error "build with -DGV_KERNEL_SRC_HASH=\"...\" (gvamp_amd/build.py computes it from the streaming-kernel sources)"
 #endif
@@ -356,10 +413,10 @@ static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
     const int64_t min_ks = side ? (c->M * 512 + 2147483646LL) / 2147483647LL : 1;
     int64_t pieces;
     if (d.skL > 0) {
-        if (d.skL < 8 || (side && min_ks > 1) || nkb < 2) return false;
+        if (d.skL < 8 || (side && min_ks > 1) || nkb < 2 || d.piv < 0 || d.piv > (nrg + 3) / 4) return false;
         pieces = (nkb + d.skL - 1) / d.skL + 1;
     } else {
-        if (d.ks < 1 || d.ks > 64 || d.ks > nkb || d.ks < min_ks) return false;
+        if (d.ks < 1 || d.ks > 64 || d.ks > nkb || d.ks < min_ks || d.piv != 0) return false;
         pieces = d.ks;
     }
     if (!(d.taper >= 0.f && d.taper < 1.f) || (d.prio != 0 && d.prio != 1)) return false;
@@ -376,12 +433,12 @@ static bool tune_cache_load(gv_ctx* c) {
     while (fgets(line, sizeof(line), f)) {
         if (strncmp(line, key.c_str(), key.size()) != 0) continue;
         gvm::Decomp d[4];
-        long long sk[4];
-        if (sscanf(line + key.size(), "%d %lld %d %f %d %lld %d %f %d %lld %d %f %d %lld %d %f", &d[0].ks, &sk[0], &d[0].prio,
-                   &d[0].taper, &d[1].ks, &sk[1], &d[1].prio, &d[1].taper, &d[2].ks, &sk[2], &d[2].prio, &d[2].taper, &d[3].ks,
-                   &sk[3], &d[3].prio, &d[3].taper) != 16)
+        long long sk[4], pv[4];
+        if (sscanf(line + key.size(), "%d %lld %lld %d %f %d %lld %lld %d %f %d %lld %lld %d %f %d %lld %lld %d %f", &d[0].ks, &sk[0],
+                   &pv[0], &d[0].prio, &d[0].taper, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[2].ks, &sk[2], &pv[2],
+                   &d[2].prio, &d[2].taper, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper) != 20)
             continue;
-        for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; got[k] = d[k]; }
+        for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; d[k].piv = pv[k]; got[k] = d[k]; }
         have = true;
     }
     fclose(f);
@@ -403,7 +460,8 @@ static void tune_cache_store(gv_ctx* c) {
     char buf[1024];
     int n = snprintf(buf, sizeof(buf), "%s", key.c_str());
     for (int k = 0; k < 4; k++)
-        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %d %.2f ", d[k]->ks, (long long)d[k]->skL, d[k]->prio, d[k]->taper);
+        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
+                      d[k]->taper);
     n += snprintf(buf + n, sizeof(buf) - n, "\n");
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
     if (fd < 0) return;
@@ -490,8 +548,8 @@ int autotune_ks(gv_ctx* c) {
             if (!solo && timed(dual, 0, 1) < 0) return -1.0;   // untimed: the first launch of a new grid shape
             const double t = timed(dual, side, reps);
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld prio %d taper %.1f : %.4f ms / %s\n", cls, cd.ks,
-                        (long long)cd.skL, cd.prio, cd.taper, t, solo ? "product" : "pair");
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f : %.4f ms / %s\n", cls, cd.ks,
+                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, t, solo ? "product" : "pair");
             return t;
         };
         gvm::Decomp best = cand[0];
@@ -527,7 +585,8 @@ int autotune_ks(gv_ctx* c) {
         }
         d = best;
         if (verbose)
-            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld prio %d taper %.1f\n", cls, d.ks, (long long)d.skL, d.prio, d.taper);
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f\n", cls, d.ks, (long long)d.skL,
+                    (long long)d.piv, d.prio, d.taper);
     }
     KCHK(c);
     c->tune_source = 1;
@@ -858,7 +917,25 @@ static int plan_decomps(gv_ctx* c) {
     // workgroups of a balanced launch lose ~10 % to the arbiter's oldest-first tail).
     int prio_only = -1;                                    // GV_PRIO=0/1 (development): restrict to one setting
     if (const char* e = getenv("GV_PRIO")) prio_only = atoi(e) ? 1 : 0;
-    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, bool balanced_ok, std::vector<gvm::Decomp>& out) {
+    // piv quads whole (0: as many whole rounds of 768 as the quads allow), the rest balanced over G workgroups; the pieces a row
+    // of the remainder is cut into are bounded so that the int32 partial sums stay below 1 GB (4 planes x 32 B per row and piece)
+    auto hybrid_of = [](int64_t nrg, int64_t nkb, int64_t rows, int64_t piv, int64_t G) -> gvm::Decomp {
+        gvm::Decomp h;
+        const int64_t nq = (nrg + 3) / 4;
+        if (piv <= 0) piv = nq / 768 * 768;
+        if (piv <= 0 || piv >= nq || nkb < 2 || G <= 0) return h;
+        const int64_t cells = (nq - piv) * nkb;
+        int64_t maxp = (int64_t)(1.0e9 / (128.0 * (double)nrg * (double)rows));
+        if (maxp > 60) maxp = 60;
+        if (maxp < 3) return h;
+        int64_t L = (cells + G - 1) / G;
+        const int64_t Lmin = (nkb + maxp - 2) / (maxp - 1);
+        if (L < Lmin) L = Lmin;
+        if (L < 8) L = 8;
+        h.ks = 1; h.skL = L; h.piv = piv; h.prio = 1;
+        return h;
+    };
+    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, int64_t rows, bool balanced_ok, std::vector<gvm::Decomp>& out) {
         out.clear();
         for (int prio = 0; prio < 2; prio++) {
             if (prio_only >= 0 && prio != prio_only) continue;
@@ -868,14 +945,20 @@ static int plan_decomps(gv_ctx* c) {
                 out.push_back(d);
             }
         }
-        if (balanced_ok && prio_only != 0 && nkb >= 2)
+        if (balanced_ok && prio_only != 0 && nkb >= 2) {
+            // hybrid: whole rounds of the 768 resident workgroups go one quad per workgroup (in step over K), the quads that are
+            // left over are cut into 768 balanced ranges -- for quad counts just above a multiple of 768 (gv_mfma.hip).  Listed
+            // before the fully balanced grids: on a tie it is the one that fetches every digit block once per XCD
+            gvm::Decomp h = hybrid_of(nrg, nkb, rows, 0, 768);
+            if (h.skL > 0) out.push_back(h);
             for (int r = 1; r <= 2; r++) {
                 gvm::Decomp d; d.ks = 1; d.skL = skL_of(nrg, nkb, 768 * r); d.prio = 1;
                 if (d.skL > 0) out.push_back(d);
             }
+        }
     };
-    build(ks3_m, pl.nrg_m, pl.nkb_m, true, c->dec_cand_m);
-    build(ks3_n, pl.nrg_n, pl.nkb_n, min_ks_n <= 1, c->dec_cand_n);
+    build(ks3_m, pl.nrg_m, pl.nkb_m, 64, true, c->dec_cand_m);
+    build(ks3_n, pl.nrg_n, pl.nkb_n, pl.rows_n, min_ks_n <= 1, c->dec_cand_n);
     c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
     // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
     // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
@@ -897,6 +980,22 @@ static int plan_decomps(gv_ctx* c) {
     if (const char* e = getenv("GV_SK_N")) {
         gvm::Decomp d; d.skL = min_ks_n > 1 ? 0 : skL_of(pl.nrg_n, pl.nkb_n, atoi(e)); d.prio = prio_only != 0;
         if (d.skL > 0) fix(c->dec_cand_n, c->ks_fixed_n, d);
+    }
+    // GV_HY_M / GV_HY_N = "<whole quads>:<workgroups of the remainder>": a hybrid decomposition (0 whole quads: whole rounds of 768)
+    auto hy = [&](const char* e, int64_t nrg, int64_t nkb, int64_t rows) {
+        long long piv = 0, G = 768;
+        sscanf(e, "%lld:%lld", &piv, &G);
+        gvm::Decomp d = hybrid_of(nrg, nkb, rows, piv, G);
+        d.prio = prio_only != 0;
+        return d;
+    };
+    if (const char* e = getenv("GV_HY_M")) {
+        gvm::Decomp d = hy(e, pl.nrg_m, pl.nkb_m, 64);
+        if (d.skL > 0) fix(c->dec_cand_m, c->ks_fixed_m, d);
+    }
+    if (const char* e = getenv("GV_HY_N")) {
+        gvm::Decomp d = hy(e, pl.nrg_n, pl.nkb_n, pl.rows_n);
+        if (d.skL > 0 && min_ks_n <= 1) fix(c->dec_cand_n, c->ks_fixed_n, d);
     }
     if (const char* e = getenv("GV_AUTOTUNE"))
         if (atoi(e) == 0) c->ks_fixed_m = c->ks_fixed_n = true;
@@ -984,7 +1083,6 @@ void gv_destroy(gv_ctx* c) {
     if (c->mbox) (void)hipHostFree(c->mbox);
     if (c->pub_counter) (void)hipFree(c->pub_counter);
     if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
-    for (hipEvent_t e : c->xfer_ev) if (e) (void)hipEventDestroy(e);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1113,7 +1211,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
             int k = 1;
             for (const gvm::Decomp& d : cand) {
-                const int p = d.skL > 0 ? (int)((nkb + d.skL - 1) / d.skL) + 1 : d.ks;
+                const int p = (int)gvm::pieces_max(d, nkb);
                 if (p > k) k = p;
             }
             return k;
@@ -1378,14 +1476,14 @@ int gv_atx2_dev(gv_ctx* c, const gv_vec* pa, const gv_vec* pb, gv_vec* outa, gv_
 
 int gv_ax(gv_ctx* c, const double* x, double* out) {
     if (ensure_work(c)) return 1;
-    if (to_device(c, c->cg_d->d, x, sizeof(double) * c->M)) return 1;
+    if (to_device(c, c->cg_d->d, x, sizeof(double) * c->M, false)) return 1;   // the kernels queue up behind the copy
     if (ax_device(c, c->cg_d->d, c->w_n->d)) return 1;
     return to_host(c, out, c->w_n->d, sizeof(double) * 4 * c->mbytes);
 }
 int gv_atx(gv_ctx* c, const double* p, double* out) {
     if (ensure_work(c)) return 1;
     NEED(c, c->mask2, "gv_atx: the phenotype mask must be set first");
-    if (to_device(c, c->w_n->d, p, sizeof(double) * 4 * c->mbytes)) return 1;
+    if (to_device(c, c->w_n->d, p, sizeof(double) * 4 * c->mbytes, false)) return 1;
     // The kernels (like data::dot_product, data.cpp:728-801, which applies no mask) need p = 0 at NA-phenotype and pad
     // slots; the reference's callers hand in filter_pheno()'d vectors.  A caller-owned host vector is not trusted to be
     // filtered -- data::get_phen() carries DBL_MAX at NA individuals (data.cpp:147) -- so the staged copy is masked here:
@@ -1741,6 +1839,7 @@ int gv_get_decomp(gv_ctx* c, gv_decomp_info* out4) {
     for (int k = 0; k < 4; k++) {
         out4[k].ks = d[k]->ks;
         out4[k].balanced_cells = d[k]->skL;
+        out4[k].whole_quads = d[k]->skL > 0 ? d[k]->piv : 0;
         out4[k].prio = d[k]->prio;
         out4[k].taper = d[k]->taper;
         out4[k].tuned = c->ks_tuned ? 1 : 0;

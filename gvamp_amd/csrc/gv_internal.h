@@ -73,8 +73,7 @@ struct gv_ctx {
     unsigned int* pub_counter = nullptr;
     bool pub_armed = false;
     unsigned long long pub_seq = 0;
-    void* xfer_pin = nullptr;      // pinned staging ring of the whole-vector host transfers (to_host / to_device): 16 x 512 KiB
-    hipEvent_t xfer_ev[16] = {};   // one event per slot
+    void* xfer_pin = nullptr;      // 8 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
     // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` / rider flags, residual traces
     // (2 x cgx_relcap doubles), a pinned staging block for the initial states
     double* cgx_state = nullptr;
@@ -203,7 +202,7 @@ bool is_multi(const gv_ctx* c);
 int comm_allreduce(gv_ctx* c, double* dev, size_t n);
 int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream);
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes);
-int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes);
+int to_device(gv_ctx* c, void* dst_dev, const void* src, size_t nbytes, bool sync = true);
 // data::Ax / data::ATx (and their two-vector forms) on device pointers, in the kernel family of the context
 // (cg: the slots of the pass that belong to a CG system with device-resident scalars -- gvm::CgHook)
 int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg = nullptr);

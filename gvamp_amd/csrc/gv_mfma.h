@@ -8,10 +8,21 @@ namespace gvm {
 struct Decomp {
     int ks = 1;          // uniform: K-segments per quad (workgroups per group of 4 row groups)
     int64_t skL = 0;     // > 0: balanced decomposition, cells (quad x K-block) per workgroup; 0: uniform K-split
+    int64_t piv = 0;     // balanced only, > 0: hybrid -- the first piv quads go one per workgroup over the whole K range (in
+                         // step, like a uniform split with ks = 1) and only the remaining quads are cut into ranges of skL cells
     int prio = 0;        // 1: waves lower their issue priority as they progress (k_mfma_matvec)
     float taper = 0.f;   // uniform split only: K-segment j is (1 + taper (ks-1-2j)/(ks-1)) times the mean length, so the
                          // workgroups dispatched last (the last segment) are the shortest and the launch's tail is short
 };
+
+// workgroups of a launch over nq quads x nkb K-blocks, and pieces (int32 partial sums per row) the epilogues add up at most
+inline int64_t piv_of(const Decomp& d, int64_t nq) { return d.skL > 0 && d.piv > 0 ? (d.piv < nq ? d.piv : nq) : 0; }
+inline int64_t grid_of(const Decomp& d, int64_t nq, int64_t nkb) {
+    if (d.skL <= 0) return nq * d.ks;
+    const int64_t piv = piv_of(d, nq);
+    return piv + ((nq - piv) * nkb + d.skL - 1) / d.skL;
+}
+inline int64_t pieces_max(const Decomp& d, int64_t nkb) { return d.skL > 0 ? (nkb + d.skL - 1) / d.skL + 1 : d.ks; }
 
 // ---- device-resident CG (gv_solvers.hip, cg_run_device) ------------------------------------------------------------
 // State block of one CG system in device memory (doubles).  The kernels of a CG step read alpha / beta / the activity

@@ -425,9 +425,17 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // partial layout (int32): [(piece * P + plane) * rows_p + row] * 8 + digit, rows_p = 64 * nrg; P = 2 (MODE 0: sum r' p, sum miss p),
 // 4 (MODE 2: planes 2v, 2v+1 belong to vector v), 1 (MODE 1, 4: the two products already added) or 2 (MODE 3: plane v = vector v); piece = ks (uniform) or w - floor(quad nkb / skL) (balanced: the
 // workgroups that touch a quad are consecutive).  pieces_of() below is the count the epilogue kernels sum over.
-__device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL, int qshift = 8) {
+//   hybrid (skL > 0, piv > 0): the first piv quads -- a whole number of rounds of the resident workgroups -- go one quad per
+//       workgroup over the whole K range (uniform, ks = 1: co-resident workgroups walk K in step, a digit block is fetched once
+//       per XCD), and only the remaining nq - piv quads are cut into balanced ranges of skL cells.  For shards whose quad count
+//       is just above a multiple of 768: neither the ragged last round of a uniform split nor the scattered K offsets of a
+//       fully balanced grid (1.13 x HBM over-fetch of digit blocks on the two-vector Ax at N = 400k x M = 125k).  The
+//       remainder's workgroups take the first block indices (they are dispatched first and are short).
+__device__ __forceinline__ int pieces_of(int64_t row, int ksplit, int64_t nkb, int64_t skL, int qshift = 8, int64_t piv = 0) {
     if (skL <= 0) return ksplit;
-    const int64_t q = row >> qshift;   // rows per quad of row groups: 256 (64-row groups) or 1024 (tile layout, Ax side)
+    int64_t q = row >> qshift;   // rows per quad of row groups: 256 (64-row groups) or 1024 (tile layout, Ax side)
+    if (q < piv) return 1;
+    q -= piv;
     return (int)(((q + 1) * nkb - 1) / skL - (q * nkb) / skL + 1);
 }
 
@@ -445,7 +453,7 @@ template <int MODE, bool SK, bool GO>
 __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                  const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                  int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial,
-                                                 const int* __restrict__ go) {
+                                                 const int* __restrict__ go, uint32_t piv) {
     // device-resident CG: a step enqueued before the host knew that every system had converged is dropped here
     if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
@@ -462,8 +470,14 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     const uint32_t nkb32 = (uint32_t)nkb, skL32 = (uint32_t)skL;
     if (SK) {
         const uint32_t U = (uint32_t)nq * nkb32;
-        u = blockIdx.x * skL32;
-        uend = u + skL32 < U ? u + skL32 : U;
+        const uint32_t nrem = gridDim.x - piv;      // hybrid: workgroups of the balanced remainder (piv == 0: all of them)
+        if (blockIdx.x < nrem) {
+            u = piv * nkb32 + blockIdx.x * skL32;
+            uend = u + skL32 < U ? u + skL32 : U;
+        } else {                                    // one whole quad
+            u = (blockIdx.x - nrem) * nkb32;
+            uend = u + nkb32;
+        }
     } else {
         const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
         u = q0 * nkb32 + kbnd.b[ks0];
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     const int64_t q = q32, kb0 = u - q32 * nkb32;
     const uint32_t seg = nkb32 - (uint32_t)kb0 < uend - u ? nkb32 - (uint32_t)kb0 : uend - u;   // to the end of the quad or of the range
     const int64_t nsteps = seg;
-    const int ks = SK ? (int)__builtin_amdgcn_readfirstlane(blockIdx.x - (q32 * nkb32) / skL32)
+    const int ks = SK ? (q32 < piv ? 0 : (int)__builtin_amdgcn_readfirstlane(blockIdx.x - ((q32 - piv) * nkb32) / skL32))
                       : (int)(blockIdx.x / (uint32_t)nq);
     const uint32_t useg0 = u;   // first cell of this segment
     u += seg;
@@ -765,7 +779,7 @@ template <int DIR, int MODE, bool SK, bool GO>
 __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                       const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                       int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial, int nv,
-                                                      const int* __restrict__ go, int64_t rstride) {
+                                                      const int* __restrict__ go, int64_t rstride, uint32_t piv) {
     // rstride (DIR 1): row groups per K-step in memory -- nrg, or more when this launch covers a sub-range of the row groups
     if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (DIR == 1) ? 64 : ((MODE == 0) ? 128 : 256);   // u32x4 per K-step of one digit buffer
@@ -784,8 +798,14 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     const uint32_t nkb32 = (uint32_t)nkb, skL32 = (uint32_t)skL;
     if (SK) {
         const uint32_t U = (uint32_t)nq * nkb32;
-        u = blockIdx.x * skL32;
-        uend = u + skL32 < U ? u + skL32 : U;
+        const uint32_t nrem = gridDim.x - piv;      // hybrid: workgroups of the balanced remainder (piv == 0: all of them)
+        if (blockIdx.x < nrem) {
+            u = piv * nkb32 + blockIdx.x * skL32;
+            uend = u + skL32 < U ? u + skL32 : U;
+        } else {                                    // one whole quad
+            u = (blockIdx.x - nrem) * nkb32;
+            uend = u + nkb32;
+        }
     } else {
         const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
         u = q0 * nkb32 + kbnd.b[ks0];
@@ -807,7 +827,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     const int64_t q = q32, kb0 = u - q32 * nkb32;
     const uint32_t seg = nkb32 - (uint32_t)kb0 < uend - u ? nkb32 - (uint32_t)kb0 : uend - u;
     const int64_t nsteps = seg;
-    const int ks = SK ? (int)__builtin_amdgcn_readfirstlane(blockIdx.x - (q32 * nkb32) / skL32)
+    const int ks = SK ? (q32 < piv ? 0 : (int)__builtin_amdgcn_readfirstlane(blockIdx.x - ((q32 - piv) * nkb32) / skL32))
                       : (int)(blockIdx.x / (uint32_t)nq);
     const uint32_t useg0 = u;
     u += seg;
@@ -1047,10 +1067,10 @@ __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, 
 // (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N): the ingredients of data::pvals_calc, data.cpp:1150-1170)
 __global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                    const double* __restrict__ scal1, const double* __restrict__ scal2,
-                                                   double* __restrict__ out, int64_t nkb, int64_t skL) {
+                                                   double* __restrict__ out, int64_t nkb, int64_t skL, int64_t piv) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    ksplit = pieces_of(m, ksplit, nkb, skL);
+    ksplit = pieces_of(m, ksplit, nkb, skL, 8, piv);
     long long s[4][7];
 #pragma unroll
     for (int pl = 0; pl < 4; pl++)
@@ -1090,7 +1110,7 @@ struct FinAtx { double* out[2]; const double* addx[2]; };   // addx != NULL: out
 __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                  const double* __restrict__ scal_base, const double* __restrict__ mave,
                                                  const double* __restrict__ msig, double inv_sqrt_n, FinAtx a, double tau,
-                                                 double gam2, int ppk, int64_t nkb, int64_t skL) {
+                                                 double gam2, int ppk, int64_t nkb, int64_t skL, int64_t piv) {
     // ppk = planes per K-split in `partial` (2, or 4 for the two-vector kernels); vector v = blockIdx.y owns planes 2v, 2v+1
     const int v = blockIdx.y, p0 = 2 * v;
     const double* __restrict__ scal = scal_base + 4 * v;
@@ -1098,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
-    ksplit = pieces_of(m, ksplit, nkb, skL);
+    ksplit = pieces_of(m, ksplit, nkb, skL, 8, piv);
     for (int ks = 0; ks < ksplit; ks++) {
         const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
         const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
@@ -1124,7 +1144,7 @@ struct FinAtxDot { double* out[2]; const double* addx[2]; const double* st[2]; d
 __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
                                                      const double* __restrict__ scal_base, const double* __restrict__ mave,
                                                      const double* __restrict__ msig, double inv_sqrt_n, FinAtxDot a, double tau,
-                                                     double gam2, int ppk, int64_t nkb, int64_t skL) {
+                                                     double gam2, int ppk, int64_t nkb, int64_t skL, int64_t piv) {
     __shared__ double sh[4];
     const int v = blockIdx.y, p0 = 2 * a.pv[v];
     const double* st = a.st[v];
@@ -1136,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
     double s = 0.0;
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
         long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
-        const int np = pieces_of(m, ksplit, nkb, skL);
+        const int np = pieces_of(m, ksplit, nkb, skL, 8, piv);
         for (int ks = 0; ks < np; ks++) {
             const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
             const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
@@ -1172,7 +1192,7 @@ struct FinAx { double* out[2]; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
-                                                int64_t nkb, int64_t skL, int qshift) {
+                                                int64_t nkb, int64_t skL, int qshift, int64_t piv) {
     // the streaming kernel has already added the r'.c and miss.e products: one plane per vector and piece, ppk = number of
     // vectors of the pass (1: MODE 1, 4; 2: MODE 3)
     const int v = blockIdx.y;
@@ -1186,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
         return;
     }
     long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
-    ksplit = pieces_of(n, ksplit, nkb, skL, qshift);
+    ksplit = pieces_of(n, ksplit, nkb, skL, qshift, piv);
     for (int ks = 0; ks < ksplit; ks++) {
         const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
         int4 x0 = px[0], x1 = px[1];
@@ -1208,13 +1228,14 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
                  const gvm::Decomp& d, int nv, const int* go) {
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
-    const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    const int64_t grid = gvm::grid_of(d, nq, nkb);
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
     const int64_t rstride = pl.rstride_n > 0 ? pl.rstride_n : nrg;
 #define GV_LAUNCH_T(SKV, GOV)                                                                                              \
     hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,     \
-                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride)
+                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride, \
+                       (uint32_t)gvm::piv_of(d, nq))
     if (MODE == 4 || !go) {
         if (d.skL > 0) GV_LAUNCH_T(true, false); else GV_LAUNCH_T(false, false);
     } else if constexpr (MODE != 4) {
@@ -1254,7 +1275,7 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     }
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
     const int64_t nq = (nrg + 3) / 4;
-    const int64_t grid = d.skL > 0 ? (nq * nkb + d.skL - 1) / d.skL : nq * d.ks;
+    const int64_t grid = gvm::grid_of(d, nq, nkb);
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     KBounds kb{};
     if (d.skL <= 0) {
@@ -1273,7 +1294,8 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     }
 #define GV_LAUNCH_MV(SKV, GOV)                                                                                             \
     hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,         \
-                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go)
+                       (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go,        \
+                       (uint32_t)gvm::piv_of(d, nq))
     if (MODE == 4 || !go) {            // (the people-statistics plane is never part of a CG step)
         if (d.skL > 0) GV_LAUNCH_MV(true, false); else GV_LAUNCH_MV(false, false);
     } else if constexpr (MODE != 4) {
@@ -1340,7 +1362,7 @@ static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, c
     }
     const int nb = dot_blocks(pl.M);
     hipLaunchKernelGGL(k_fin_atx_dot, dim3(nb, nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL);
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL, piv_of(d, (pl.nrg_m + 3) / 4));
     for (int v = 0; v < nv; v++)
         if (cg.dot_out[v]) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
 }
@@ -1357,7 +1379,7 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
     }
     FinAtx f{{out, nullptr}, {addx, nullptr}};
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 1), dim3(256), 0, s, pl.partial, pl.dm[0].ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2, pl.nkb_m, pl.dm[0].skL);
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 2, pl.nkb_m, pl.dm[0].skL, piv_of(pl.dm[0], (pl.nrg_m + 3) / 4));
 }
 
 // data::ATx of TWO N-vectors in one pass over stripes_m
@@ -1374,7 +1396,7 @@ void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int
     }
     FinAtx f{{outa, outb}, {addxa, addxb}};
     hipLaunchKernelGGL(k_fin_atx, dim3(nblk(pl.M, 256), 2), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4, pl.nkb_m, pl.dm[1].skL);
+                       pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4, pl.nkb_m, pl.dm[1].skL, piv_of(pl.dm[1], (pl.nrg_m + 3) / 4));
 }
 
 // one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
@@ -1387,7 +1409,7 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
         launch_stream<2>(s, q, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
     }
     hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, pl.scal + 4, out4, pl.nkb_m, pl.dm[1].skL);
+                       pl.scal, pl.scal + 4, out4, pl.nkb_m, pl.dm[1].skL, piv_of(pl.dm[1], (pl.nrg_m + 3) / 4));
 }
 
 // operands cv / ev (and cv2 / ev2) -> digit buffers of the Ax side.  Two stripe sets: one vector dig0 = [c | e], two vectors
@@ -1413,7 +1435,7 @@ static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64
                    double* outa, double* outb) {
     FinAx f{{outa, outb}};
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad,
-                       pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8);
+                       pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8, piv_of(d, (pl.nrg_n + 3) / 4));
 }
 
 // ---- data::Ax in two stages: the operands of the whole vector (ax_prep), then the product for a range of row groups

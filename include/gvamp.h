@@ -328,6 +328,8 @@ typedef struct {
     int prio;                /* progress-based wave priority on */
     float taper;             /* uniform split: taper of the segment lengths */
     int tuned;               /* 1 once the pick has been made (measured or read from the cache) */
+    int64_t whole_quads;     /* balanced only, > 0: hybrid -- that many groups of four row groups go one per workgroup over the
+                              * whole K range, only the remaining ones are cut into ranges of balanced_cells cells */
 } gv_decomp_info;
 /* Wall time of the last ingest (gv_upload_bed / gv_upload_bed_file / gv_synth_bed), split into allocating the resident
  * layouts (hipMalloc of 100+ GB: the driver maps and wipes the pages; 0 when the buffers were reused) and filling them. */

@@ -1,0 +1,62 @@
+"""Verdict over the JSON files scripts/first_8gpu.sh leaves: scaling table, the assertions each leg must hold, A/B deltas.
+Exit code 0 = all held (legs skipped for want of GPUs are reported, not failed)."""
+import glob
+import json
+import os
+import sys
+
+
+def load(path):
+    try:
+        txt = [ln for ln in open(path).read().splitlines() if ln.strip().startswith("{")]
+        return json.loads(txt[-1]) if txt else {"failed": "no JSON line"}
+    except (OSError, ValueError) as e:
+        return {"failed": repr(e)}
+
+
+def main(out):
+    bad, rows = [], {}
+    last = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_bench_n1.json")))
+    ref = json.load(open(last[-1]))["value"] if last else None
+    for n in (1, 2, 4, 8):
+        d = load(os.path.join(out, "bench_n%d.json" % n))
+        if "skipped" in d:
+            print("bench --gpus %d: %s" % (n, d["skipped"]))
+            continue
+        if "failed" in d:
+            bad.append("bench --gpus %d: %s" % (n, d["failed"]))
+            continue
+        rows[n] = d
+        if d.get("n_gpus") != n:
+            bad.append("bench --gpus %d reported n_gpus %r" % (n, d.get("n_gpus")))
+        if n > 1 and d.get("multi_gpu", {}).get("rccl_nranks") != n:
+            bad.append("bench --gpus %d: multi_gpu.rccl_nranks = %r" % (n, d.get("multi_gpu", {}).get("rccl_nranks")))
+        if n == 1 and ref and abs(d["value"] / ref - 1) > 0.03:
+            bad.append("1-GPU value %.0f GB/s is more than 3 %% from the committed line %.0f (%s)" % (d["value"], ref, last[-1]))
+    if 1 in rows:
+        print("%-6s %12s %10s %12s %14s" % ("GPUs", "GB/s", "x 1 GPU", "efficiency", "VAMP it/s"))
+        for n, d in sorted(rows.items()):
+            s = d["value"] / rows[1]["value"]
+            print("%-6d %12.0f %10.2f %12.3f %14s" % (n, d["value"], s, s / n, d.get("vamp", {}).get("iters_per_s")))
+    for fam, keys in (("overlap", (0, 2, 4)), ("cgdevice", (0, 1))):
+        vals = {k: load(os.path.join(out, "%s_%d.json" % (fam, k))) for k in keys}
+        if all("value" in v for v in vals.values()):
+            print(fam + ": " + ", ".join("%d -> %.0f GB/s, %s it/s, all-reduce %.3f ms/Ax" % (
+                k, v["value"], v.get("vamp", {}).get("iters_per_s"), v.get("multi_gpu", {}).get("ms_allreduce_per_ax", float("nan")))
+                for k, v in vals.items()))
+        else:
+            print(fam + ": " + ", ".join("%d: %s" % (k, v.get("skipped") or v.get("failed")) for k, v in vals.items() if "value" not in v))
+            bad += ["%s_%d: %s" % (fam, k, v["failed"]) for k, v in vals.items() if "failed" in v]
+    sim = os.path.join(out, "sim_np8.json")
+    if os.path.exists(sim):
+        s = json.load(open(sim))
+        print("gvamp_sim np=8 vs the reference's files:", s)
+        if not s.get("ok"):
+            bad.append("gvamp_sim np=8 does not reproduce tests/golden/survey_probe/sim_np8_*")
+    for b in bad:
+        print("FAILED:", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/first8"))

@@ -312,11 +312,13 @@ def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
         {"GV_KS_M": "4", "GV_KS_N": "3", "GV_TAPER": "0.9"},      # tapered K-segments (long first, short last)
         {"GV_SK_M": "37", "GV_SK_N": "53"},                       # balanced, ranges of >= 8 cells across quad boundaries
         {"GV_SK_M": "768", "GV_SK_N": "1536", "GV_PRIO": "0"},
+        {"GV_HY_M": "2:5", "GV_HY_N": "3:7"},                     # hybrid: 2 / 3 quads whole, the rest in 5 / 7 balanced ranges
+        {"GV_HY_M": "3:768", "GV_HY_N": "1:40", "GV_PRIO": "0"},
         {},                                                       # whatever the on-device autotune picks
     ]
     results = []
     for env in settings:
-        for k in ("GV_AUTOTUNE", "GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_PRIO", "GV_TAPER"):
+        for k in ("GV_AUTOTUNE", "GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_HY_M", "GV_HY_N", "GV_PRIO", "GV_TAPER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -87,7 +87,8 @@ def test_tile_layout_products_bit_identical_to_two_layouts_and_vs_oracle(oracle,
 
 
 @pytest.mark.parametrize("env", [{"GV_KS_M": "1", "GV_KS_N": "1"}, {"GV_KS_M": "3", "GV_KS_N": "5", "GV_TAPER": "0.9", "GV_PRIO": "1"},
-                                 {"GV_SK_M": "768", "GV_SK_N": "768"}, {"GV_SK_M": "97", "GV_SK_N": "1536"}])
+                                 {"GV_SK_M": "768", "GV_SK_N": "768"}, {"GV_SK_M": "97", "GV_SK_N": "1536"},
+                                 {"GV_HY_M": "60:33", "GV_HY_N": "5:11"}, {"GV_HY_M": "1:768", "GV_HY_N": "8:2", "GV_PRIO": "0"}])
 def test_tile_layout_every_decomposition_gives_the_same_bits(env):
     """uniform / tapered / balanced decompositions, with and without wave priority, on a shape with several quads of row groups
     and enough K-steps on both sides"""
@@ -116,6 +117,8 @@ def test_tile_layout_every_decomposition_gives_the_same_bits(env):
             sh.atx2_dev(za, zb, wa, wb)
             got = (z1, w1, zb.download(), wb.download())
             assert all(v["tuned"] for v in sh.decomp().values())
+            if "GV_HY_M" in env:      # the override took: some quads whole, the rest in balanced ranges
+                assert all("whole_quads" in v for v in sh.decomp().values()), sh.decomp()
     finally:
         for k, v in old.items():
             if v is None:
