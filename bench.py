@@ -487,6 +487,11 @@ def main():
     # process on the same box, and checked bit for bit against the two-layout result above --------------------------------
     if a.mode == 1 and layout == 1 and not a.no_tile_leg:
         barrier()
+        # this leg always MEASURES its decompositions (no cache, no shipped table): its tune_s is what a cold first contact with a
+        # shape costs on this box, whatever the main leg found in the cache or in gv_tune_builtin.h
+        cold_env = {k: os.environ.get(k) for k in ("GV_TUNE_CACHE", "GV_TUNE_BUILTIN")}
+        os.environ["GV_TUNE_CACHE"] = "0"
+        os.environ["GV_TUNE_BUILTIN"] = "0"
         with capi.Shard(N, M, Mt=Mt, S=S, device=local_rank) as st:
             st.set_layout(False, 2)
             st.set_kernel_mode(1)
@@ -533,6 +538,11 @@ def main():
                 "atx": {"avg_ms": round(m_atx, 4), "GBps": round(shard_bytes / (m_atx * 1e-3) / 1e9, 1) if m_atx > 0 else None},
                 "bit_identical_to_two_layouts": same, "ingest_s": round(t_in, 2), "tune_s": round(tt_s, 3), "tune_source": tt_src,
                 "decomposition": st.decomp()}
+        for k, v in cold_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

@@ -519,10 +519,10 @@ class Shard:
         return a.value, f.value
 
     def tune_info(self):
-        """(seconds spent picking the decompositions, source: 'pending' / 'model' / 'measured' / 'cache' / 'fixed')"""
+        """(seconds spent picking the decompositions, source: 'pending' / 'model' / 'measured' / 'cache' / 'fixed' / 'builtin')"""
         sec, src = C.c_double(), C.c_int()
         self._ck(self.L.gv_tune_info(self.h, C.byref(sec), C.byref(src)))
-        return sec.value, {-1: "pending", 0: "model", 1: "measured", 2: "cache", 3: "fixed"}[src.value]
+        return sec.value, {-1: "pending", 0: "model", 1: "measured", 2: "cache", 3: "fixed", 4: "builtin"}[src.value]
 
     def decomp(self):
         """work decomposition per streaming-kernel class (gv_get_decomp)"""

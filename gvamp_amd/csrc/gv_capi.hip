@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include "gv_internal.h"
+#include "gv_tune_builtin.h"
 
 namespace gvi {
 
@@ -449,6 +450,23 @@ static bool tune_cache_load(gv_ctx* c) {
     if (!c->ks_fixed_n) { c->plan.dn[0] = got[2]; c->plan.dn[1] = got[3]; }
     return true;
 }
+// picks shipped in-tree for this very build of the kernels (gv_tune_builtin.h); GV_TUNE_BUILTIN=0 ignores them
+static bool tune_builtin_load(gv_ctx* c) {
+    const char* on = getenv("GV_TUNE_BUILTIN");
+    if ((on && atoi(on) == 0) || strcmp(GV_BUILTIN_FOR_HASH, GV_KERNEL_SRC_HASH) != 0) return false;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0 || pr.multiProcessorCount != 256) return false;
+    for (const BuiltinPick& b : GV_BUILTIN_PICKS) {
+        if (b.N != c->N || b.M != c->M || b.layout != c->plan.layout || b.N == 0) continue;
+        for (int k = 0; k < 4; k++)
+            if (!decomp_ok(c, b.d[k], k >> 1)) return false;
+        if (!c->ks_fixed_m) { c->plan.dm[0] = b.d[0]; c->plan.dm[1] = b.d[1]; }
+        if (!c->ks_fixed_n) { c->plan.dn[0] = b.d[2]; c->plan.dn[1] = b.d[3]; }
+        return true;
+    }
+    return false;
+}
 static void tune_cache_store(gv_ctx* c) {
     const std::string path = tune_cache_file(), key = tune_key(c);
     if (path.empty() || key.empty() || c->ks_fixed_m || c->ks_fixed_n) return;   // overrides are not picks
@@ -488,6 +506,7 @@ int autotune_ks(gv_ctx* c) {
     c->tune_source = 0;
     if ((c->ks_fixed_m && c->ks_fixed_n) || !c->have_stripes || c->M <= 0 || !c->have_stats) { c->tune_source = 3; return 0; }
     if (tune_cache_load(c)) { c->tune_source = 2; return 0; }
+    if (tune_builtin_load(c)) { c->tune_source = 4; return 0; }
     const auto wall0 = std::chrono::steady_clock::now();
     gvm::Plan& pl = c->plan;
     double *xm = nullptr, *wm = nullptr, *wm2 = nullptr, *pn = nullptr, *zn = nullptr, *zn2 = nullptr;

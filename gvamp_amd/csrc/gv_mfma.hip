@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
     if (tile * 16 >= M) return;
     const int64_t rg = tile >> 2, i = tile & 3;
     uint32_t n2 = 0, n1 = 0, n0 = 0;
-    for (int64_t kb = 0; kb < nkb; kb++) {
-        uint4 v = stripes[(rg * nkb + kb) * 256 + i * 64 + lane];
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    auto count = [&](const v4u& v, int64_t kb) {
         const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
         uint32_t ws[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -111,7 +111,17 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
             n1 += __popc(~hi & lo & pm);
             n0 += __popc(~hi & ~lo & pm);
         }
+    };
+    // four K-blocks per trip: 4 KiB of independent non-temporal loads in flight per wave (one load at a time streamed the shard
+    // at 4.5 TB/s where the matvec kernels reach 6.6)
+    const v4u* src = reinterpret_cast<const v4u*>(stripes) + rg * nkb * 256 + i * 64 + lane;
+    int64_t kb = 0;
+    for (; kb + 4 <= nkb; kb += 4) {
+        const v4u v0 = __builtin_nontemporal_load(src + (kb + 0) * 256), v1 = __builtin_nontemporal_load(src + (kb + 1) * 256),
+                    v2 = __builtin_nontemporal_load(src + (kb + 2) * 256), v3 = __builtin_nontemporal_load(src + (kb + 3) * 256);
+        count(v0, kb); count(v1, kb + 1); count(v2, kb + 2); count(v3, kb + 3);
     }
+    for (; kb < nkb; kb++) count(__builtin_nontemporal_load(src + kb * 256), kb);
     // sum over the 4 lanes (g) that share row r
     n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
     n1 += __shfl_xor(n1, 16, 64); n1 += __shfl_xor(n1, 32, 64);

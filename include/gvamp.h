@@ -337,8 +337,10 @@ int gv_ingest_info(gv_ctx* ctx, double* alloc_seconds, double* fill_seconds);
 int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
 /* How the picks were made: *source = -1 not yet (the first matvec in kernel mode 1 makes them), 0 the cost model's first
  * candidate (tuning impossible), 1 measured on the device now (*seconds of wall time), 2 read from the cache an earlier run on
- * the same (device, N, M) left ($GV_TUNE_CACHE_DIR, $XDG_CACHE_HOME/gvamp_amd or ~/.cache/gvamp_amd; GV_TUNE_CACHE=0
- * disables it), 3 fixed by an override.  Picks never change results (exact integer accumulation). */
+ * the same (device, N, M, kernel sources) left ($GV_TUNE_CACHE_DIR, $XDG_CACHE_HOME/gvamp_amd or ~/.cache/gvamp_amd;
+ * GV_TUNE_CACHE=0 disables it), 3 fixed by an override, 4 taken from the table shipped with the library for the shapes of
+ * BASELINE.json and the per-GPU shards of the headline job on an MI355X (gv_tune_builtin.h; GV_TUNE_BUILTIN=0 ignores it).
+ * Picks never change results (exact integer accumulation). */
 int gv_tune_info(gv_ctx* ctx, double* seconds, int* source);
 /* device copy bandwidth probe: copies nbytes device->device `reps` times, returns GB/s (read+write bytes) */
 int gv_copy_bandwidth(gv_ctx* ctx, size_t nbytes, int reps, double* gbps);

@@ -72,6 +72,18 @@ def test_defaults_of_the_c_abi_are_the_measured_engine():
     assert re.search(r"bool want_raw = false, want_stripes = true;", txt) and re.search(r"bool want_auto = true;", txt)
 
 
+def test_shipped_tuning_table_belongs_to_the_current_kernels():
+    """gv_tune_builtin.h records the hash of the streaming-kernel sources it was measured on; the library ignores a table whose
+    hash differs (it then measures), but a stale table in the tree means scripts/tune_table.py has to run again on an MI355X."""
+    from gvamp_amd import build
+    txt = open(os.path.join(ROOT, "gvamp_amd", "csrc", "gv_tune_builtin.h")).read()
+    h = re.search(r'GV_BUILTIN_FOR_HASH = "([0-9a-f]+|none)"', txt).group(1)
+    assert h in ("none", build.kernel_src_hash()[:16]), "re-run scripts/tune_table.py: the kernels changed after the table was measured"
+    if h != "none":
+        rows = re.findall(r"^    \{(\d+), (\d+), ([01]), ", txt, flags=re.M)
+        assert ("400000", "1000000", "0") in rows and ("400000", "125000", "0") in rows and ("100000", "500000", "0") in rows
+
+
 def test_no_cpu_fallback(built):
     """Without a HIP device the product fails loudly (with a GPU present it simply works)."""
     from gvamp_amd import capi

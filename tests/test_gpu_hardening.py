@@ -235,6 +235,47 @@ print(json.dumps(out))
     assert len(open(tmp_path / "cache" / "decomp.txt").read().splitlines()) == 2
 
 
+def test_shipped_picks_cover_the_baseline_shapes(tmp_path):
+    """gv_tune_builtin.h: on the shapes BASELINE.json names (config 1 here: N=2000 x M=10000) a cold run -- no cache -- takes its
+    decompositions from the table shipped with the library instead of measuring (gv_tune_info source "builtin", 0 s);
+    GV_TUNE_BUILTIN=0 measures; the cache wins over the table; the bits are the same either way."""
+    import json
+    import re
+    import sys
+    from gvamp_amd import build
+    txt = open(os.path.join(ROOT, "gvamp_amd", "csrc", "gv_tune_builtin.h")).read()
+    if re.search(r'GV_BUILTIN_FOR_HASH = "([0-9a-f]+|none)"', txt).group(1) != build.kernel_src_hash()[:16]:
+        pytest.skip("gv_tune_builtin.h was measured for other kernel sources (scripts/tune_table.py regenerates it on an MI355X)")
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from gvamp_amd import capi
+out = {}
+for stripes in (1, 2):
+    with capi.Shard(2000, 10000) as sh:
+        sh.set_layout(False, stripes)
+        sh.synth_bed(5, 5000)
+        sh.compute_markers_statistics()
+        z = sh.Ax(np.ones(10000))
+        sec, src = sh.tune_info()
+        out[str(stripes)] = {"src": src, "sec": sec, "norm": float(np.linalg.norm(z))}
+print(json.dumps(out))
+""" % ROOT
+    def run(**extra):
+        env = dict(os.environ, GV_TUNE_CACHE_DIR=str(tmp_path / "cache"), **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    cold = run(GV_TUNE_CACHE="0")
+    assert all(cold[k]["src"] == "builtin" and cold[k]["sec"] == 0 for k in ("1", "2")), cold
+    meas = run(GV_TUNE_CACHE="0", GV_TUNE_BUILTIN="0")
+    assert all(meas[k]["src"] == "measured" for k in ("1", "2"))
+    assert all(meas[k]["norm"] == cold[k]["norm"] for k in ("1", "2"))
+    run(GV_TUNE_BUILTIN="0")                                        # measures and fills the cache ...
+    assert run()["1"]["src"] == "cache"                             # ... which is consulted before the table
+
+
 @pytest.mark.parametrize("stripes", [1, 2])
 def test_bed_file_slab_equals_upload_from_memory_and_a_short_file_fails_loudly(tmp_path, stripes):
     """read_genotype_data (data.cpp:201-234): a rank's slab at byte offset 3 + S*mbytes of the .bed, streamed through the
