@@ -171,3 +171,30 @@ def test_tile_layout_halves_the_resident_bytes_and_mode0_still_needs_raw_rows():
             sh.Ax(np.ones(M))
         with pytest.raises(capi.GvError):
             sh.set_layout(False, 4)
+
+
+def test_reingest_under_the_automatic_choice_keeps_the_resident_layout():
+    """gv_set_layout(.., 3) decides at the FIRST ingest; a later ingest on the same context (bench.py's LD leg, any second upload)
+    keeps the layout that is resident -- a context that had to take the tile layout because two stripe sets did not fit must not
+    tear it down and try the two stripe sets again.  Both directions, results unchanged."""
+    N, M = 3000, 4096
+    bed, bed2 = synth.synth_bed(N, M, seed=1), synth.synth_bed(N, M, seed=2)
+    x = np.random.default_rng(0).standard_normal(M)
+    for first in (2, 1):
+        with capi.Shard(N, M) as sh:
+            sh.set_layout(False, first)
+            sh.upload_bed(bed)
+            sh.compute_markers_statistics()
+            z1 = sh.Ax(x)
+            assert sh.get_layout() == first
+            sh.set_layout(False, 3)                 # automatic from here on: plenty of free HBM, it would pick two stripe sets
+            sh.upload_bed(bed2)
+            assert sh.get_layout() == first
+            sh.compute_markers_statistics()
+            z2 = sh.Ax(x)
+            sh.upload_bed(bed)
+            sh.compute_markers_statistics()
+            assert np.array_equal(sh.Ax(x), z1) and not np.array_equal(z2, z1)
+    with capi.Shard(N, M) as sh:                    # nothing configured: the automatic choice, two stripe sets at this size
+        sh.upload_bed(bed)
+        assert sh.get_layout() == 1 and sh.get_kernel_mode() == 1
