@@ -300,3 +300,14 @@ def test_host_exceptions_stop_at_the_c_boundary():
             hostapi.infere_linear(sh, np.zeros(N), None, None, iterations=1)
         r = hostapi.infere_linear(sh, np.random.default_rng(0).standard_normal(N), [0.9, 0.1], [0, 0.01], iterations=1)   # still usable
         assert r.niter == 1
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() is what the driver runs on the GPU box before the bench: it must keep working whatever the
+    library's defaults are (round 3 changed them under it)."""
+    import importlib
+    sys_path_added = ROOT not in __import__("sys").path
+    if sys_path_added:
+        __import__("sys").path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
