@@ -164,11 +164,14 @@ void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);   // ordered sum of block partials
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
-                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride);
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
+                const double* other_st = nullptr, const int* ride_report = nullptr);
+void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride);
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
               double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc = nullptr,
-              const double* at_p = nullptr, int64_t m = 0);
+              const double* at_p = nullptr, int64_t m = 0, const double* other_st = nullptr, int* go = nullptr,
+              const int* ride = nullptr);
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,

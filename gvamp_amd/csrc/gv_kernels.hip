@@ -639,8 +639,12 @@ __global__ __launch_bounds__(256) void k_aat_ab(double* __restrict__ st, double*
 }
 // beta, <r,z>, ||r|| / ||v|| and its trace, the 1e-4 stopping rule (:98-120); status -> host mailbox (slot seq & 1, system 0).
 // ST_NORMV holds ||v||^2 for this solver (the reference takes the square root of the ratio, :113-114).
+// other_st / go (may be NULL): the joint solver's pipelined loop (gv_cg_solve_aat2w) -- *go = this system or the M-space system
+// behind other_st is still running: passes enqueued after both have finished are dropped on the device.  ride (may be NULL):
+// reported in status word 7 (1 rider pending, 2 rode).
 __global__ void k_aat_decide(double* __restrict__ st, const double* __restrict__ red, double* __restrict__ relres, int max_iter,
-                             double* mailbox, unsigned long long* flag, unsigned long long seq) {
+                             double* mailbox, unsigned long long* flag, unsigned long long seq, const double* other_st, int* go,
+                             const int* ride) {
     if (threadIdx.x == 0) {
         if (st[gvm::ST_ACTIVE] != 0.0) {
             const int iters = (int)st[gvm::ST_ITERS] + 1;
@@ -661,7 +665,8 @@ __global__ void k_aat_decide(double* __restrict__ st, const double* __restrict__
             st[gvm::ST_STEPPED] = 0.0;
         double* mb = mailbox + (seq & 1ull) * (2 * 8);
         mb[0] = st[gvm::ST_ACTIVE]; mb[1] = st[gvm::ST_ITERS]; mb[2] = st[gvm::ST_CONV]; mb[3] = st[gvm::ST_RELERR];
-        mb[4] = 0.0; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED]; mb[7] = 0.0;
+        mb[4] = 0.0; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED]; mb[7] = ride ? (double)*ride : 0.0;
+        if (go) *go = (st[gvm::ST_ACTIVE] != 0.0 || (other_st && other_st[gvm::ST_ACTIVE] != 0.0)) ? 1 : 0;
         __threadfence_system();
         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -685,10 +690,16 @@ __global__ void k_ride_copy(double* __restrict__ out, const double* __restrict__
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[i];
 }
+// the rider rode in the pass just made if it was pending and exactly one of the two systems had finished before that pass (the
+// flags still say so: the step kernels that may change them come behind this launch)
+__global__ void k_ride_mark(const double* __restrict__ st0, const double* __restrict__ st1, int* __restrict__ ride) {
+    if (threadIdx.x == 0 && *ride == 1 && ((st0[gvm::ST_ACTIVE] != 0.0) != (st1[gvm::ST_ACTIVE] != 0.0))) *ride = 2;
+}
 // The scalar part of a CG step (vamp.cpp:1174-1223) for every system, on the device: iteration count, Onsager rule, beta,
 // <r,z>, relative residual and its trace, stopping rules; then *go = some system is still running, and the status of every
 // system goes to the host mailbox (slot = seq & 1: the host reads status s while the device may already write s + 1).
-struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; int* ride; };
+struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; int* ride;
+                   const double* other_st; const int* ride_report; };   // other_st: a system stepped elsewhere that also keeps *go up
 constexpr int CGX_STATUS = 8;   // doubles per system in the mailbox: active, iters, converged, rel_err, onsager, n_relres, stepped
 __global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
                              unsigned long long* flag, unsigned long long seq) {
@@ -741,12 +752,12 @@ __global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __rest
         double* mb = mailbox + (seq & 1ull) * (2 * CGX_STATUS) + v * CGX_STATUS;
         mb[0] = st[gvm::ST_ACTIVE]; mb[1] = st[gvm::ST_ITERS]; mb[2] = st[gvm::ST_CONV]; mb[3] = st[gvm::ST_RELERR];
         mb[4] = st[gvm::ST_ONS]; mb[5] = st[gvm::ST_NRELRES]; mb[6] = st[gvm::ST_STEPPED];
-        mb[7] = a.ride ? (double)*a.ride : 0.0;
+        mb[7] = a.ride ? (double)*a.ride : (a.ride_report ? (double)*a.ride_report : 0.0);
     }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        *go = any;
+        *go = (any || (a.other_st && a.other_st[gvm::ST_ACTIVE] != 0.0)) ? 1 : 0;
         __threadfence_system();
         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1112,7 +1123,8 @@ void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
               double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
-              unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m) {
+              unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m, const double* other_st,
+              int* go, const int* ride) {
     const int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, partial);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, red);
@@ -1120,7 +1132,7 @@ void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, doubl
     // A^T mu += alpha A^T p (at_p = the first half of this application), before k_aat_decide may clear ST_ACTIVE
     if (at_acc && m > 0) hipLaunchKernelGGL(k_axpy_st, dim3(nblk(m, 256)), dim3(256), 0, s, at_acc, at_p, st, m);
     hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, red + 2);
-    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq);
+    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq, other_st, go, ride);
     hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);
 }
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
@@ -1128,11 +1140,17 @@ void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, c
     if (n <= 0) return;
     hipLaunchKernelGGL(k_ride_copy, dim3(nblk(n, 256)), dim3(256), 0, s, out, w0, w1, st0, st1, ride, n);
 }
+void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride) {
+    hipLaunchKernelGGL(k_ride_mark, dim3(1), dim3(64), 0, s, st0, st1, ride);
+}
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
-                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride) {
+                int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
+                const double* other_st, const int* ride_report) {
     CgxDecide a{};
     a.nsys = nsys;
     a.ride = ride;
+    a.other_st = other_st;
+    a.ride_report = ride_report;
     for (int k = 0; k < nsys; k++) { a.st[k] = st[k]; a.red[k] = red[k]; a.relres[k] = relres[k]; }
     hipLaunchKernelGGL(k_cgx_decide, dim3(1), dim3(64), 0, s, a, gam2, max_iter, go, mailbox, flag, seq);
 }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     // the rider takes the slot of the one system that has finished (uniform over the launch: nothing changes these flags
     // between the k_cgx_decide of the previous step and the one of this step)
     if (a.ride && *a.ride == 1 && st && st[gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) x = a.alt_x;
-    const bool upd = st && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;
+    const bool upd = st && a.pw[v] && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;   // (a slot may name a state for the rider's sake only)
     const double beta = upd ? st[gvm::ST_BETA] : 0.0;
     const double* zz = a.z[v];
     double* pw = a.pw[v];

@@ -979,7 +979,160 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         };
         b_post();
 
+        const char* pe = getenv("GV_AAT_PIPELINE");
+        const bool pipe_on = !(pe && atoi(pe) == 0);
+        bool pipelined = false;
         for (;;) {
+            // ---- the steady state, enqueued ahead of its statuses (GV_AAT_PIPELINE=0: the host-paced loop below only) -------------
+            // Once both systems are stepping and share their passes -- X: an ATx pass carrying the first half of Q_A (A^T p_a) and the
+            // second half of Q_B; Y: an Ax pass carrying the second half of Q_A and the first half of Q_B -- nothing the host does
+            // between two passes depends on a scalar except WHICH systems are still running.  So the host enqueues pass k + 1 and its
+            // step kernels before it has read the status of the step behind pass k (one mailbox slot per parity, as cg_run_device):
+            // the device never waits for a launch, whatever the host's launch rate (profiles/r3_cfg5_*.txt: 26 waits of 15-40 us per
+            // three iterations on a fast host, every small-kernel section host-paced on a slow one).  What speculation costs:
+            //   * a system that finished at step k still has its next first half in the pass enqueued meanwhile: a wasted SLOT of a
+            //     two-vector pass (free) whose step kernels return on the system's ACTIVE flag; products and passes are counted as the
+            //     host-paced loop would have made them (the wasted slots and the dropped passes are taken back below);
+            //   * a pass enqueued after BOTH had finished is dropped on the device (*go == 0: the k_aat_decide / k_cgx_decide of the
+            //     two systems keep the flag together);
+            //   * the rider (z1 = A x1_hat) wants the slot a finished system leaves in an Ax pass, in the very pass the host-paced
+            //     loop would have used -- one pass before the host knows: it is placed on the device (gvm::CgHook::ride, as in
+            //     cg_run_device), every Ax pass keeps both slots while it is pending.
+            // Per system the kernels, their order and their operands are those of the loop below: bit-identical results.
+            {
+                // (a pass or two of the host-paced loop come first: the right-hand side of solve a, and one pass that aligns the two
+                // systems when they start half an application apart)
+                if (!pipelined && dev && pipe_on && at_acc && max_iter > 0 && !hr.pending && a_phase == 1 && ha.pending && hb.pending &&
+                    sb.active && !ha.one_half && !hb.one_half && ha.kind() == hb.kind()) {
+                    pipelined = true;
+                    double* stA = c->cgx_state;
+                    double* stB = c->cgx_state + gvm::ST_SIZE;
+                    unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
+                    int* pin_go = reinterpret_cast<int*>(c->cgx_pin + 2 * gvm::ST_SIZE);
+                    int* d_ride = c->cgx_go + 1;
+                    bool ride_pending = hz.pending;
+                    pin_go[0] = 1;
+                    pin_go[1] = ride_pending ? 1 : 0;
+                    MIX_HIP(hipMemcpyAsync(c->cgx_go, pin_go, 2 * sizeof(int), hipMemcpyHostToDevice, s));
+                    MIX_HIP(hipStreamSynchronize(s));          // (the pinned words are reused by the next call)
+                    struct PassRec { int kind; bool slotA, slotB; };
+                    struct StepRec { int sys; unsigned long long seq; int after_pass; };
+                    std::vector<PassRec> passes;
+                    std::vector<StepRec> steps;
+                    size_t applied = 0;                         // statuses read so far
+                    bool hostA = true, hostB = true, rode = false;
+                    int endA = -1, endB = -1;                   // index of the pass whose step finished the system
+                    const int itersA0 = a_iters;
+                    bool b_first_capture = sb.iters == 0;       // its first application delivers A^T A v_b (cg_capture_first_product)
+                    auto apply = [&](const StepRec& r, const CgxStatus& stt) {
+                        if (r.sys == 0) {
+                            a_iters = (int)stt.iters; a_rel = stt.rel; a_nrel = (int)stt.nrel;
+                            if (stt.active == 0.0 && hostA) { hostA = false; a_conv = (int)stt.conv; endA = r.after_pass; }
+                        } else {
+                            sb.iters = (int)stt.iters; sb.converged = (int)stt.conv; sb.onsager = stt.ons; sb.n_relres = (int)stt.nrel;
+                            sb.rel_err = stt.rel;
+                            if (stt.active == 0.0 && hostB) { hostB = false; sb.active = false; endB = r.after_pass; }
+                        }
+                        if (stt.ride == 2.0 && ride_pending) { ride_pending = false; rode = true; }
+                    };
+                    int kind = ha.kind();                       // 1: X (ATx), 0: Y (Ax)
+                    const int64_t ax0p = c->cnt.n_ax, atx0p = c->cnt.n_atx, axp0 = c->cnt.n_ax_pass, atxp0 = c->cnt.n_atx_pass;
+                    while (hostA || hostB) {
+                        // both slots are kept while the rider waits for one (Ax passes); otherwise the slots of the systems the host
+                        // believes running
+                        const bool slotA = hostA || (kind == 0 && ride_pending), slotB = hostB || (kind == 0 && ride_pending);
+                        gvm::CgHook hk;
+                        hk.go = c->cgx_go;
+                        const int iB = slotA ? 1 : 0;           // B's slot index in the pass
+                        if (kind == 1) {                        // X: MA = A^T p_a | d_b = tau A^T w + gam2 p_b, <d_b, p_b>
+                            if (slotB) { hk.state[iB] = stB; hk.dot_part[iB] = c->red_partial; hk.dot_out[iB] = c->red_out; }
+                            if (slotA && slotB) MIX_TRY(atx2_device(c, p, c->w_n->d, MA->d, sb.d, nullptr, sb.p, tau, gam2, &hk));
+                            else if (slotA) MIX_TRY(atx_device(c, p, MA->d, nullptr, tau, gam2, &hk));
+                            else MIX_TRY(atx_device(c, c->w_n->d, sb.d, sb.p, tau, gam2, &hk));
+                            passes.push_back(PassRec{1, slotA, slotB});
+                            if (slotB && hostB) {
+                                if (b_first_capture) { cg_capture_first_product(c, sb, tau, gam2, diag_b); b_first_capture = false; }
+                                if (multi && comm_allreduce(c, c->red_out, 8)) { rc = 1; goto done; }
+                                double *a_st[1] = {stB}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z}, *a_part[1] = {c->red_partial},
+                                       *a_red[1] = {c->red_out};
+                                const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out};
+                                gvk::cgx_ab(s, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag_b, M);
+                                if (multi && comm_allreduce(c, c->red_out, 8)) { rc = 1; goto done; }
+                                const double* c_red[1] = {c->red_out};
+                                double* c_rel[1] = {sb.relres ? c->cgx_rel + c->cgx_relcap : nullptr};
+                                const unsigned long long seq = ++c->mbox_seq;
+                                gvk::cgx_decide(s, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq, nullptr, stA, d_ride);
+                                MIX_HIP(hipGetLastError());
+                                steps.push_back(StepRec{1, seq, (int)passes.size() - 1});
+                            }
+                        } else {                                // Y: d_a = A MA | w_n = A p_b (p_b <- z_b + beta p_b on the way in)
+                            if (slotA) hk.state[0] = stA;       // (for the rider's sake: no search direction to advance in this slot)
+                            if (slotB) { hk.state[iB] = stB; hk.p[iB] = sb.p; hk.z[iB] = sb.z; }
+                            if (ride_pending && slotA && slotB) { hk.ride = d_ride; hk.alt_x = wm->ride_x->d; }
+                            if (slotA && slotB) MIX_TRY(ax2_device(c, MA->d, sb.p, d, c->w_n->d, &hk));
+                            else if (slotA) MIX_TRY(ax_device(c, MA->d, d, &hk));
+                            else MIX_TRY(ax_device(c, sb.p, c->w_n->d, &hk));
+                            passes.push_back(PassRec{0, slotA, slotB});
+                            if (ride_pending && slotA && slotB) {
+                                gvk::ride_copy(s, wm->ride_out->d, d, c->w_n->d, stA, stB, d_ride, n);
+                                gvk::ride_mark(s, stA, stB, d_ride);
+                            }
+                            if (slotA && hostA) {
+                                const unsigned long long seq = ++c->mbox_seq;
+                                gvk::aat_step(s, stA, mu, p, r, d, z, DG->d, tau, gam2, n, c->red_partial, c->red_out + 16,
+                                              relres_a ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, flag_dev, seq, at_acc, MA->d, M, stB,
+                                              c->cgx_go, d_ride);
+                                MIX_HIP(hipGetLastError());
+                                steps.push_back(StepRec{0, seq, (int)passes.size() - 1});
+                            }
+                        }
+                        kind = 1 - kind;
+                        // the status of everything but the step just enqueued
+                        while (applied + 1 < steps.size()) {
+                            CgxStatus s2[2];
+                            MIX_TRY(cgx_wait(c, steps[applied].seq, s2));
+                            apply(steps[applied], s2[0]);
+                            applied++;
+                        }
+                    }
+                    while (applied < steps.size()) {            // drain (a dropped step republishes the unchanged state)
+                        CgxStatus s2[2];
+                        MIX_TRY(cgx_wait(c, steps[applied].seq, s2));
+                        apply(steps[applied], s2[0]);
+                        applied++;
+                    }
+                    // ---- accounting: what the host-paced loop would have counted.  A pass after the one whose step finished the
+                    // LAST system was dropped on the device; a slot of a system in a pass after the one that finished it was wasted
+                    // (unless the rider took it: it rode in the first Ax pass in which exactly one system had finished).
+                    {
+                        const int last_useful = endA > endB ? endA : endB;
+                        int64_t d_ax = 0, d_atx = 0, d_axp = 0, d_atxp = 0;
+                        bool rider_slot_found = false;
+                        for (int i = 0; i < (int)passes.size(); i++) {
+                            const PassRec& q = passes[i];
+                            const int nslots = (q.slotA ? 1 : 0) + (q.slotB ? 1 : 0);
+                            if (i > last_useful) {              // dropped entirely
+                                (q.kind ? d_atx : d_ax) += nslots;
+                                (q.kind ? d_atxp : d_axp) += 1;
+                                continue;
+                            }
+                            int wasted = 0;
+                            if (q.slotA && endA >= 0 && i > endA) wasted++;
+                            if (q.slotB && endB >= 0 && i > endB) wasted++;
+                            if (wasted && rode && !rider_slot_found && q.kind == 0 && wasted == 1 && nslots == 2) { rider_slot_found = true; wasted--; }
+                            (q.kind ? d_atx : d_ax) += wasted;
+                        }
+                        c->cnt.n_ax -= d_ax; c->cnt.n_atx -= d_atx; c->cnt.n_ax_pass -= d_axp; c->cnt.n_atx_pass -= d_atxp;
+                        (void)ax0p; (void)atx0p; (void)axp0; (void)atxp0; (void)itersA0;
+                    }
+                    a_phase = 3;
+                    ha.pending = false;
+                    hb.pending = false;
+                    sb.active = false;
+                    if (rode) hz.pending = false;
+                }
+            }
+
             HalfOp* todo[2];
             int nt = 0;
             // up to two pending half-applications of the same kind share a pass.  Priority: the right-hand side of solve a,
