@@ -644,8 +644,10 @@ __global__ __launch_bounds__(256) void k_aat_ab(double* __restrict__ st, double*
 // reported in status word 7 (1 rider pending, 2 rode).
 __global__ void k_aat_decide(double* __restrict__ st, const double* __restrict__ red, double* __restrict__ relres, int max_iter,
                              double* mailbox, unsigned long long* flag, unsigned long long seq, const double* other_st, int* go,
-                             const int* ride) {
+                             const int* ride, int* ride_mark) {
     if (threadIdx.x == 0) {
+        // the rider rode in the Ax pass just made if it was pending and exactly one system had finished before it (flags unchanged yet)
+        if (ride_mark && *ride_mark == 1 && other_st && ((st[gvm::ST_ACTIVE] != 0.0) != (other_st[gvm::ST_ACTIVE] != 0.0))) *ride_mark = 2;
         if (st[gvm::ST_ACTIVE] != 0.0) {
             const int iters = (int)st[gvm::ST_ITERS] + 1;
             st[gvm::ST_ITERS] = (double)iters;
@@ -1124,7 +1126,7 @@ void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
               double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m, const double* other_st,
-              int* go, const int* ride) {
+              int* go, const int* ride, int* ride_mark) {
     const int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, partial);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, red);
@@ -1132,7 +1134,7 @@ void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, doubl
     // A^T mu += alpha A^T p (at_p = the first half of this application), before k_aat_decide may clear ST_ACTIVE
     if (at_acc && m > 0) hipLaunchKernelGGL(k_axpy_st, dim3(nblk(m, 256)), dim3(256), 0, s, at_acc, at_p, st, m);
     hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, red + 2);
-    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq, other_st, go, ride);
+    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq, other_st, go, ride, ride_mark);
     hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);
 }
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,

@@ -42,6 +42,7 @@ struct CgHook {
     // step late); the product lands in that slot's output, k_ride_copy moves it out and k_cgx_decide sets *ride = 2.
     const int* ride = nullptr;
     const double* alt_x = nullptr;
+    double* ride_out = nullptr;              // != NULL: the Ax epilogue writes the rider's product there itself (no k_ride_copy)
     double* dot_part[2] = {nullptr, nullptr};
     double* dot_out[2] = {nullptr, nullptr};
 };

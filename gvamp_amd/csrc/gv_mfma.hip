@@ -229,11 +229,12 @@ constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per v
 // CG hook (device-resident CG): x is the search direction p of system st; when that system took a step and is still
 // running, p <- z + beta p (vamp.cpp:1209-1210) happens here, on the way into the operands, instead of in a launch of its own.
 struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2];
-                const int* ride; const double* alt_x; };
+                const int* ride; const double* alt_x; const int* go; };
 __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
                                                  int64_t M, double* __restrict__ partial, double* __restrict__ scal,
                                                  unsigned int* __restrict__ counters) {
     __shared__ double shm[256], shs[256];
+    if (a.go && *a.go == 0) return;      // a pass enqueued after every system had finished: dropped (as its streaming kernel is)
     const int v = blockIdx.y;
     const double* x = a.x[v];
     double* __restrict__ cv = a.cv[v];
@@ -296,10 +297,11 @@ __global__ __launch_bounds__(256) void k_prep_people(int kind, const double* __r
     if (last_block(partial, mx, s, counters, shm, shs)) prep_final(partial, gridDim.x, scal, shm, shs);
 }
 // ATx operand p: block partials [0] = max|p|, [1] = sum p.  blockIdx.y = vector.
-struct PrepAtx { const double* p[2]; };
+struct PrepAtx { const double* p[2]; const int* go; };
 __global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* __restrict__ partial, double* __restrict__ scal,
                                                   unsigned int* __restrict__ counters) {
     __shared__ double shm[256], shs[256];
+    if (a.go && *a.go == 0) return;
     const int v = blockIdx.y;
     const double* __restrict__ p = a.p[v];
     double mx = 0.0, s = 0.0;
@@ -1198,7 +1200,9 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
 }
 
 // data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
-struct FinAx { double* out[2]; };
+// ride / st / ride_out (gvm::CgHook::ride_out): the slot the rider took on the way in (k_prep_ax, same test on the same flags)
+// delivers its product straight into ride_out
+struct FinAx { double* out[2]; const int* ride; const double* st[2]; double* ride_out; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
@@ -1208,6 +1212,9 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     const int v = blockIdx.y;
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
+    if (a.ride_out && a.ride && *a.ride == 1 && a.st[v] && a.st[v][gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] &&
+        a.st[1 - v][gvm::ST_ACTIVE] != 0.0)
+        out = a.ride_out;
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= npad) return;
     const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
@@ -1347,9 +1354,10 @@ static int prep_blocks(int64_t n) {
 }
 
 // vector preparation of one (nv = 1) or two (nv = 2) N-vectors: scal[4v..] and the digit columns 8v.. of dig0
-static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, double* red_partial) {
+static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, double* red_partial,
+                           const int* go = nullptr) {
     const int nv = pb ? 2 : 1, nb = prep_blocks(npad);
-    PrepAtx pa_{{pa, pb}};
+    PrepAtx pa_{{pa, pb}, go};
     hipLaunchKernelGGL(k_prep_atx, dim3(nb, nv), dim3(256), 0, s, pa_, npad, red_partial, pl.scal, pl.counters);
     QuantArgs q{};
     q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
@@ -1379,7 +1387,7 @@ static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, c
 
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
          double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2, const CgHook* cg) {
-    prep_quant_atx(s, pl, p, nullptr, npad, red_partial);
+    prep_quant_atx(s, pl, p, nullptr, npad, red_partial, cg ? cg->go : nullptr);
     launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[0], cg ? cg->go : nullptr);
     if (cg && cg->dot_out[0]) {
         double* o[2] = {out, nullptr};
@@ -1396,7 +1404,7 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb, const double* addxa,
           const double* addxb, double tau, double gam2, const CgHook* cg) {
-    prep_quant_atx(s, pl, pa, pb, npad, red_partial);
+    prep_quant_atx(s, pl, pa, pb, npad, red_partial, cg ? cg->go : nullptr);
     launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1], cg ? cg->go : nullptr);
     if (cg && (cg->dot_out[0] || cg->dot_out[1])) {
         double* o[2] = {outa, outb};
@@ -1442,8 +1450,9 @@ static void quant_ax(hipStream_t s, const Plan& pl, int nv) {
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
 }
 static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64_t npad, const uint32_t* mask2, double post,
-                   double* outa, double* outb) {
-    FinAx f{{outa, outb}};
+                   double* outa, double* outb, const CgHook* cg = nullptr, int64_t n0 = 0) {
+    FinAx f{{outa, outb}, nullptr, {nullptr, nullptr}, nullptr};
+    if (cg && cg->ride_out && nv == 2) { f.ride = cg->ride; f.st[0] = cg->state[0]; f.st[1] = cg->state[1]; f.ride_out = cg->ride_out + n0; }
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad,
                        pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8, piv_of(d, (pl.nrg_n + 3) / 4));
 }
@@ -1455,7 +1464,8 @@ static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64
 void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
              double* red_partial, const CgHook* cg) {
     const int nv = xb ? 2 : 1, nb = prep_blocks(pl.M);
-    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr, nullptr};
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr, nullptr,
+              cg ? cg->go : nullptr};
     if (cg) {
         for (int v = 0; v < nv; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
         if (nv == 2) { pa.ride = cg->ride; pa.alt_x = cg->alt_x; }
@@ -1479,7 +1489,7 @@ void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, co
     const Decomp& d = nv == 2 ? pl.dn[1] : pl.dn[0];
     if (nv == 2) launch_stream<3>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
     else         launch_stream<1>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
-    fin_ax(s, q, d, nv, nrows, mask2 + n0 / 16, post, outa + n0, outb ? outb + n0 : nullptr);
+    fin_ax(s, q, d, nv, nrows, mask2 + n0 / 16, post, outa + n0, outb ? outb + n0 : nullptr, cg, n0);
 }
 
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,

@@ -1068,20 +1068,22 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                         } else {                                // Y: d_a = A MA | w_n = A p_b (p_b <- z_b + beta p_b on the way in)
                             if (slotA) hk.state[0] = stA;       // (for the rider's sake: no search direction to advance in this slot)
                             if (slotB) { hk.state[iB] = stB; hk.p[iB] = sb.p; hk.z[iB] = sb.z; }
-                            if (ride_pending && slotA && slotB) { hk.ride = d_ride; hk.alt_x = wm->ride_x->d; }
+                            const bool may_ride = ride_pending && slotA && slotB;
+                            // one rank: the epilogue delivers the rider's product itself; sharded: it is copied out of the slot behind the
+                            // cross-rank sum and the scaling of that slot's output
+                            if (may_ride) { hk.ride = d_ride; hk.alt_x = wm->ride_x->d; if (!multi) hk.ride_out = wm->ride_out->d; }
                             if (slotA && slotB) MIX_TRY(ax2_device(c, MA->d, sb.p, d, c->w_n->d, &hk));
                             else if (slotA) MIX_TRY(ax_device(c, MA->d, d, &hk));
                             else MIX_TRY(ax_device(c, sb.p, c->w_n->d, &hk));
                             passes.push_back(PassRec{0, slotA, slotB});
-                            if (ride_pending && slotA && slotB) {
-                                gvk::ride_copy(s, wm->ride_out->d, d, c->w_n->d, stA, stB, d_ride, n);
-                                gvk::ride_mark(s, stA, stB, d_ride);
-                            }
+                            // (the rider's product went straight to ride_out; the A-step's decide marks it done, else a launch of its own)
+                            if (may_ride && multi) gvk::ride_copy(s, wm->ride_out->d, d, c->w_n->d, stA, stB, d_ride, n);
+                            if (may_ride && !hostA) gvk::ride_mark(s, stA, stB, d_ride);
                             if (slotA && hostA) {
                                 const unsigned long long seq = ++c->mbox_seq;
                                 gvk::aat_step(s, stA, mu, p, r, d, z, DG->d, tau, gam2, n, c->red_partial, c->red_out + 16,
                                               relres_a ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, flag_dev, seq, at_acc, MA->d, M, stB,
-                                              c->cgx_go, d_ride);
+                                              c->cgx_go, d_ride, may_ride ? d_ride : nullptr);
                                 MIX_HIP(hipGetLastError());
                                 steps.push_back(StepRec{0, seq, (int)passes.size() - 1});
                             }

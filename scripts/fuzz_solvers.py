@@ -116,6 +116,27 @@ def solves(sh, M, S, P):
         x = dict(xit=(s1.iters, s1.converged, s2.iters, s2.converged, s3.iters, s3.converged), xr1=r1, xr2=r2, xr3=r3,
                  mn=mn.download(), mn2=mn2.download(), atm=atm.download(), mb2=mb2.download(), aat=aat.download(),
                  ata2=ata2.download())
+        # the form the VAMP loop uses at levels 3 / 4 (A^T mu_a accumulated inside the solve, a rider, the right-hand side completed
+        # inside): its steady state is enqueued ahead of its statuses (gv_cg_solve_aat2w) -- against the host-paced loop
+        # (GV_AAT_PIPELINE=0): every output and every counter bit for bit
+        outs = []
+        for pipe in ("1", "0"):
+            os.environ["GV_AAT_PIPELINE"] = pipe
+            vq = sh.vecN(P["vn"])
+            q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po = sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecN(), sh.vecN()
+            sh.counters(reset=True)
+            (sa_, ra_), (sb_, rb_) = sh.cg_solve_aat2(vq, mn0, vb, P["tau"], P["gam2"], P["max_iter"], q_mn, q_at, q_mb, aat_mu_a=q_aat,
+                                                      ata_mu_b=q_ata, accumulate_at_mu_a=True, pre_x=va, pre_out=q_po,
+                                                      ride_x=mu, ride_out=q_ro)
+            cq = sh.counters()
+            outs.append(((sa_.iters, sa_.converged, sa_.n_relres, sb_.iters, sb_.converged, sb_.n_relres) + tuple(cq[k] for k in keys),
+                         [ra_, rb_] + [q.download() for q in (vq, q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po)]))
+            for q in (vq, q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po):
+                q.free()
+        os.environ.pop("GV_AAT_PIPELINE", None)
+        assert outs[0][0] == outs[1][0], ("pipelined XXT solver: counts", outs[0][0], outs[1][0])
+        for a_, b_ in zip(outs[0][1], outs[1][1]):
+            assert np.array_equal(a_, b_, equal_nan=True), "pipelined XXT solver: outputs differ from the host-paced loop"
     return dict(**x, it=(st.iters, st.converged, st.n_relres, sa.iters, sa.converged, sa.n_relres, sb.iters, sb.converged, sb.n_relres),
                 cnt=tuple(c1[k] for k in keys) + tuple(c2[k] for k in keys), rr=rr, ra=ra, rb=rb, ons=sb.onsager,
                 mu=mu.download(), mu_a=mu_a.download(), mu_b=mu_b.download(), ro=ro.download(), amu=amu.download(),

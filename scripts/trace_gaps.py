@@ -8,7 +8,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # streaming launches to skip (autotune, sim_phen, iteration 1)
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-idx = [i for i, e in enumerate(ev) if "k_mfma_matvec" in e[2]]
+# streaming launches that streamed: a pass enqueued after every CG system had finished returns at once on the device (the GO
+# instantiations) and is not a pass
+idx = [i for i, e in enumerate(ev) if ("k_mfma_matvec" in e[2] or "k_mfma_tile" in e[2]) and e[1] - e[0] > 20000]
 lo, hi = idx[skip if skip >= 0 else max(0, len(idx) + skip)], idx[-1]     # skip < 0: only the last -skip streaming launches
 seg = ev[lo:hi + 1]
 span = seg[-1][1] - seg[0][0]
@@ -23,7 +25,7 @@ for s, e, n in seg:
         idle += s - busy_end
         gaps.append(s - busy_end)
     busy_end = max(busy_end, e)
-nstream = sum(1 for e in seg if "k_mfma_matvec" in e[2])
+nstream = sum(1 for e in seg if ("k_mfma_matvec" in e[2] or "k_mfma_tile" in e[2]) and e[1] - e[0] > 20000)
 print("span %.3f ms, %d streaming launches, idle %.3f ms (%.1f %%)" % (span / 1e6, nstream, idle / 1e6, 100.0 * idle / span))
 for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0]):
     print("%8.3f ms %5.1f %% %6d x %7.1f us  %s" % (t / 1e6, 100.0 * t / span, c, t / c / 1e3, k))
