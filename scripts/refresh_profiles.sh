@@ -32,8 +32,8 @@ run() {  # name N M iters fuse xxt last-streaming-launches
   rm -rf $O/$1
 }
 run cfg5 50000 200000 6 4 1 -27        # the last three iterations (9 passes each): steady state, set-up excluded
-run shard125k 400000 125000 6 4 0 -18
-run cfg2 100000 500000 6 4 0 -27
+run shard125k 400000 125000 6 4 0 -10
+run cfg2 100000 500000 6 4 0 -18
 # counter passes of the four streaming-kernel classes on 12.5 GB shards (FETCH_SIZE against the algorithmic bytes)
 bash scripts/diag_twovec.sh 400000 125000 > /dev/null 2>&1
 bash scripts/diag_twovec.sh 100000 500000 > /dev/null 2>&1
