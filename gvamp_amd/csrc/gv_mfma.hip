@@ -98,21 +98,18 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global 16-row tile
     if (tile * 16 >= M) return;
     const int64_t rg = tile >> 2, i = tile & 3;
-    // r' codes: 10 = a 2, 01 = a 1, 00 = a 0, 11 = missing.  Three popcounts per dword -- the present entries with the high bit, with
-    // the low bit, with both -- give every count: n2 = H - B, n1 = L - B, missing = B, n0 = present - H - L + B.
-    uint32_t cH = 0, cL = 0, cB = 0, cP = 0;
+    uint32_t n2 = 0, n1 = 0, n0 = 0;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     auto count = [&](const v4u& v, int64_t kb) {
         const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
         uint32_t ws[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const uint32_t pm = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
-            const uint32_t lo = ws[d] & pm, hi = (ws[d] >> 1) & pm;
-            cH += __popc(hi);
-            cL += __popc(lo);
-            cB += __popc(hi & lo);
-            cP += __popc(pm);
+            uint32_t pm = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
+            uint32_t lo = ws[d] & 0x55555555u, hi = (ws[d] >> 1) & 0x55555555u;
+            n2 += __popc(hi & ~lo & pm);
+            n1 += __popc(~hi & lo & pm);
+            n0 += __popc(~hi & ~lo & pm);
         }
     };
     // four K-blocks per trip: 4 KiB of independent non-temporal loads in flight per wave (one load at a time streamed the shard
@@ -125,7 +122,6 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
         count(v0, kb); count(v1, kb + 1); count(v2, kb + 2); count(v3, kb + 3);
     }
     for (; kb < nkb; kb++) count(__builtin_nontemporal_load(src + kb * 256), kb);
-    uint32_t n2 = cH - cB, n1 = cL - cB, n0 = cP - cH - cL + cB;
     // sum over the 4 lanes (g) that share row r
     n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
     n1 += __shfl_xor(n1, 16, 64); n1 += __shfl_xor(n1, 32, 64);
@@ -1006,14 +1002,12 @@ __global__ __launch_bounds__(256) void k_stats_tile(const uint4* __restrict__ ti
             const uint32_t pm = (J < P4) ? (mask2[J] & 0x55555555u) : 0u;
             uint32_t T[4];
             transpose4x4_bytes(v.x, v.y, v.z, v.w, T);   // T[t] = marker 4q + t, 16 individuals of group J
-            const uint32_t np = __popc(pm);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {          // three popcounts per word, as in k_stats_stripes
-                const uint32_t lo = T[t] & pm, hi = (T[t] >> 1) & pm;
-                const uint32_t h = __popc(hi), l = __popc(lo), b = __popc(hi & lo);
-                n2[t] += h - b;
-                n1[t] += l - b;
-                n0[t] += np - h - l + b;
+            for (int t = 0; t < 4; t++) {
+                const uint32_t lo = T[t] & 0x55555555u, hi = (T[t] >> 1) & 0x55555555u;
+                n2[t] += __popc(hi & ~lo & pm);
+                n1[t] += __popc(~hi & lo & pm);
+                n0[t] += __popc(~hi & ~lo & pm);
             }
         }
     }
