@@ -18,7 +18,7 @@ EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_synth_bed_ld", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_get_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
-    "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots",
+    "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots", "gv_vec_dots_ex",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
@@ -28,6 +28,10 @@ EXPORTS = [
 
 class GvError(RuntimeError):
     pass
+
+
+class DotSpec(C.Structure):            # gv_dot_spec (include/gvamp.h)
+    _fields_ = [("xa", C.c_void_p), ("xb", C.c_void_p), ("ya", C.c_void_p), ("yb", C.c_void_p), ("sync", C.c_int)]
 
 
 class CgStats(C.Structure):
@@ -111,6 +115,7 @@ def load():
     L.gv_vec_mul.argtypes = [vp, vp, vp, vp]
     L.gv_vec_dot.argtypes = [vp, vp, vp, C.c_int, dp]
     L.gv_vec_dots.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, dp]
+    L.gv_vec_dots_ex.argtypes = [vp, C.c_int, C.POINTER(DotSpec), dp]
     L.gv_ax_dev.argtypes = [vp, vp, vp]
     L.gv_atx_dev.argtypes = [vp, vp, vp]
     L.gv_ax2_dev.argtypes = [vp, vp, vp, vp, vp]
@@ -344,6 +349,16 @@ class Shard:
         ys = (C.c_void_p * n)(*[p[1].h for p in pairs])
         out = np.empty(n)
         self._ck(self.L.gv_vec_dots(self.h, n, xs, ys, sync, _dp(out)))
+        return out
+
+    def dots_ex(self, specs):
+        """specs: (xa, xb, ya, yb, sync) tuples, xb / yb may be None: <xa - xb, ya - yb> in one launch and one read-back"""
+        n = len(specs)
+        arr = (DotSpec * n)()
+        for k, (xa, xb, ya, yb, sync) in enumerate(specs):
+            arr[k] = DotSpec(xa.h, xb.h if xb is not None else None, ya.h, yb.h if yb is not None else None, int(sync))
+        out = np.empty(n)
+        self._ck(self.L.gv_vec_dots_ex(self.h, n, arr, _dp(out)))
         return out
 
     def lmmse_mult(self, v, tau, gam2, out):

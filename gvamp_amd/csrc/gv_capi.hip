@@ -1467,6 +1467,35 @@ int gv_vec_dots(gv_ctx* c, int n, const gv_vec* const* x, const gv_vec* const* y
     if (sync && comm_allreduce(c, c->red_out, n)) return 1;
     return read_scalars(c, n, out);
 }
+int gv_vec_dots_ex(gv_ctx* c, int n, const gv_dot_spec* spec, double* out) {
+    NEED(c, n >= 1 && n <= 8, "gv_vec_dots_ex: 1 <= n <= 8");
+    const double *xa[8], *xb[8], *ya[8], *yb[8];
+    int64_t len[8];
+    bool any_sync = false;
+    for (int k = 0; k < n; k++) {
+        const gv_dot_spec& q = spec[k];
+        NEED(c, q.xa && q.ya, "gv_vec_dots_ex: xa and ya are required");
+        NEED(c, q.ya->space == q.xa->space && (!q.xb || q.xb->space == q.xa->space) && (!q.yb || q.yb->space == q.xa->space),
+             "gv_vec_dots_ex: the vectors of one pair live in one space");
+        xa[k] = q.xa->d; xb[k] = q.xb ? q.xb->d : nullptr;
+        ya[k] = q.ya->d; yb[k] = q.yb ? q.yb->d : nullptr;
+        len[k] = q.xa->len;
+        any_sync = any_sync || q.sync != 0;
+    }
+    const bool multi = any_sync && is_multi(c);
+    if (!multi) arm_scalars(c);
+    gvk::dots_ex(c->stream, n, xa, xb, ya, yb, len, c->red_partial, c->red_out);
+    KCHK(c);
+    if (multi)      // the scalars to be summed over the ranks, one all-reduce per run of neighbours
+        for (int k = 0; k < n;) {
+            if (!spec[k].sync) { k++; continue; }
+            int e = k;
+            while (e < n && spec[e].sync) e++;
+            if (comm_allreduce(c, c->red_out + k, (size_t)(e - k))) return 1;
+            k = e;
+        }
+    return read_scalars(c, n, out);
+}
 int gv_vec_dot(gv_ctx* c, const gv_vec* x, const gv_vec* y, int sync, double* out) {
     return gv_vec_dots(c, 1, &x, &y, sync, out);
 }

@@ -157,6 +157,8 @@ void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n)
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
 void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
           double* out);
+void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const* xb, const double* const* ya,
+             const double* const* yb, const int64_t* n, double* partial, double* out);   // <xa - xb, ya - yb>, lengths n[k]
 // device-resident CG step (gv_solvers.hip: cg_run_device)
 void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
             double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,

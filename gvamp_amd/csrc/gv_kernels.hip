@@ -498,6 +498,36 @@ __global__ __launch_bounds__(256) void k_dots(DotArgs a, int K, int64_t n, doubl
     }
 }
 
+// Several dots of one VAMP iteration in ONE launch and one read-back (gv_vec_dots_ex): pair k is <xa - xb, ya - yb> over n[k]
+// entries (xb / yb may be NULL).  Pair k is summed exactly as a k_dots launch of its own over n[k] entries would sum it -- the
+// first nb[k] = red_blocks(n[k]) blocks stride over it by nb[k] * 256, the others leave +0 partials, which add nothing in
+// k_finalize -- and a difference is rounded once, as k_axpby(1, ., -1, .) rounds it: the batched scalars are bit-identical to
+// those of the axpby + dots launches they replace.
+struct DotExArgs { const double* xa[8]; const double* xb[8]; const double* ya[8]; const double* yb[8]; long long n[8]; int nb[8]; };
+__global__ __launch_bounds__(256) void k_dots_ex(DotExArgs a, int K, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    for (int k = 0; k < K; k++) {
+        double s = 0.0;
+        if ((int)blockIdx.x < a.nb[k]) {
+            const double *xa = a.xa[k], *xb = a.xb[k], *ya = a.ya[k], *yb = a.yb[k];
+            const bool square = xa == ya && xb == yb;
+            const int64_t n = a.n[k], stride = (int64_t)a.nb[k] * 256;
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+                double x = xa[i];
+                if (xb) x = x - xb[i];
+                double y = x;
+                if (!square) {
+                    y = ya[i];
+                    if (yb) y = y - yb[i];
+                }
+                s = fma(x, y, s);
+            }
+        }
+        s = block_sum_256(s, sh);
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * K + k] = s;
+    }
+}
+
 // vamp.cpp:1169-1176 : mu += alpha p ; partial of <v, mu>
 __global__ __launch_bounds__(256) void k_cg_a(double* __restrict__ mu, const double* __restrict__ p, double alpha,
                                               const double* __restrict__ v, int64_t n,
@@ -1099,6 +1129,20 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
     }
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_dots, dim3(nb), dim3(256), 0, s, a, K, n, partial);
+    launch_finalize(s, partial, nb, K, out);
+}
+
+void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const* xb, const double* const* ya,
+             const double* const* yb, const int64_t* n, double* partial, double* out) {
+    DotExArgs a{};
+    int nb = 1;
+    for (int k = 0; k < K; k++) {
+        a.xa[k] = xa[k]; a.xb[k] = xb[k]; a.ya[k] = ya[k]; a.yb[k] = yb[k];
+        a.n[k] = n[k];
+        a.nb[k] = red_blocks(n[k], 256);
+        if (a.nb[k] > nb) nb = a.nb[k];
+    }
+    hipLaunchKernelGGL(k_dots_ex, dim3(nb), dim3(256), 0, s, a, K, partial);
     launch_finalize(s, partial, nb, K, out);
 }
 

@@ -160,7 +160,7 @@ double vamp::g2d_onsager(double gam2_, double tau, data* dataset, int* iters) {
 // The two CG solves of one iteration share the operator (tau A^T A + gam2 I): gv_cg_solve2 applies it to both pending
 // directions in one two-vector Ax + ATx pair per round.  Iterates, stopping rules and results per solve are unchanged.
 double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
-                          gv_vec* ride_x, gv_vec* ride_out) {
+                          gv_vec* ride_x, gv_vec* ride_out, bool defer_dot) {
     draw_onsager_probe(dataset);
     gv_cg_stats sa, sb;
     std::vector<double> ra(CG_max_iter > 0 ? CG_max_iter : 1), rb(CG_max_iter > 0 ? CG_max_iter : 1);
@@ -213,37 +213,8 @@ double vamp::fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset
     }
     if (cg_iters) *cg_iters = sa.iters;
     if (onsager_iters) *onsager_iters = sb.iters;
+    if (defer_dot) return 0.0;          // <u, invQ u> travels with the other scalars of the iteration (infere_linear)
     return gam2 * dotM(bern_vec, invQ_bern_vec);
-}
-
-// vamp.cpp:892-927.  temp = A x2 - y is also what err_measures(2) recomputes (:1301-1314); its R2 is taken here so
-// that the duplicate Ax of the reference is not repeated.
-void vamp::updateNoisePrec(data* dataset, double* R2_out) {
-    (void)dataset;
-    gv_vec* ata = tM;
-    if (have_derived) {                                                    // both products came out of the solves
-        ck(gv_vec_axpby(ctx, tN, 1.0, ax2_der, -1.0, y), "gv_vec_axpby");   // temp = A x2_hat - y
-        ata = ata_der;
-    } else {
-        ck(gv_ax2_dev(ctx, x2_hat, invQ_bern_vec, tN, tN2), "gv_ax2_dev");  // A x2_hat (:897) and A invQ u (:913), one pass
-        ck(gv_vec_axpby(ctx, tN, 1.0, tN, -1.0, y), "gv_vec_axpby");      // temp = A x2_hat - y
-    }
-    const gv_vec* xs[2] = {tN, y};
-    const gv_vec* ys[2] = {tN, y};
-    double d2[2];
-    ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
-    const double temp_norm2 = d2[0];
-    if (!have_derived) ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
-    const double trace_corr = dotM(bern_vec, ata) * Mt;
-    if (verbose && rank == 0) {
-        std::cout << "l2_norm2(temp) / N = " << temp_norm2 / N << std::endl;
-        std::cout << "trace_correction / N = " << trace_corr / N << std::endl;
-    }
-    gamw = (double)N / (temp_norm2 + trace_corr);
-    if (R2_out) {
-        const double l2_pred_err = sqrt(temp_norm2 / d2[1]);
-        *R2_out = 1 - l2_pred_err * l2_pred_err;
-    }
 }
 
 // vamp.cpp:929-1072: EM on (probs, vars).  The loop over markers (:953-1013) is gv_prior_estep; its 1 + 2(L-1) sums
@@ -350,7 +321,6 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         ck(gv_vec_upload(ctx, frozen, f.data()), "gv_vec_upload");
     }
 
-    double fused_alpha2 = 0;
     // the reference's named MPI_Wtime brackets (vamp.cpp:425-433,:515-530,:557,:617-637,:733-736), printed by rank 0 when
     // verbose: the device is drained before each reading so that a phase is charged with its own kernels
     auto tick = [&]() -> double {
@@ -456,16 +426,33 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         st.alpha1 = alpha1; st.eta1 = eta1; st.gam2 = gam2; st.rho = rho;
 
         if (auto_var_max_iter == 0 || it <= 1) updatePrior(1);            // :518-519
-        auto z1_outputs_b = [&]() {   // err_measures(1) (:1295-1317): R2 of the cached z1
+        // ---- the scalars of the iteration's second half -- R2 of z1 (:1295-1317), <u, invQ u> (:631), |x2 - r2|^2 (:686-693), the two
+        // sums of updateNoisePrec (:892-927) and the stopping rule (:741-749) -- do not depend on one another: they are gathered and
+        // travel in ONE launch and ONE read-back (gv_vec_dots_ex) instead of six; each is bit-identical to its own axpby + dot
+        struct { gv_dot_spec spec[8]; int* slot[8]; int n = 0; } tail;
+        auto want = [&](int* slot, const gv_vec* xa, const gv_vec* xb, const gv_vec* ya, const gv_vec* yb, int sync) {
+            tail.spec[tail.n] = gv_dot_spec{xa, xb, ya, yb, sync};
+            tail.slot[tail.n++] = slot;
+        };
+        int k_z1 = -1, k_yy = -1, k_alpha2 = -1, k_gam2 = -1, k_temp = -1, k_trace = -1, k_stop = -1, k_stop_n = -1;
+        auto z1_r2 = [&](double num, double den) {   // err_measures(1) (:1295-1317): R2 of the cached z1
+            const double e = sqrt(num / den);
+            st.R2_denoise = 1 - e * e;
+            R2trains.push_back(st.R2_denoise);
+            if (verbose && rank == 0) std::cout << "R2 = " << st.R2_denoise << std::endl;
+        };
+        auto z1_outputs_b = [&]() {
+            if (z1_rides) {                   // z1 comes out of the solve: with the tail
+                want(&k_z1, y, z1, y, z1, 0);
+                want(&k_yy, y, nullptr, y, nullptr, 0);
+                return;
+            }
             ck(gv_vec_axpby(ctx, tN, 1.0, y, -1.0, z1), "gv_vec_axpby");
             const gv_vec* xs[2] = {tN, y};
             const gv_vec* ys[2] = {tN, y};
             double d2[2];
             ck(gv_vec_dots(ctx, 2, xs, ys, 0, d2), "gv_vec_dots");
-            const double e = sqrt(d2[0] / d2[1]);
-            st.R2_denoise = 1 - e * e;
-            R2trains.push_back(st.R2_denoise);
-            if (verbose && rank == 0) std::cout << "R2 = " << st.R2_denoise << std::endl;
+            z1_r2(d2[0], d2[1]);
         };
         if (!z1_rides) z1_outputs_b();
         if (verbose && rank == 0) {
@@ -493,8 +480,9 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             ck(gv_vec_axpby(ctx, vM, gamw, aty, gam2, r2), "gv_vec_axpby");   // v = gamw A^T y + gam2 r2 (:590-591)
             gv_vec* warm = (it == 1 || !have_mu_CG_last) ? nullptr : mu_CG_last;
             if (fuse_solves) {
-                fused_alpha2 = fused_solves(vM, warm, gamw, dataset, &st.cg_iters, &st.onsager_iters,
-                                            z1_rides ? x1_hat : nullptr, z1_rides ? z1 : nullptr);
+                fused_solves(vM, warm, gamw, dataset, &st.cg_iters, &st.onsager_iters, z1_rides ? x1_hat : nullptr,
+                             z1_rides ? z1 : nullptr, true);
+                want(&k_alpha2, bern_vec, nullptr, invQ_bern_vec, nullptr, 1);
                 if (z1_rides) {
                     double tz = now_s();
                     z1_outputs_a();
@@ -572,7 +560,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             }
             ck(gv_vec_copy(ctx, mu_CG_last_N, tN2), "gv_vec_copy");
             ck(gv_vec_axpby(ctx, x2_hat, gamw, at_out, 1.0, r2), "gv_vec_axpby");
-            fused_alpha2 = gam2 * dotM(bern_vec, invQ_bern_vec);
+            want(&k_alpha2, bern_vec, nullptr, invQ_bern_vec, nullptr, 1);
             // A x2_hat = A r2 + gamw A A^T u, the latter from the residual of the N-space solve (no pass)
             if (have_derived) ck(gv_vec_axpby(ctx, ax2_der, 1.0, ax2_der, gamw, aat_der), "gv_vec_axpby");
         } else {
@@ -599,27 +587,59 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             std::cout << (fuse_solves ? "CG + onsager (shared passes) took " : "CG took ") << tick() - t_cg << " seconds."
                       << std::endl;
         const double t_ons = tick();
-        if (fuse_solves) alpha2 = fused_alpha2;                           // :631, solved together with x2_hat above
-        else {
+        const double gam2_solve = gam2;                                    // alpha2 = gam2 <u, invQ u> (:631) with the gam2 of the solves
+        if (!fuse_solves) {
             alpha2 = g2d_onsager(gam2, gamw, dataset, &st.onsager_iters);
             if (verbose && rank == 0) std::cout << "onsager took " << tick() - t_ons << " seconds." << std::endl;
         }
-        st.alpha2 = alpha2;
-        if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
+        double onsager_approx = 0;
         if (it > 1 && diagnostics) {
             // "polynomial onsager" diagnostics (:646-681): printed only; off by default (they cost 3 Ax per iteration)
             ck(gv_vec_axpby(ctx, tM, 1.0, r2, -1.0, r2_prev), "gv_vec_axpby");
-            const double onsager_approx = dotM(x2_hat, tM) / dotM(r2, tM);
+            onsager_approx = dotM(x2_hat, tM) / dotM(r2, tM);
             ck(gv_ax_dev(ctx, r2, tN), "gv_ax_dev");
             ck(gv_ax_dev(ctx, x2_hat, tN2), "gv_ax_dev");
             ck(gv_ax_dev(ctx, x2_hat, tN2), "gv_ax_dev");
-            if (rank == 0) std::cout << "onsager approx = " << onsager_approx << std::endl;
         }
+        // updateNoisePrec (:892-927): A x2_hat (:897) and A^T A invQ u (:913-914) -- by-products of the solves, or one Ax pass for
+        // both and one ATx pass.  temp = A x2_hat - y is also what err_measures(2) recomputes (:1301-1314): its R2 is taken here.
+        const gv_vec *ax2 = ax2_der, *ata = ata_der;
+        if (!have_derived) {
+            ck(gv_ax2_dev(ctx, x2_hat, invQ_bern_vec, tN, tN2), "gv_ax2_dev");
+            ck(gv_atx_dev(ctx, tN2, tM), "gv_atx_dev");
+            ax2 = tN;
+            ata = tM;
+        }
+        const bool reest = auto_var_max_iter >= 1 && it > 2;               // :686-693
+        if (reest) want(&k_gam2, x2_hat, r2, x2_hat, r2, 1);
+        want(&k_temp, ax2, y, ax2, y, 0);
+        {
+            bool have_yy = false;                                          // (already asked for with the R2 of z1)
+            for (int k = 0; k < tail.n; k++) have_yy = have_yy || tail.slot[k] == &k_yy;
+            if (!have_yy) want(&k_yy, y, nullptr, y, nullptr, 0);
+        }
+        want(&k_trace, bern_vec, nullptr, ata, nullptr, 1);
+        want(&k_stop, x1_hat_prev, x1_hat, x1_hat_prev, x1_hat, 1);        // stopping criterion (:741-749)
+        want(&k_stop_n, x1_hat_prev, nullptr, x1_hat_prev, nullptr, 1);
+        double tv[8];
+        {   // the sums every rank holds whole (N-space) first, then the ones summed over the ranks: one all-reduce
+            gv_dot_spec ordered[8];
+            int no = 0;
+            for (int pass = 0; pass < 2; pass++)
+                for (int k = 0; k < tail.n; k++)
+                    if ((tail.spec[k].sync != 0) == (pass == 1)) {
+                        ordered[no] = tail.spec[k];
+                        *tail.slot[k] = no++;
+                    }
+            ck(gv_vec_dots_ex(ctx, no, ordered, tv), "gv_vec_dots_ex");
+        }
+        if (k_z1 >= 0) z1_r2(tv[k_z1], tv[k_yy]);
+        if (k_alpha2 >= 0) alpha2 = gam2_solve * tv[k_alpha2];             // :631, solved together with x2_hat above
+        st.alpha2 = alpha2;
+        if (verbose && rank == 0) std::cout << "alpha2 = " << alpha2 << std::endl;
+        if (it > 1 && diagnostics && rank == 0) std::cout << "onsager approx = " << onsager_approx << std::endl;
         eta2 = gam2 / alpha2;                                              // :682
-        if (auto_var_max_iter >= 1 && it > 2) {                            // :686-693
-            ck(gv_vec_axpby(ctx, tM, 1.0, x2_hat, -1.0, r2), "gv_vec_axpby");
-            gam2 = std::min(std::max(1 / (1 / eta2 + dotM(tM, tM) / Mt), gamma_min), gamma_max);
-        }
+        if (reest) gam2 = std::min(std::max(1 / (1 / eta2 + tv[k_gam2] / Mt), gamma_min), gamma_max);
         gam2s.push_back(gam2);
         st.eta2 = eta2; st.gam2_reest = gam2;
         gam1 = std::min(std::max(eta2 - gam2, gamma_min), gamma_max);     // :702
@@ -627,7 +647,16 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         st.gam1_next = gam1;
         if (verbose && rank == 0) std::cout << "gam2 re-est = " << gam2 << std::endl << "gam1 = " << gam1 << std::endl;
 
-        updateNoisePrec(dataset, &st.R2_lmmse);                            // :726 (+ err_measures(2), :731)
+        {   // :726 (+ err_measures(2), :731)
+            const double temp_norm2 = tv[k_temp], trace_corr = tv[k_trace] * Mt;
+            if (verbose && rank == 0) {
+                std::cout << "l2_norm2(temp) / N = " << temp_norm2 / N << std::endl;
+                std::cout << "trace_correction / N = " << trace_corr / N << std::endl;
+            }
+            gamw = (double)N / (temp_norm2 + trace_corr);
+            const double l2_pred_err = sqrt(temp_norm2 / tv[k_yy]);
+            st.R2_lmmse = 1 - l2_pred_err * l2_pred_err;
+        }
         R2trains.push_back(st.R2_lmmse);
         st.gamw = gamw;
         if (verbose && rank == 0) std::cout << "R2 = " << st.R2_lmmse << std::endl << "gamw = " << gamw << std::endl;
@@ -642,16 +671,10 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         st.n_ax_pass = (long)(c1.n_ax_pass - c0.n_ax_pass);
         st.n_atx_pass = (long)(c1.n_atx_pass - c0.n_atx_pass);
 
-        // stopping criterion (:741-749)
-        ck(gv_vec_axpby(ctx, tM, 1.0, x1_hat_prev, -1.0, x1_hat), "gv_vec_axpby");
-        const gv_vec* xs[2] = {tM, x1_hat_prev};
-        const gv_vec* ys[2] = {tM, x1_hat_prev};
-        double d2[2];
-        ck(gv_vec_dots(ctx, 2, xs, ys, 1, d2), "gv_vec_dots");
         st.seconds_io = t_io;
         st.seconds = now_s() - t_start - t_io;
         stats.push_back(st);
-        if (it > 1 && sqrt(d2[0] / d2[1]) < stop_criteria_thr) {
+        if (it > 1 && sqrt(tv[k_stop] / tv[k_stop_n]) < stop_criteria_thr) {
             if (verbose && rank == 0)
                 std::cout << "VAMP stopping criteria fulfilled with threshold = " << stop_criteria_thr << "." << std::endl;
             break;

@@ -88,7 +88,7 @@ public:
     bool probe_product_is_usable(double tau, double gam2);                    // level 4: is the captured A^T A u accurate enough to keep?                                   // vamp.cpp:875-882 (host RNG)
     // LMMSE solve (:593-596) and Onsager probe solve (:884) in lock-step on the shared operator; returns alpha2
     double fused_solves(gv_vec* v, gv_vec* mu_start, double tau, data* dataset, int* cg_iters, int* onsager_iters,
-                        gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr);
+                        gv_vec* ride_x = nullptr, gv_vec* ride_out = nullptr, bool defer_dot = false);
     gv_vec *aat_der = nullptr;        // --use-XXT-denoiser 1: A A^T u from the residual of the N-space solve
     gv_vec *ax2_der = nullptr, *ata_der = nullptr;   // --fuse-solves 2: A x2_hat and A^T A invQ u as by-products of the solves
     bool have_derived = false;
@@ -106,7 +106,6 @@ public:
     bool have_probe = false;          // draw_onsager_probe: bern_vec is resident for (seed + S) == probe_key
     long unsigned int probe_key = 0;
     void updatePrior(int verbose);                       // vamp.cpp:929-1072
-    void updateNoisePrec(data* dataset, double* R2_out); // vamp.cpp:892-927 (+ the R2 of err_measures(2), :1301-1314)
 
     void set_verbose(int v) { verbose = v; }
     void set_keep_history(int k) { keep_history = k; }

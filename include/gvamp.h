@@ -104,6 +104,16 @@ int gv_vec_mul(gv_ctx* ctx, gv_vec* out, const gv_vec* x, const gv_vec* y);
 int gv_vec_dot(gv_ctx* ctx, const gv_vec* x, const gv_vec* y, int sync, double* out);
 /* several dots in one pass and ONE all-reduce: out[k] = <x[k], y[k]> */
 int gv_vec_dots(gv_ctx* ctx, int n, const gv_vec* const* x, const gv_vec* const* y, int sync, double* out);
+/* The scalars one VAMP iteration reads after its solves (vamp.cpp:631, :686-693, :892-927, :741-749, :1295-1317), in one launch
+ * and one read-back: out[k] = <xa - xb, ya - yb> (xb / yb may be NULL: the plain vector); pairs of either space may be mixed;
+ * sync != 0 adds the cross-rank all-reduce of that scalar.  Each scalar is bit-identical to gv_vec_axpby(t, 1, xa, -1, xb) ...
+ * gv_vec_dot(t, u): the difference is rounded once, the sum runs in the same order. */
+typedef struct gv_dot_spec {
+    const gv_vec* xa; const gv_vec* xb;
+    const gv_vec* ya; const gv_vec* yb;
+    int sync;
+} gv_dot_spec;
+int gv_vec_dots_ex(gv_ctx* ctx, int n, const gv_dot_spec* spec, double* out);
 int gv_ax_dev(gv_ctx* ctx, const gv_vec* x, gv_vec* out);  /* data::Ax on handles */
 int gv_atx_dev(gv_ctx* ctx, const gv_vec* p, gv_vec* out); /* data::ATx on handles */
 /* Two vectors per pass over the shard (kernel mode 1; two single passes otherwise): outa = A xa, outb = A xb, and

@@ -314,3 +314,36 @@ def test_bed_file_slab_equals_upload_from_memory_and_a_short_file_fails_loudly(t
             sh.upload_bed_file(str(tmp_path / "nope.bed"))
         with pytest.raises(capi.GvError):                     # nothing usable is resident after the failed ingest
             sh.compute_markers_statistics()
+
+
+@pytest.mark.parametrize("N,M", [(3001, 70001), (1200, 300000)])
+def test_gathered_dots_equal_their_own_launches_bit_for_bit(N, M):
+    """gv_vec_dots_ex (the iteration's tail in one launch and one read-back, host/vamp.cpp) against the launches it replaces:
+    gv_vec_axpby(t, 1, xa, -1, xb) + gv_vec_dot / gv_vec_dots per scalar -- mixed spaces and lengths (12 to 1024 reduction blocks),
+    plain and difference operands, squares and mixed products: the same bits."""
+    rng = np.random.default_rng(N + M)
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(1)
+        sh.compute_markers_statistics()
+        a, b, c = (sh.vecM(rng.standard_normal(M)) for _ in range(3))
+        u, v = (sh.vecN(rng.standard_normal(N) * 1e3) for _ in range(2))
+        tM, tM2, tN = sh.vecM(), sh.vecM(), sh.vecN()
+        want = []
+        sh.axpby(tN, 1.0, u, -1.0, v)
+        want.append(sh.dot(tN, tN, 0))                     # <u - v, u - v>
+        want.append(sh.dot(u, u, 0))                       # <u, u>
+        want.append(sh.dot(a, b, 1))                       # <a, b>
+        sh.axpby(tM, 1.0, a, -1.0, b)
+        want.append(sh.dot(tM, tM, 1))                     # <a - b, a - b>
+        sh.axpby(tM2, 1.0, c, -1.0, a)
+        want.append(sh.dot(tM, tM2, 1))                    # <a - b, c - a>
+        want.append(sh.dot(tM, c, 1))                      # <a - b, c>
+        got = sh.dots_ex([(u, v, u, v, 0), (u, None, u, None, 0), (a, None, b, None, 1), (a, b, a, b, 1), (a, b, c, a, 1),
+                          (a, b, c, None, 1)])
+        assert [float(x).hex() for x in got] == [float(x).hex() for x in want]
+        # and against numpy, to a rounding-level tolerance
+        A, B, Cc, U, V = (x.download() for x in (a, b, c, u, v))
+        ref = [np.dot(U - V, U - V), np.dot(U, U), np.dot(A, B), np.dot(A - B, A - B), np.dot(A - B, Cc - A), np.dot(A - B, Cc)]
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-9)
+        with pytest.raises(capi.GvError, match="one space"):
+            sh.dots_ex([(a, u, a, u, 0)])
