@@ -728,6 +728,8 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
     NEED(c, c->have_stats, "ATx: bed and marker statistics must be set first");
     if (c->M == 0) {   // empty shard: no markers; the <d,p> a CG hook asks for is 0 from this rank (it is all-reduced next)
         if (cg && cg->dot_out[0]) { gvk::fill(c->stream, cg->dot_out[0], 8, 0.0); KCHK(c); }
+        // (the N-space search direction a pass would have advanced on its way in -- CgHook::pn -- is replicated on every rank)
+        if (cg && cg->pn[0]) { gvk::p_update_st(c->stream, cg->pn[0], cg->zn[0], cg->state[0], c->npad); KCHK(c); }
         c->cnt.n_atx++;
         c->cnt.n_atx_pass++;
         return 0;
@@ -813,8 +815,10 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
                 const double* addxb, double tau, double gam2, const gvm::CgHook* cg) {
     if (c->M == 0) {   // empty shard: no local markers, no collective in ATx
-        for (int k = 0; k < 2 && cg; k++)
+        for (int k = 0; k < 2 && cg; k++) {
             if (cg->dot_out[k]) gvk::fill(c->stream, cg->dot_out[k], 8, 0.0);
+            if (cg->pn[k]) gvk::p_update_st(c->stream, cg->pn[k], cg->zn[k], cg->state[k], c->npad);
+        }
         KCHK(c);
         c->cnt.n_atx += 2;
         c->cnt.n_atx_pass += 1;
@@ -852,9 +856,11 @@ void free_dataset(gv_ctx* c) {
     };
     F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial); F(c->counts);
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.tiles); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
-    F(c->plan.cv2); F(c->plan.ev2); F(c->plan.counters);
+    F(c->plan.cv2); F(c->plan.ev2);
     F(c->plan.scal); F(c->plan.partial);
     F(c->cgx_state); F(c->cgx_go); F(c->cgx_rel);
+    F(c->aat_slab);
+    c->aat_slab_cap = 0;
     c->cgx_relcap = 0;
     if (c->cgx_pin) { (void)hipHostFree(c->cgx_pin); c->cgx_pin = nullptr; }
     c->plan = gvm::Plan();
@@ -1208,7 +1214,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
         // (re)build the geometry and the buffers of the MFMA family for the layout asked for
         for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
-                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.counters, (void**)&pl.scal, (void**)&pl.partial})
+                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         if (plan_decomps(c)) return 1;
         const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
@@ -1224,8 +1230,6 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.cv2, sizeof(double) * (M > 0 ? M : 1)));
         HIPCHK(c, hipMalloc(&pl.ev2, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.counters, sizeof(unsigned int) * 4));
-        HIPCHK(c, hipMemsetAsync(pl.counters, 0, sizeof(unsigned int) * 4, c->stream));
         HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
         auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
             int k = 1;

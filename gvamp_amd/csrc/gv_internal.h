@@ -81,6 +81,8 @@ struct gv_ctx {
     double* cgx_rel = nullptr;
     int cgx_relcap = 0;
     double* cgx_pin = nullptr;
+    double* aat_slab = nullptr;    // work vectors of the N-space solvers (gv_solvers.hip: aat_scratch), kept between calls
+    size_t aat_slab_cap = 0;
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
     gv_vec *w_n = nullptr, *w_n2 = nullptr;                  // N-space scratch (lmmse_mult, two-vector form)
     gv_vec *cg2_r = nullptr, *cg2_z = nullptr, *cg2_p = nullptr, *cg2_d = nullptr;   // second CG system (gv_cg_solve2)
@@ -160,20 +162,26 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
 void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const* xb, const double* const* ya,
              const double* const* yb, const int64_t* n, double* partial, double* out);   // <xa - xb, ya - yb>, lengths n[k]
 // device-resident CG step (gv_solvers.hip: cg_run_device)
-void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
-            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-            double* const* red, double diag, int64_t n);
+// dp_part != NULL (one rank): <d,p> of system k is still in dp_nb block partials at dp_part[k] and the three sums of this
+// launch stay block partials too (k_cgx_decide adds them up: cgx_decide's part / part_nb); returns the number of blocks
+int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
+           double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
+           double* const* red, double diag, int64_t n, const double* const* dp_part = nullptr, int dp_nb = 0);
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);   // ordered sum of block partials
+void state_init(hipStream_t s, double* dst, const double* q);   // q: gvm::ST_SIZE doubles, by value in the launch
+void set_ints(hipStream_t s, int* dst, int a, int b);
 void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
                 int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
-                const double* other_st = nullptr, const int* ride_report = nullptr);
+                const double* other_st = nullptr, const int* ride_report = nullptr, const double* const* part = nullptr,
+                int part_nb = 0);
 void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride);
+void p_update_st(hipStream_t s, double* p, const double* z, const double* st, int64_t n);   // p = z + beta p while st is stepping
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
-              double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
+              double gam2, int64_t n, double* partial, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc = nullptr,
               const double* at_p = nullptr, int64_t m = 0, const double* other_st = nullptr, int* go = nullptr,
-              const int* ride = nullptr, int* ride_mark = nullptr);
+              const int* ride = nullptr, int* ride_mark = nullptr, bool p_update = true);
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,

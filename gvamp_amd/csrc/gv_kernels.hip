@@ -31,6 +31,22 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// scalar k of nblocks block partials (K per block), added up by a block of 256 threads for itself in the order of k_finalize
+// (strided partial sums, then a fixed tree): the consumer of a reduction takes the place of a k_finalize launch -- same bits,
+// one launch less per reduction (a CG step has two or three; profiles/r3_cfg5_gaps.txt).  sh: 256 doubles.  Valid in every thread.
+__device__ __forceinline__ double sum_partials_256(const double* __restrict__ partial, int nblocks, int K, int k, double* sh) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * K + k];
+    __syncthreads();
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -581,13 +597,16 @@ __global__ __launch_bounds__(256) void k_cg_b(double* __restrict__ r, const doub
 struct CgxAB {
     double* st[2]; double* mu[2]; const double* p[2]; const double* v[2]; double* r[2]; const double* d[2]; double* z[2];
     const double* dp[2]; double* part[2]; double* red[2];
+    const double* dpp[2]; int dp_nb;      // dpp[v] != NULL: <d,p> still in dp_nb block partials (one rank: no all-reduce, no k_finalize)
 };
 __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n) {
     __shared__ double sh[4];
+    __shared__ double shr[256];
     const int v = blockIdx.y;
     double* st = a.st[v];
     if (st[gvm::ST_ACTIVE] == 0.0) return;
-    const double alpha = st[gvm::ST_RZ] / a.dp[v][0];                    // vamp.cpp:1167
+    const double dp = a.dpp[v] ? sum_partials_256(a.dpp[v], a.dp_nb, 1, 0, shr) : a.dp[v][0];
+    const double alpha = st[gvm::ST_RZ] / dp;                            // vamp.cpp:1167
     double* __restrict__ mu = a.mu[v];
     const double* __restrict__ p = a.p[v];
     const double* __restrict__ vv = a.v[v];
@@ -641,14 +660,20 @@ __global__ __launch_bounds__(256) void k_aat_dq(double* __restrict__ d, const do
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // alpha = <r,z> / <d,p> (:88); mu += alpha p (:90-93); r -= alpha d; z = r / diag[n] (:95-105); partials of <r,z>, <r,r>
+// <d,p> arrives as the dp_nb block partials of k_aat_dq (every block adds them up for itself: sum_partials_256); at_acc (may be
+// NULL): A^T mu += alpha A^T p over m entries, what k_axpy_st did in a launch of its own
 __global__ __launch_bounds__(256) void k_aat_ab(double* __restrict__ st, double* __restrict__ mu, const double* __restrict__ p,
                                                 double* __restrict__ r, const double* __restrict__ d, double* __restrict__ z,
-                                                const double* __restrict__ diag, const double* __restrict__ dp, int64_t n,
-                                                double* __restrict__ partial) {
+                                                const double* __restrict__ diag, const double* __restrict__ dp_part, int dp_nb,
+                                                int64_t n, double* __restrict__ partial, double* __restrict__ at_acc,
+                                                const double* __restrict__ at_p, int64_t m) {
     __shared__ double sh[4];
+    __shared__ double shr[256];
     if (st[gvm::ST_ACTIVE] == 0.0) return;
-    const double alpha = st[gvm::ST_RZ] / dp[0];
+    const double alpha = st[gvm::ST_RZ] / sum_partials_256(dp_part, dp_nb, 1, 0, shr);
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (at_acc)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) at_acc[i] += alpha * at_p[i];
     double s0 = 0, s1 = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         mu[i] = fma(alpha, p[i], mu[i]);
@@ -672,9 +697,15 @@ __global__ __launch_bounds__(256) void k_aat_ab(double* __restrict__ st, double*
 // other_st / go (may be NULL): the joint solver's pipelined loop (gv_cg_solve_aat2w) -- *go = this system or the M-space system
 // behind other_st is still running: passes enqueued after both have finished are dropped on the device.  ride (may be NULL):
 // reported in status word 7 (1 rider pending, 2 rode).
-__global__ void k_aat_decide(double* __restrict__ st, const double* __restrict__ red, double* __restrict__ relres, int max_iter,
-                             double* mailbox, unsigned long long* flag, unsigned long long seq, const double* other_st, int* go,
-                             const int* ride, int* ride_mark) {
+// part / nb: the block partials k_aat_ab left (<r,z>, <r,r>), added up here (one block of 256 threads) instead of by k_finalize
+__global__ __launch_bounds__(256) void k_aat_decide(double* __restrict__ st, const double* __restrict__ part, int nb,
+                                                    double* __restrict__ relres, int max_iter, double* mailbox,
+                                                    unsigned long long* flag, unsigned long long seq, const double* other_st,
+                                                    int* go, const int* ride, int* ride_mark) {
+    __shared__ double shr[256];
+    double red[2];
+    red[0] = sum_partials_256(part, nb, 2, 0, shr);
+    red[1] = sum_partials_256(part, nb, 2, 1, shr);
     if (threadIdx.x == 0) {
         // the rider rode in the Ax pass just made if it was pending and exactly one system had finished before it (flags unchanged yet)
         if (ride_mark && *ride_mark == 1 && other_st && ((st[gvm::ST_ACTIVE] != 0.0) != (other_st[gvm::ST_ACTIVE] != 0.0))) *ride_mark = 2;
@@ -711,6 +742,15 @@ __global__ void k_p_update_st(double* __restrict__ p, const double* __restrict__
     if (i < n) p[i] = fma(beta, p[i], z[i]);
 }
 
+// initial state block of a CG system / the go and rider words, carried by the launch itself: no pinned staging block that a
+// stream synchronisation would have to protect before the host may write the next one
+struct StateInit { double q[gvm::ST_SIZE]; };
+__global__ void k_state_init(double* __restrict__ dst, StateInit a) {
+    if (threadIdx.x < gvm::ST_SIZE) dst[threadIdx.x] = a.q[threadIdx.x];
+}
+__global__ void k_set_ints(int* __restrict__ dst, int a, int b) {
+    if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
+}
 // the rider's product (see gvm::CgHook::ride) out of the slot that carried it
 __global__ void k_ride_copy(double* __restrict__ out, const double* __restrict__ w0, const double* __restrict__ w1,
                             const double* __restrict__ st0, const double* __restrict__ st1, const int* __restrict__ ride,
@@ -731,11 +771,19 @@ __global__ void k_ride_mark(const double* __restrict__ st0, const double* __rest
 // <r,z>, relative residual and its trace, stopping rules; then *go = some system is still running, and the status of every
 // system goes to the host mailbox (slot = seq & 1: the host reads status s while the device may already write s + 1).
 struct CgxDecide { double* st[2]; const double* red[2]; double* relres[2]; int nsys; int* ride;
-                   const double* other_st; const int* ride_report; };   // other_st: a system stepped elsewhere that also keeps *go up
+                   const double* other_st; const int* ride_report;      // other_st: a system stepped elsewhere that also keeps *go up
+                   const double* part[2]; int part_nb; };               // part[v] != NULL: <v,mu>, <r,z>, <r,r> still in block partials
 constexpr int CGX_STATUS = 8;   // doubles per system in the mailbox: active, iters, converged, rel_err, onsager, n_relres, stepped
-__global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
-                             unsigned long long* flag, unsigned long long seq) {
+__global__ __launch_bounds__(256) void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
+                                                    unsigned long long* flag, unsigned long long seq) {
     __shared__ int any;
+    __shared__ double shr[256];
+    __shared__ double qs[2][3];
+    for (int v = 0; v < a.nsys; v++)
+        for (int k = 0; k < 3; k++) {
+            const double q = a.part[v] ? sum_partials_256(a.part[v], a.part_nb, 3, k, shr) : a.red[v][k];
+            if (threadIdx.x == 0) qs[v][k] = q;
+        }
     if (threadIdx.x == 0) {
         any = 0;
         // the rider rode in this step if it was pending and exactly one system had finished before the step (the flags
@@ -749,7 +797,7 @@ __global__ void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __rest
     if (v < a.nsys) {
         double* st = a.st[v];
         if (st[gvm::ST_ACTIVE] != 0.0) {
-            const double* q = a.red[v];                 // <v,mu>, <r,z>, <r,r>
+            const double* q = qs[v];                    // <v,mu>, <r,z>, <r,r>
             const int iters = (int)st[gvm::ST_ITERS] + 1;
             st[gvm::ST_ITERS] = (double)iters;
             bool stepping = true;
@@ -1146,18 +1194,23 @@ void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const*
     launch_finalize(s, partial, nb, K, out);
 }
 
-void cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
-            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-            double* const* red, double diag, int64_t n) {
+int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
+           double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
+           double* const* red, double diag, int64_t n, const double* const* dp_part, int dp_nb) {
     CgxAB a{};
     for (int k = 0; k < nsys; k++) {
         a.st[k] = st[k]; a.mu[k] = mu[k]; a.p[k] = p[k]; a.v[k] = v[k]; a.r[k] = r[k]; a.d[k] = d[k]; a.z[k] = z[k];
         a.dp[k] = dp[k]; a.part[k] = part[k]; a.red[k] = red[k];
+        a.dpp[k] = dp_part ? dp_part[k] : nullptr;
     }
+    a.dp_nb = dp_nb;
     const int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cgx_ab, dim3(nb, nsys), dim3(256), 0, s, a, diag, n);
     // (an inactive system's kernel slice returns at once and its stale partials are summed into a slot nobody reads)
-    for (int k = 0; k < nsys; k++) hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, s, part[k], nb, 3, red[k]);
+    // one rank (dp_part != NULL): k_cgx_decide adds the block partials up itself; sharded: the sums are all-reduced first
+    if (!dp_part)
+        for (int k = 0; k < nsys; k++) hipLaunchKernelGGL(k_finalize, dim3(3), dim3(256), 0, s, part[k], nb, 3, red[k]);
+    return nb;
 }
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out) {
     hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
@@ -1167,18 +1220,25 @@ void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_
     hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
 }
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
+// Three launches (four with the search-direction update): every reduction is added up by the kernel that consumes it
+// (sum_partials_256), A^T mu += alpha A^T p (at_p = the first half of this application) rides in k_aat_ab -- before
+// k_aat_decide may clear ST_ACTIVE -- and p <- z + beta p is left to the k_prep_atx of the next pass when p_update == false.
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
-              double gam2, int64_t n, double* partial, double* red, double* relres, int max_iter, double* mailbox,
+              double gam2, int64_t n, double* partial, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m, const double* other_st,
-              int* go, const int* ride, int* ride_mark) {
+              int* go, const int* ride, int* ride_mark, bool p_update) {
     const int nb = red_blocks(n, 256);
-    hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, partial);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, partial, nb, 1, red);
-    hipLaunchKernelGGL(k_aat_ab, dim3(nb), dim3(256), 0, s, st, mu, p, r, d, z, diag, red, n, partial);
-    // A^T mu += alpha A^T p (at_p = the first half of this application), before k_aat_decide may clear ST_ACTIVE
-    if (at_acc && m > 0) hipLaunchKernelGGL(k_axpy_st, dim3(nblk(m, 256)), dim3(256), 0, s, at_acc, at_p, st, m);
-    hipLaunchKernelGGL(k_finalize, dim3(2), dim3(256), 0, s, partial, nb, 2, red + 2);
-    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(64), 0, s, st, red + 2, relres, max_iter, mailbox, flag, seq, other_st, go, ride, ride_mark);
+    double* part_dq = partial;                       // <d,p>: nb doubles
+    double* part_ab = partial + 2 * RED_BLOCKS;      // <r,z>, <r,r>: 2 nb doubles (clear of the sums its own blocks still read)
+    hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, part_dq);
+    hipLaunchKernelGGL(k_aat_ab, dim3(nb), dim3(256), 0, s, st, mu, p, r, d, z, diag, part_dq, nb, n, part_ab,
+                       (at_acc && m > 0) ? at_acc : nullptr, at_p, m);
+    hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(256), 0, s, st, part_ab, nb, relres, max_iter, mailbox, flag, seq, other_st, go,
+                       ride, ride_mark);
+    if (p_update) hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);
+}
+void p_update_st(hipStream_t s, double* p, const double* z, const double* st, int64_t n) {
+    if (n <= 0) return;
     hipLaunchKernelGGL(k_p_update_st, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, st, n);
 }
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
@@ -1186,19 +1246,29 @@ void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, c
     if (n <= 0) return;
     hipLaunchKernelGGL(k_ride_copy, dim3(nblk(n, 256)), dim3(256), 0, s, out, w0, w1, st0, st1, ride, n);
 }
+void state_init(hipStream_t s, double* dst, const double* q) {
+    StateInit a;
+    for (int i = 0; i < gvm::ST_SIZE; i++) a.q[i] = q[i];
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, s, dst, a);
+}
+void set_ints(hipStream_t s, int* dst, int a, int b) { hipLaunchKernelGGL(k_set_ints, dim3(1), dim3(64), 0, s, dst, a, b); }
 void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride) {
     hipLaunchKernelGGL(k_ride_mark, dim3(1), dim3(64), 0, s, st0, st1, ride);
 }
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
                 int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
-                const double* other_st, const int* ride_report) {
+                const double* other_st, const int* ride_report, const double* const* part, int part_nb) {
     CgxDecide a{};
     a.nsys = nsys;
     a.ride = ride;
     a.other_st = other_st;
     a.ride_report = ride_report;
-    for (int k = 0; k < nsys; k++) { a.st[k] = st[k]; a.red[k] = red[k]; a.relres[k] = relres[k]; }
-    hipLaunchKernelGGL(k_cgx_decide, dim3(1), dim3(64), 0, s, a, gam2, max_iter, go, mailbox, flag, seq);
+    a.part_nb = part_nb;
+    for (int k = 0; k < nsys; k++) {
+        a.st[k] = st[k]; a.red[k] = red[k]; a.relres[k] = relres[k];
+        a.part[k] = part ? part[k] : nullptr;
+    }
+    hipLaunchKernelGGL(k_cgx_decide, dim3(1), dim3(256), 0, s, a, gam2, max_iter, go, mailbox, flag, seq);
 }
 
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n, double* partial,

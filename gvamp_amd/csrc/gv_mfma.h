@@ -36,6 +36,9 @@ struct CgHook {
     // Ax side (k_prep_ax): the search direction is advanced on the way in, p <- z + beta p, when the system stepped
     double* p[2] = {nullptr, nullptr};
     const double* z[2] = {nullptr, nullptr};
+    // ATx side (k_prep_atx): the same for an N-space system whose search direction is the operand of slot v (gv_cg_solve_aat2w)
+    double* pn[2] = {nullptr, nullptr};
+    const double* zn[2] = {nullptr, nullptr};
     // ATx side (k_fin_atx_dot): <out, addx> = <Q p, p>, block partials, then gvk::finalize -> dot_out[v][0]
     // Rider (gv_cg_extras.ride_x): while *ride == 1 and exactly one of the two systems has finished, the finished system's
     // slot of a two-vector Ax pass carries alt_x instead (decided on the device: the host learns of a finished system one
@@ -45,6 +48,7 @@ struct CgHook {
     double* ride_out = nullptr;              // != NULL: the Ax epilogue writes the rider's product there itself (no k_ride_copy)
     double* dot_part[2] = {nullptr, nullptr};
     double* dot_out[2] = {nullptr, nullptr};
+    bool dot_self = false;                   // the consumer adds the block partials of <out, addx> up itself: no gvk::finalize launch
 };
 
 struct Plan {
@@ -69,7 +73,6 @@ struct Plan {
     double* ev = nullptr;           // M doubles: e = (mave - 3) * c
     double* cv2 = nullptr;          // the same for the second vector of a two-vector Ax
     double* ev2 = nullptr;
-    unsigned int* counters = nullptr;   // 2 ticket counters of the prep kernels (last block finalises), zero between launches
     double* scal = nullptr;         // 2 x 4 doubles: amax, sum, 2^(54-e), 2^(e-54) (second set: marker_sums2's p2)
     int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
     size_t partial_bytes = 0;
@@ -103,6 +106,8 @@ void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, 
              double* red_partial, const CgHook* cg = nullptr);
 void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
              double* outa, double* outb, const CgHook* cg = nullptr);
+
+int atx_dot_blocks(const Plan& pl);   // number of block partials of the fused <d, p> (CgHook::dot_part)
 
 // two vectors per pass (the LMMSE and the Onsager CG of one VAMP iteration share the operator, vamp.cpp:593-596,:884)
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,

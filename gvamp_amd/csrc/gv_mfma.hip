@@ -160,18 +160,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // scal[0] = amax, scal[1] = sum (ordered), scal[2] = 2^(54-e) (quantisation multiplier, 0 if amax is 0 / not finite),
-// scal[3] = 2^(e-54).  Run by the LAST block of a prep launch to finish (ticket counter): the block partials are read
-// through the L2 (agent-scope atomic loads) and combined in a fixed order, so the scalars do not depend on which block
-// happens to be last.
-__device__ __forceinline__ double ld_l2(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ void prep_final(const double* partial, int nblocks, double* scal, double* shm, double* shs) {
+// scal[3] = 2^(e-54).  The prep kernels leave block partials; every block of the quantisation launch behind them adds them up
+// for itself in a fixed order (prep_scalars) and block 0 stores the four scalars for the epilogue of the pass.  (Until round 3
+// the LAST block of the prep launch did it behind a ticket counter: 256 serialised atomics per vector, 12 of the 17-21 us a
+// two-vector k_prep_ax took at M = 200k -- profiles/r3_cfg5_gaps.txt.)
+__device__ __forceinline__ void prep_scalars(const double* __restrict__ partial, int nblocks, double* shm, double* shs,
+                                              double (&out)[4]) {
     double mx = 0.0, s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) {
-        mx = fmax(mx, ld_l2(partial + 2 * b));
-        s += ld_l2(partial + 2 * b + 1);
+        mx = fmax(mx, partial[2 * b]);
+        s += partial[2 * b + 1];
     }
     shm[threadIdx.x] = mx;
     shs[threadIdx.x] = s;
@@ -183,29 +181,26 @@ __device__ void prep_final(const double* partial, int nblocks, double* scal, dou
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        double amax = shm[0];
-        scal[0] = amax;
-        scal[1] = shs[0];
-        if (amax > 0.0 && amax <= 1.7976931348623157e308) {
-            int e = ilogb(amax) + 1;
-            scal[2] = ldexp(1.0, 54 - e);
-            scal[3] = ldexp(1.0, e - 54);
-        } else if (amax == 0.0) {
-            scal[2] = 0.0;
-            scal[3] = 0.0;
-        } else {
-            // a NaN or an infinity among the entries (the prep kernels raise amax to +inf for either): fixed point has no
-            // encoding for it.  Defined behaviour = what fp64 sums over the whole vector give in the reference: every
-            // output entry of this product is NaN (digits are quantised with multiplier 0, the epilogue multiplies by NaN).
-            scal[2] = 0.0;
-            scal[3] = __longlong_as_double(0x7ff8000000000000LL);
-        }
+    const double amax = shm[0];
+    out[0] = amax;
+    out[1] = shs[0];
+    if (amax > 0.0 && amax <= 1.7976931348623157e308) {
+        int e = ilogb(amax) + 1;
+        out[2] = ldexp(1.0, 54 - e);
+        out[3] = ldexp(1.0, e - 54);
+    } else if (amax == 0.0) {
+        out[2] = 0.0;
+        out[3] = 0.0;
+    } else {
+        // a NaN or an infinity among the entries (the prep kernels raise amax to +inf for either): fixed point has no
+        // encoding for it.  Defined behaviour = what fp64 sums over the whole vector give in the reference: every
+        // output entry of this product is NaN (digits are quantised with multiplier 0, the epilogue multiplies by NaN).
+        out[2] = 0.0;
+        out[3] = __longlong_as_double(0x7ff8000000000000LL);
     }
 }
-// block partials written -> ticket; true in the block that took the last ticket (it also resets the counter)
-__device__ __forceinline__ bool last_block(double* partial_v, double mx, double s, unsigned int* counter, double* shm, double* shs) {
-    __shared__ bool is_last;
+// block partials of a prep launch: [2b] = max, [2b + 1] = sum (fixed order within the block)
+__device__ __forceinline__ void prep_block_partials(double* partial_v, double mx, double s, double* shm, double* shs) {
     mx = wave_max(mx);
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = mx; shs[threadIdx.x >> 6] = s; }
@@ -213,13 +208,7 @@ __device__ __forceinline__ bool last_block(double* partial_v, double mx, double 
     if (threadIdx.x == 0) {
         partial_v[2 * blockIdx.x] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
         partial_v[2 * blockIdx.x + 1] = shs[0] + shs[1] + shs[2] + shs[3];
-        __threadfence();
-        const unsigned int t = atomicAdd(counter, 1u);
-        is_last = t == gridDim.x - 1;
-        if (is_last) *counter = 0;
     }
-    __syncthreads();
-    return is_last;
 }
 
 constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per vector
@@ -231,9 +220,8 @@ constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per v
 struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2];
                 const int* ride; const double* alt_x; const int* go; };
 __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
-                                                 int64_t M, double* __restrict__ partial, double* __restrict__ scal,
-                                                 unsigned int* __restrict__ counters) {
-    __shared__ double shm[256], shs[256];
+                                                 int64_t M, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
     if (a.go && *a.go == 0) return;      // a pass enqueued after every system had finished: dropped (as its streaming kernel is)
     const int v = blockIdx.y;
     const double* x = a.x[v];
@@ -261,8 +249,7 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
         mx = (isfinite(c) && isfinite(e)) ? fmax(mx, fmax(fabs(c), fabs(e))) : __longlong_as_double(0x7ff0000000000000LL);
         s += mu * c;
     }
-    if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
-        prep_final(partial + v * PREP_STRIDE, gridDim.x, scal + 4 * v, shm, shs);
+    prep_block_partials(partial + v * PREP_STRIDE, mx, s, shm, shs);
 }
 // Operands of the three per-individual sums behind data::compute_people_statistics (data.cpp:590-624), in the Ax form
 // out = sum_m plane_m c_m + sum_m miss_m e_m - K0 with sigma = msig, mu = mave:
@@ -273,9 +260,8 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
 // what the code 3 and K0 put in.)  kind 1 + kind 2 = sum_m b ((a - mu) sigma)^2.
 __global__ __launch_bounds__(256) void k_prep_people(int kind, const double* __restrict__ mave, const double* __restrict__ msig,
                                                      int64_t M, double* __restrict__ cv, double* __restrict__ ev,
-                                                     double* __restrict__ partial, double* __restrict__ scal,
-                                                     unsigned int* __restrict__ counters) {
-    __shared__ double shm[256], shs[256];
+                                                     double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
     double mx = 0.0, s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
         const double mu = mave[i], s2 = msig[i] * msig[i];
@@ -294,41 +280,63 @@ __global__ __launch_bounds__(256) void k_prep_people(int kind, const double* __r
         mx = fmax(mx, fmax(fabs(c), fabs(e)));
         s += k;
     }
-    if (last_block(partial, mx, s, counters, shm, shs)) prep_final(partial, gridDim.x, scal, shm, shs);
+    prep_block_partials(partial, mx, s, shm, shs);
 }
 // ATx operand p: block partials [0] = max|p|, [1] = sum p.  blockIdx.y = vector.
-struct PrepAtx { const double* p[2]; const int* go; };
-__global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* __restrict__ partial, double* __restrict__ scal,
-                                                  unsigned int* __restrict__ counters) {
-    __shared__ double shm[256], shs[256];
+// CG hook (gv_cg_solve_aat2w, N-space system): slot v's operand is the search direction p of system st[v]; when that system
+// took a step and is still running, p <- z + beta p (denoiserXXT.cpp:109-110) happens here, on the way into the digits, as
+// k_prep_ax does it for the M-space systems (= k_p_update_st, bit for bit).
+struct PrepAtx { const double* p[2]; const int* go; const double* st[2]; double* pw[2]; const double* z[2]; };
+__global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
     if (a.go && *a.go == 0) return;
     const int v = blockIdx.y;
-    const double* __restrict__ p = a.p[v];
+    const double* p = a.p[v];
+    const double* st = a.st[v];
+    const bool upd = st && a.pw[v] && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;
+    const double beta = upd ? st[gvm::ST_BETA] : 0.0;
+    const double* zz = a.z[v];
+    double* pw = a.pw[v];
     double mx = 0.0, s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         double val = p[i];
+        if (upd) {
+            val = fma(beta, val, zz[i]);
+            pw[i] = val;
+        }
         mx = isfinite(val) ? fmax(mx, fabs(val)) : __longlong_as_double(0x7ff0000000000000LL);   // fmax would drop a NaN
         s += val;
     }
-    if (last_block(partial + v * PREP_STRIDE, mx, s, counters + v, shm, shs))
-        prep_final(partial + v * PREP_STRIDE, gridDim.x, scal + 4 * v, shm, shs);
+    prep_block_partials(partial + v * PREP_STRIDE, mx, s, shm, shs);
 }
 
 // fixed-point digits of v in MFMA B-operand order.  Thread = (kb, g, d, s): 4 entries k = 256kb+64g+16d+4t+s (t=0..3)
 // become byte t of one dword per digit c, stored at byte  ((kb*4 + d)*4 + g)*ncol*16 + (col0 + c)*16 + 4s.
 // Digit column 7 of each vector is zero.
 // ncol = 8 (ATx: 2 KiB per K-block) or 16 (Ax: [c | e], 4 KiB per K-block); col0 = first column of this vector.
-struct QuantArgs { const double* v[4]; const double* scal[4]; uint32_t* out[4]; int col0[4]; };
+// part[j] / nblocks: the block partials the prep launch left for the vector of slot j; scal[j]: where block 0 of a slot with
+// wr[j] != 0 stores the vector's four scalars (two slots may quantise two operands of ONE vector -- c and e -- with one scale)
+struct QuantArgs { const double* v[4]; double* scal[4]; const double* part[4]; uint32_t* out[4]; int col0[4]; int wr[4]; int nblocks; };
+// the scale of this block's vector from the prep launch's block partials (every block for itself, same order: same bits)
+__device__ __forceinline__ double quant_scale(const QuantArgs& a) {
+    __shared__ double shm[256], shs[256];
+    double sc[4];
+    prep_scalars(a.part[blockIdx.y], a.nblocks, shm, shs, sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.wr[blockIdx.y]) {
+        double* o = a.scal[blockIdx.y];
+        o[0] = sc[0]; o[1] = sc[1]; o[2] = sc[2]; o[3] = sc[3];
+    }
+    return sc[2];
+}
 __global__ __launch_bounds__(256) void k_quant(QuantArgs a, int64_t n, int64_t nkb, int ncol) {
     const double* __restrict__ v = a.v[blockIdx.y];
-    const double* __restrict__ scal = a.scal[blockIdx.y];
     uint32_t* __restrict__ out = a.out[blockIdx.y];
     const int col0 = a.col0[blockIdx.y];
+    const double mult = quant_scale(a);
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nkb * 64) return;
     const int s = tid & 3, d = (tid >> 2) & 3, g = (tid >> 4) & 3;
     const int64_t kb = tid >> 6;
-    const double mult = scal[2];
     uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -1046,14 +1054,13 @@ __global__ __launch_bounds__(256) void k_stats_tile(const uint4* __restrict__ ti
 // kstep * 256 + (gam * 16 + col0 + c) * 4 + i.  Thread = (kstep, i, gam): four consecutive entries.
 __global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t nsteps) {
     const double* __restrict__ v = a.v[blockIdx.y];
-    const double* __restrict__ scal = a.scal[blockIdx.y];
     uint32_t* __restrict__ out = a.out[blockIdx.y];
     const int col0 = a.col0[blockIdx.y];
+    const double mult = quant_scale(a);
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= nsteps * 16) return;
     const int gam = tid & 3, i = (tid >> 2) & 3;
     const int64_t kstep = tid >> 4;
-    const double mult = scal[2];
     uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -1345,8 +1352,7 @@ void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* ma
                        nkb, P4, nonas, alpha_scale, mave, msig, counts);
 }
 
-// Blocks of a prep launch.  The last block to finish re-reads every block's partials (prep_final), so the launch pays for
-// each extra block twice; measured on an N = 400k vector: 1024 blocks 42 us, 256 blocks 14 us, 128 blocks 11 us.
+// Blocks of a prep launch (every block of the quantisation launch behind it adds their partials up: prep_scalars)
 constexpr int PREP_BLOCKS = 256;
 static int prep_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -1355,13 +1361,17 @@ static int prep_blocks(int64_t n) {
 
 // vector preparation of one (nv = 1) or two (nv = 2) N-vectors: scal[4v..] and the digit columns 8v.. of dig0
 static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, double* red_partial,
-                           const int* go = nullptr) {
+                           const CgHook* cg = nullptr) {
     const int nv = pb ? 2 : 1, nb = prep_blocks(npad);
-    PrepAtx pa_{{pa, pb}, go};
-    hipLaunchKernelGGL(k_prep_atx, dim3(nb, nv), dim3(256), 0, s, pa_, npad, red_partial, pl.scal, pl.counters);
+    PrepAtx pa_{{pa, pb}, cg ? cg->go : nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (cg)
+        for (int v = 0; v < nv; v++)
+            if (cg->pn[v]) { pa_.st[v] = cg->state[v]; pa_.pw[v] = cg->pn[v]; pa_.z[v] = cg->zn[v]; }
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb, nv), dim3(256), 0, s, pa_, npad, red_partial);
     QuantArgs q{};
-    q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
-    q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
+    q.nblocks = nb;
+    q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0; q.part[0] = red_partial; q.wr[0] = 1;
+    q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8; q.part[1] = red_partial + PREP_STRIDE; q.wr[1] = 1;
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), nv), dim3(256), 0, s, q, npad, pl.nkb_m, nv == 2 ? 16 : 8);
 }
 
@@ -1381,13 +1391,16 @@ static void fin_atx_cg(hipStream_t s, const Plan& pl, const Decomp& d, int nv, c
     const int nb = dot_blocks(pl.M);
     hipLaunchKernelGGL(k_fin_atx_dot, dim3(nb, nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M,
                        pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, nv == 2 ? 4 : 2, pl.nkb_m, d.skL, piv_of(d, (pl.nrg_m + 3) / 4));
-    for (int v = 0; v < nv; v++)
-        if (cg.dot_out[v]) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
+    if (!cg.dot_self)
+        for (int v = 0; v < nv; v++)
+            if (cg.dot_out[v]) gvk::finalize(s, cg.dot_part[v], nb, 1, cg.dot_out[v]);
 }
+// blocks of the <d, p> partials k_fin_atx_dot leaves (for a consumer that adds them up itself: CgHook::dot_self)
+int atx_dot_blocks(const Plan& pl) { return dot_blocks(pl.M); }
 
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,
          double inv_sqrt_n, double* red_partial, double* out, const double* addx, double tau, double gam2, const CgHook* cg) {
-    prep_quant_atx(s, pl, p, nullptr, npad, red_partial, cg ? cg->go : nullptr);
+    prep_quant_atx(s, pl, p, nullptr, npad, red_partial, cg);
     launch_stream<0>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[0], cg ? cg->go : nullptr);
     if (cg && cg->dot_out[0]) {
         double* o[2] = {out, nullptr};
@@ -1404,7 +1417,7 @@ void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const dou
 void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int64_t npad, const double* mave,
           const double* msig, double inv_sqrt_n, double* red_partial, double* outa, double* outb, const double* addxa,
           const double* addxb, double tau, double gam2, const CgHook* cg) {
-    prep_quant_atx(s, pl, pa, pb, npad, red_partial, cg ? cg->go : nullptr);
+    prep_quant_atx(s, pl, pa, pb, npad, red_partial, cg);
     launch_stream<2>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1], cg ? cg->go : nullptr);
     if (cg && (cg->dot_out[0] || cg->dot_out[1])) {
         double* o[2] = {outa, outb};
@@ -1432,8 +1445,12 @@ void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double*
 
 // operands cv / ev (and cv2 / ev2) -> digit buffers of the Ax side.  Two stripe sets: one vector dig0 = [c | e], two vectors
 // dig0 = [c_a | c_b], dig1 = [e_a | e_b].  Tile layout: always the second form (a one-vector pass leaves columns 8..15 unused).
-static void quant_ax(hipStream_t s, const Plan& pl, int nv) {
+static void quant_ax(hipStream_t s, const Plan& pl, int nv, const double* red_partial, int nb) {
     QuantArgs q{};
+    q.nblocks = nb;
+    q.part[0] = q.part[1] = red_partial;                      // slots 0, 1: c and e of vector a; 2, 3: of vector b
+    q.part[2] = q.part[3] = red_partial + PREP_STRIDE;
+    q.wr[0] = q.wr[2] = 1;
     if (pl.layout == 1 || nv == 2) {
         q.v[0] = pl.cv;  q.scal[0] = pl.scal;     q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
         q.v[1] = pl.ev;  q.scal[1] = pl.scal;     q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;
@@ -1470,8 +1487,8 @@ void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, 
         for (int v = 0; v < nv; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
         if (nv == 2) { pa.ride = cg->ride; pa.alt_x = cg->alt_x; }
     }
-    hipLaunchKernelGGL(k_prep_ax, dim3(nb, nv), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial, pl.scal, pl.counters);
-    quant_ax(s, pl, nv);
+    hipLaunchKernelGGL(k_prep_ax, dim3(nb, nv), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial);
+    quant_ax(s, pl, nv, red_partial, nb);
 }
 void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
              double* outa, double* outb, const CgHook* cg) {
@@ -1502,9 +1519,8 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
 void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, const double* msig, const uint32_t* mask2,
                int64_t npad, double* red_partial, double* out) {
     const int nb = prep_blocks(pl.M);
-    hipLaunchKernelGGL(k_prep_people, dim3(nb), dim3(256), 0, s, kind, mave, msig, pl.M, pl.cv, pl.ev, red_partial, pl.scal,
-                       pl.counters);
-    quant_ax(s, pl, 1);
+    hipLaunchKernelGGL(k_prep_people, dim3(nb), dim3(256), 0, s, kind, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
+    quant_ax(s, pl, 1, red_partial, nb);
     gvm::Plan pq = pl;      // no roofline events around the statistics passes
     pq.ev0 = pq.ev1 = nullptr;
     if (kind == 1) launch_stream<4>(s, pq, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, pl.dn[0]);

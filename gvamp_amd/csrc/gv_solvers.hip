@@ -70,18 +70,13 @@ static void cg_capture_first_product(gv_ctx* c, const CgSys& s, double tau, doub
 static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
     // z = r / diag (:1152), <r,z>, ||v||^2 ; p = z (:1154)
     const int64_t M = c->M;
-    double sc[4];
-    arm_scalars(c);
-    gvk::cg_step_b(c->stream, s.r, s.d, 0.0, diag, s.z, s.mu, M, c->red_partial, c->red_out);
-    KCHK(c);
-    if (read_scalars(c, 4, sc)) return 1;
+    double sc[5];
+    gvk::cg_step_b(c->stream, s.r, s.d, 0.0, diag, s.z, s.mu, M, c->red_partial, c->red_out);          // red_out[0..3]
     const double* vv[1] = {s.v};
-    arm_scalars(c);
-    gvk::dots(c->stream, 1, vv, vv, M, c->red_partial, c->red_out);
+    gvk::dots(c->stream, 1, vv, vv, M, c->red_partial + 4 * RED_BLOCKS, c->red_out + 4);               // red_out[4]
     KCHK(c);
-    double vn2;
-    if (read_scalars(c, 1, &vn2)) return 1;
-    double pk[2] = {sc[0], vn2};
+    if (read_scalars(c, 5, sc)) return 1;            // both reductions in ONE read-back
+    double pk[2] = {sc[0], sc[4]};
     if (multi && allreduce_scalars(c, pk, 2)) return 1;
     s.rz = pk[0];
     s.norm_v = sqrt(pk[1]);
@@ -221,7 +216,6 @@ static int cgx_alloc(gv_ctx* c, int max_iter) {
     if (!c->cgx_state) {
         HIPCHK(c, hipMalloc(&c->cgx_state, sizeof(double) * 2 * gvm::ST_SIZE));
         HIPCHK(c, hipMalloc(&c->cgx_go, sizeof(int) * 4));
-        HIPCHK(c, hipHostMalloc(&c->cgx_pin, sizeof(double) * (2 * gvm::ST_SIZE + 2)));
     }
     if (max_iter > c->cgx_relcap) {
         if (c->cgx_rel) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->cgx_rel); c->cgx_rel = nullptr; }
@@ -274,23 +268,21 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     c->plan.ev0 = c->plan.ev1 = nullptr;       // no per-launch events inside the loop
     const bool riding = ride_x != nullptr && nsys == 2;
     // ---- initial states -> device
-    double* pin = c->cgx_pin;
     int go0 = 0;
     for (int k = 0; k < 2; k++) {
-        double* q = pin + k * gvm::ST_SIZE;
+        double q[gvm::ST_SIZE];
         for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
-        if (k >= nsys) continue;
-        const CgSys& s = sys[k];
-        q[gvm::ST_RZ] = s.rz; q[gvm::ST_NORMV] = s.norm_v; q[gvm::ST_PREV_ONS] = s.prev_onsager; q[gvm::ST_ONS] = s.onsager;
-        q[gvm::ST_RELERR] = s.rel_err; q[gvm::ST_ACTIVE] = s.active ? 1.0 : 0.0; q[gvm::ST_ITERS] = s.iters;
-        q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
-        go0 |= s.active ? 1 : 0;
+        if (k < nsys) {
+            const CgSys& s = sys[k];
+            q[gvm::ST_RZ] = s.rz; q[gvm::ST_NORMV] = s.norm_v; q[gvm::ST_PREV_ONS] = s.prev_onsager; q[gvm::ST_ONS] = s.onsager;
+            q[gvm::ST_RELERR] = s.rel_err; q[gvm::ST_ACTIVE] = s.active ? 1.0 : 0.0; q[gvm::ST_ITERS] = s.iters;
+            q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
+            go0 |= s.active ? 1 : 0;
+        }
+        gvk::state_init(st, c->cgx_state + k * gvm::ST_SIZE, q);        // (by value in the launch: no pinned staging to protect)
     }
-    int* pin_go = reinterpret_cast<int*>(pin + 2 * gvm::ST_SIZE);
-    pin_go[0] = go0;
-    pin_go[1] = riding ? 1 : 0;                // 1: rider pending, 2: rode
-    HIPCHK(c, hipMemcpyAsync(c->cgx_state, pin, sizeof(double) * 2 * gvm::ST_SIZE, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->cgx_go, pin_go, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+    gvk::set_ints(st, c->cgx_go, go0, riding ? 1 : 0);                    // rider word: 1 pending, 2 rode
+    KCHK(c);
     double* dst[2] = {c->cgx_state, c->cgx_state + gvm::ST_SIZE};
     double* drel[2] = {c->cgx_rel, c->cgx_rel + c->cgx_relcap};
     int* d_ride = c->cgx_go + 1;
@@ -326,6 +318,10 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             hk.dot_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8;
             hk.dot_out[j] = c->red_out + 8 * act[j];
         }
+        // one rank: no all-reduce between a reduction and its consumer -- the consumer adds the block partials up itself and the
+        // four k_finalize launches of a step go (gvk::cgx_ab / cgx_decide)
+        const bool self = !multi && M > 0;
+        hk.dot_self = self;
         double* wn[2] = {c->w_n->d, c->w_n2->d};
         if (two) {
             if (ovl) {             // chunks of individuals, each slice exchanged on the side stream behind the next chunk
@@ -366,15 +362,17 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         if (multi && comm_allreduce(c, c->red_out, K)) return 1;               // <d,p>
         {
             double *a_st[2], *a_mu[2], *a_r[2], *a_z[2], *a_part[2], *a_red[2];
-            const double *a_p[2], *a_v[2], *a_d[2], *a_dp[2];
+            const double *a_p[2], *a_v[2], *a_d[2], *a_dp[2], *a_dpp[2];
             for (int j = 0; j < ns; j++) {
                 CgSys& s = sys[act[j]];
                 a_st[j] = dst[act[j]]; a_mu[j] = s.mu; a_p[j] = s.p; a_v[j] = s.v; a_r[j] = s.r; a_d[j] = s.d; a_z[j] = s.z;
                 a_dp[j] = c->red_out + 8 * act[j];
-                a_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8;
+                a_dpp[j] = hk.dot_part[j];
+                a_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8 + 4 * RED_BLOCKS;   // (clear of the <d,p> partials)
                 a_red[j] = c->red_out + 8 * act[j];
             }
-            gvk::cgx_ab(st, ns, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M);
+            const int nb_ab = gvk::cgx_ab(st, ns, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M,
+                                          self ? a_dpp : nullptr, self ? gvm::atx_dot_blocks(c->plan) : 0);
             for (int j = 0; j < ns; j++)
                 if (sys[act[j]].az) gvk::axpy_st(st, sys[act[j]].az, wn[j], dst[act[j]], npad);   // A mu += alpha A p
             KCHK(c);
@@ -382,8 +380,9 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             const double* c_red[2] = {c->red_out, c->red_out + 8};
             double* c_rel[2] = {sys[0].relres ? drel[0] : nullptr, (nsys > 1 && sys[1].relres) ? drel[1] : nullptr};
             const unsigned long long seq = ++c->mbox_seq;
+            const double* c_part[2] = {c->red_partial + 4 * RED_BLOCKS, c->red_partial + (size_t)RED_BLOCKS * 8 + 4 * RED_BLOCKS};
             gvk::cgx_decide(st, nsys, dst, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq,
-                            (two && ride_pending) ? d_ride : nullptr);
+                            (two && ride_pending) ? d_ride : nullptr, nullptr, nullptr, self ? c_part : nullptr, nb_ab);
             KCHK(c);
             steps.push_back(seq);
         }
@@ -444,22 +443,22 @@ static bool cgx_usable(const gv_ctx* c) {
 }
 // initial state of one system -> device block blk (0 / 1); normv: ||v|| (M-space systems) or ||v||^2 (CG_solverAAT)
 static int cgx_upload_state(gv_ctx* c, int blk, double rz, double normv, int denoiser, bool active) {
-    double* q = c->cgx_pin + blk * gvm::ST_SIZE;
+    double q[gvm::ST_SIZE];
     for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
     q[gvm::ST_RZ] = rz; q[gvm::ST_NORMV] = normv; q[gvm::ST_ACTIVE] = active ? 1.0 : 0.0; q[gvm::ST_DENOISER] = denoiser;
-    HIPCHK(c, hipMemcpyAsync(c->cgx_state + blk * gvm::ST_SIZE, q, sizeof(double) * gvm::ST_SIZE, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // the pinned block may be rewritten for the other system right away
+    gvk::state_init(c->stream, c->cgx_state + blk * gvm::ST_SIZE, q);      // (by value in the launch: nothing to wait for)
+    KCHK(c);
     return 0;
 }
 // the same for an M-space system that may already have taken steps on the host (iteration count, Onsager memory, trace length)
 static int cgx_upload_sys(gv_ctx* c, int blk, const CgSys& s) {
-    double* q = c->cgx_pin + blk * gvm::ST_SIZE;
+    double q[gvm::ST_SIZE];
     for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
     q[gvm::ST_RZ] = s.rz; q[gvm::ST_NORMV] = s.norm_v; q[gvm::ST_PREV_ONS] = s.prev_onsager; q[gvm::ST_ONS] = s.onsager;
     q[gvm::ST_RELERR] = s.rel_err; q[gvm::ST_ACTIVE] = s.active ? 1.0 : 0.0; q[gvm::ST_ITERS] = s.iters;
     q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
-    HIPCHK(c, hipMemcpyAsync(c->cgx_state + blk * gvm::ST_SIZE, q, sizeof(double) * gvm::ST_SIZE, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    gvk::state_init(c->stream, c->cgx_state + blk * gvm::ST_SIZE, q);
+    KCHK(c);
     return 0;
 }
 // one CG_solverAAT step (state block 0) after d = A (A^T p) has arrived
@@ -467,7 +466,7 @@ static int aat_step_device(gv_ctx* c, double* mu, double* p, double* r, double* 
                            double gam2, int max_iter, bool want_rel, CgxStatus* out, double* at_acc = nullptr,
                            const double* at_p = nullptr) {
     const unsigned long long seq = ++c->mbox_seq;
-    gvk::aat_step(c->stream, c->cgx_state, mu, p, r, d, z, DG, tau, gam2, c->npad, c->red_partial, c->red_out + 16,
+    gvk::aat_step(c->stream, c->cgx_state, mu, p, r, d, z, DG, tau, gam2, c->npad, c->red_partial,
                   want_rel ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq,
                   at_acc, at_p, c->M);
     KCHK(c);
@@ -476,22 +475,28 @@ static int aat_step_device(gv_ctx* c, double* mu, double* p, double* r, double* 
     *out = s2[0];
     return 0;
 }
+// one rank: the consumers of the M-space system's reductions add the block partials up themselves (no k_finalize launches)
+static bool mspace_self_reduce(const gv_ctx* c, bool multi) { return !multi && c->M > 0; }
 // one precondCG_solver step of the M-space system in state block 1 after d = Q p has arrived through an ATx pass whose
 // epilogue (CgHook: dot_part / dot_out = red_partial / red_out) left <d,p>
 static int mspace_step_device(gv_ctx* c, CgSys& sb, double gam2, double diag, int max_iter, bool multi, CgxStatus* out) {
     double* dst1 = c->cgx_state + gvm::ST_SIZE;
     if (multi && comm_allreduce(c, c->red_out, 8)) return 1;
-    double *a_st[1] = {dst1}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z}, *a_part[1] = {c->red_partial},
+    const bool self = mspace_self_reduce(c, multi);        // (the pass before this step was enqueued with CgHook::dot_self = self)
+    double *a_st[1] = {dst1}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z}, *a_part[1] = {c->red_partial + 4 * RED_BLOCKS},
            *a_red[1] = {c->red_out};
-    const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out};
-    gvk::cgx_ab(c->stream, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, c->M);
+    const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out}, *a_dpp[1] = {c->red_partial};
+    const int nb_ab = gvk::cgx_ab(c->stream, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, c->M,
+                                  self ? a_dpp : nullptr, self ? gvm::atx_dot_blocks(c->plan) : 0);
     KCHK(c);
     if (multi && comm_allreduce(c, c->red_out, 8)) return 1;
     const double* c_red[1] = {c->red_out};
+    const double* c_part[1] = {a_part[0]};
     double* c_rel[1] = {sb.relres ? c->cgx_rel + c->cgx_relcap : nullptr};
     const unsigned long long seq = ++c->mbox_seq;
     gvk::cgx_decide(c->stream, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
-                    reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq, nullptr);
+                    reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq, nullptr, nullptr, nullptr,
+                    self ? c_part : nullptr, nb_ab);
     KCHK(c);
     CgxStatus s2[2];
     if (cgx_wait(c, seq, s2)) return 1;
@@ -685,12 +690,65 @@ int gv_cg_solve2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const g
     return gv_cg_solve2x(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, mu_b, st_a, st_b, relres_a, relres_b, nullptr);
 }
 
+// Work vectors of the N-space solvers: nn N-space vectors and nm M-space ones as views into ONE allocation the context keeps
+// between calls, zeroed by one fill per call (six allocations, six fills and six releases per solve before: ~0.1 ms of a
+// 5 ms VAMP iteration at N = 50k).  vec_del on a view releases the handle only.
+static int aat_scratch(gv_ctx* c, int nn, int nm, gv_vec** out) {
+    const size_t ln = (size_t)c->npad, lm = (size_t)(c->M > 0 ? c->M : 1);
+    const size_t lm_pad = (lm + 63) / 64 * 64;
+    const size_t need = ln * (size_t)nn + lm_pad * (size_t)nm;
+    if (c->aat_slab_cap < need) {
+        if (c->aat_slab) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->aat_slab);
+            c->aat_slab = nullptr;
+            c->aat_slab_cap = 0;
+        }
+        if (hipMalloc(&c->aat_slab, sizeof(double) * need) != hipSuccess) {
+            (void)hipGetLastError();
+            c->aat_slab = nullptr;
+            return fail(c, "no room for the work vectors of the N-space solver (%zu doubles)", need);
+        }
+        c->aat_slab_cap = need;
+    }
+    HIPCHK(c, hipMemsetAsync(c->aat_slab, 0, sizeof(double) * need, c->stream));
+    double* at = c->aat_slab;
+    for (int k = 0; k < nn + nm; k++) {
+        gv_vec* v = new gv_vec();
+        v->ctx = c;
+        v->space = k < nn ? GV_SPACE_N : GV_SPACE_M;
+        v->len = k < nn ? 4 * c->mbytes : c->M;
+        v->cap = k < nn ? c->npad : (int64_t)lm;
+        v->d = at;
+        v->owns = false;
+        c->live_vecs.insert(v);
+        out[k] = v;
+        at += k < nn ? ln : lm_pad;
+    }
+    return 0;
+}
+
 // vamp::lmmse_multAAT (denoiserXXT.cpp:15-35): out = tau A A^T u + gam2 u on N-space device pointers
 static int lmmse_aat_device(gv_ctx* c, const double* u, double tau, double gam2, double* tmpM, double* out) {
     if (atx_device(c, u, tmpM)) return 1;
     if (ax_device(c, tmpM, out)) return 1;
     gvk::axpby(c->stream, out, tau, out, gam2, u, c->npad);
     KCHK(c);
+    return 0;
+}
+
+// z = r / diag (denoiserXXT.cpp:76-77) with <r,z>, and ||v||^2: two reductions into neighbouring scalars, ONE read-back
+static int aat_init_scalars(gv_ctx* c, double* r, double* d, const double* diag, double* z, const double* v, double* rz,
+                            double* vn2) {
+    const int64_t n = c->npad;
+    gvk::cg_step_b_diag(c->stream, r, d, 0.0, diag, z, n, c->red_partial, c->red_out);          // red_out[0..1]
+    const double* vv[1] = {v};
+    gvk::dots(c->stream, 1, vv, vv, n, c->red_partial + 2 * RED_BLOCKS, c->red_out + 2);         // red_out[2]
+    KCHK(c);
+    double sc[3];
+    if (read_scalars(c, 3, sc)) return 1;
+    *rz = sc[0];
+    *vn2 = sc[2];
     return 0;
 }
 
@@ -704,10 +762,10 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
     if (ensure_work(c)) return 1;
     hipStream_t s = c->stream;
     const int64_t n = c->npad;
-    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG}) vec_del(c, x); };
-    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
-        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
+    gv_vec* W[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (gv_vec* x : W) vec_del(c, x); };
+    if (aat_scratch(c, 5, 0, W)) return 1;
+    gv_vec *R = W[0], *Z = W[1], *P = W[2], *D = W[3], *DG = W[4];
     double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_out->d, *tmpM = c->cg_d->d;
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
     int rc = 0, iters = 0, converged = 0, n_relres = 0;
@@ -724,15 +782,8 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
             gvk::fill(s, mu, n, 0.0);
             AAT_HIP(hipMemcpyAsync(r, v->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         }
-        arm_scalars(c);
-        gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);   // z = r / diag (:76-77)
-        AAT_TRY(read_scalars(c, 2, sc));
-        double rz = sc[0];
-        const double* vv[1] = {v->d};
-        arm_scalars(c);
-        gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
-        double vn2;
-        AAT_TRY(read_scalars(c, 1, &vn2));
+        double rz, vn2;
+        AAT_TRY(aat_init_scalars(c, r, d, DG->d, z, v->d, &rz, &vn2));      // z = r / diag (:76-77), <r,z>, ||v||^2
         AAT_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         if (cgx_usable(c) && max_iter > 0) {      // scalars on the device, one read-back per step
             AAT_TRY(cgx_alloc(c, max_iter));
@@ -870,11 +921,10 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
     const bool multi = is_multi(c);
     const bool dev = cgx_usable(c) && max_iter > 0;      // scalars of both systems on the device (state blocks 0 = a, 1 = b)
     if (dev && cgx_alloc(c, max_iter)) return 1;
-    gv_vec *R = nullptr, *Z = nullptr, *P = nullptr, *D = nullptr, *DG = nullptr, *MA = nullptr;
-    auto cleanup = [&]() { for (gv_vec* x : {R, Z, P, D, DG, MA}) vec_del(c, x); };
-    for (gv_vec** x : {&R, &Z, &P, &D, &DG})
-        if (vec_new(c, GV_SPACE_N, x)) { cleanup(); return 1; }
-    if (vec_new(c, GV_SPACE_M, &MA)) { cleanup(); return 1; }
+    gv_vec* W[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (gv_vec* x : W) vec_del(c, x); };
+    if (aat_scratch(c, 5, 1, W)) return 1;
+    gv_vec *R = W[0], *Z = W[1], *P = W[2], *D = W[3], *DG = W[4], *MA = W[5];
     double *r = R->d, *z = Z->d, *p = P->d, *d = D->d, *mu = mu_a->d;
     const int64_t ax0 = c->cnt.n_ax, atx0 = c->cnt.n_atx;
     int rc = 0;
@@ -906,21 +956,12 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         if (dev && sb.relres) sb.relres = &rel0;
         MIX_TRY(cg_first_step_from_known_product(c, sb, tau, gam2, diag_b, max_iter, multi));
         sb.relres = keep_rel;
-        if (dev && keep_rel && sb.n_relres > 0)
-            MIX_HIP(hipMemcpyAsync(c->cgx_rel + c->cgx_relcap, &rel0, sizeof(double), hipMemcpyHostToDevice, s));
-        if (dev) { MIX_HIP(hipStreamSynchronize(s)); MIX_TRY(cgx_upload_sys(c, 1, sb)); }
+        if (dev && keep_rel && sb.n_relres > 0) gvk::fill(s, c->cgx_rel + c->cgx_relcap, 1, rel0);
+        if (dev) MIX_TRY(cgx_upload_sys(c, 1, sb));
     }
     {
         auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
-            double sc[2];
-            arm_scalars(c);
-            gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, c->red_out);
-            if (read_scalars(c, 2, sc)) return 1;
-            a_rz = sc[0];
-            const double* vv[1] = {v_a->d};
-            arm_scalars(c);
-            gvk::dots(s, 1, vv, vv, n, c->red_partial, c->red_out);
-            if (read_scalars(c, 1, &a_vn2)) return 1;
+            if (aat_init_scalars(c, r, d, DG->d, z, v_a->d, &a_rz, &a_vn2)) return 1;
             if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
             return 0;
         };
@@ -1008,13 +1049,12 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                     double* stA = c->cgx_state;
                     double* stB = c->cgx_state + gvm::ST_SIZE;
                     unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK);
-                    int* pin_go = reinterpret_cast<int*>(c->cgx_pin + 2 * gvm::ST_SIZE);
                     int* d_ride = c->cgx_go + 1;
                     bool ride_pending = hz.pending;
-                    pin_go[0] = 1;
-                    pin_go[1] = ride_pending ? 1 : 0;
-                    MIX_HIP(hipMemcpyAsync(c->cgx_go, pin_go, 2 * sizeof(int), hipMemcpyHostToDevice, s));
-                    MIX_HIP(hipStreamSynchronize(s));          // (the pinned words are reused by the next call)
+                    gvk::set_ints(s, c->cgx_go, 1, ride_pending ? 1 : 0);
+                    // from here on p_a <- z_a + beta p_a belongs to the k_prep_atx of the next X pass; a host-paced step before this
+                    // point has advanced p_a already and must not be seen as pending
+                    gvk::fill(s, stA + gvm::ST_STEPPED, 1, 0.0);
                     struct PassRec { int kind; bool slotA, slotB; };
                     struct StepRec { int sys; unsigned long long seq; int after_pass; };
                     std::vector<PassRec> passes;
@@ -1044,8 +1084,11 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                         gvm::CgHook hk;
                         hk.go = c->cgx_go;
                         const int iB = slotA ? 1 : 0;           // B's slot index in the pass
+                        const bool self = mspace_self_reduce(c, multi);
                         if (kind == 1) {                        // X: MA = A^T p_a | d_b = tau A^T w + gam2 p_b, <d_b, p_b>
-                            if (slotB) { hk.state[iB] = stB; hk.dot_part[iB] = c->red_partial; hk.dot_out[iB] = c->red_out; }
+                            // (p_a <- z_a + beta p_a on the way in: the A-step behind the Y pass leaves it to this launch)
+                            if (slotA) { hk.state[0] = stA; hk.pn[0] = p; hk.zn[0] = z; }
+                            if (slotB) { hk.state[iB] = stB; hk.dot_part[iB] = c->red_partial; hk.dot_out[iB] = c->red_out; hk.dot_self = self; }
                             if (slotA && slotB) MIX_TRY(atx2_device(c, p, c->w_n->d, MA->d, sb.d, nullptr, sb.p, tau, gam2, &hk));
                             else if (slotA) MIX_TRY(atx_device(c, p, MA->d, nullptr, tau, gam2, &hk));
                             else MIX_TRY(atx_device(c, c->w_n->d, sb.d, sb.p, tau, gam2, &hk));
@@ -1053,15 +1096,19 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                             if (slotB && hostB) {
                                 if (b_first_capture) { cg_capture_first_product(c, sb, tau, gam2, diag_b); b_first_capture = false; }
                                 if (multi && comm_allreduce(c, c->red_out, 8)) { rc = 1; goto done; }
-                                double *a_st[1] = {stB}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z}, *a_part[1] = {c->red_partial},
-                                       *a_red[1] = {c->red_out};
-                                const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out};
-                                gvk::cgx_ab(s, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag_b, M);
+                                double *a_st[1] = {stB}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z},
+                                       *a_part[1] = {c->red_partial + 4 * RED_BLOCKS}, *a_red[1] = {c->red_out};
+                                const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out},
+                                             *a_dpp[1] = {c->red_partial};
+                                const int nb_ab = gvk::cgx_ab(s, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag_b, M,
+                                                              self ? a_dpp : nullptr, self ? gvm::atx_dot_blocks(c->plan) : 0);
                                 if (multi && comm_allreduce(c, c->red_out, 8)) { rc = 1; goto done; }
                                 const double* c_red[1] = {c->red_out};
+                                const double* c_part[1] = {a_part[0]};
                                 double* c_rel[1] = {sb.relres ? c->cgx_rel + c->cgx_relcap : nullptr};
                                 const unsigned long long seq = ++c->mbox_seq;
-                                gvk::cgx_decide(s, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq, nullptr, stA, d_ride);
+                                gvk::cgx_decide(s, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev, flag_dev, seq, nullptr, stA,
+                                                d_ride, self ? c_part : nullptr, nb_ab);
                                 MIX_HIP(hipGetLastError());
                                 steps.push_back(StepRec{1, seq, (int)passes.size() - 1});
                             }
@@ -1081,9 +1128,9 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                             if (may_ride && !hostA) gvk::ride_mark(s, stA, stB, d_ride);
                             if (slotA && hostA) {
                                 const unsigned long long seq = ++c->mbox_seq;
-                                gvk::aat_step(s, stA, mu, p, r, d, z, DG->d, tau, gam2, n, c->red_partial, c->red_out + 16,
+                                gvk::aat_step(s, stA, mu, p, r, d, z, DG->d, tau, gam2, n, c->red_partial,
                                               relres_a ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, flag_dev, seq, at_acc, MA->d, M, stB,
-                                              c->cgx_go, d_ride, may_ride ? d_ride : nullptr);
+                                              c->cgx_go, d_ride, may_ride ? d_ride : nullptr, false);
                                 MIX_HIP(hipGetLastError());
                                 steps.push_back(StepRec{0, seq, (int)passes.size() - 1});
                             }
@@ -1153,7 +1200,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 if (todo[k] == &hb) {
                     hk.state[k] = c->cgx_state + gvm::ST_SIZE;
                     if (hb.stage == 0) { hk.p[k] = sb.p; hk.z[k] = sb.z; }
-                    else { hk.dot_part[k] = c->red_partial; hk.dot_out[k] = c->red_out; }
+                    else { hk.dot_part[k] = c->red_partial; hk.dot_out[k] = c->red_out; hk.dot_self = mspace_self_reduce(c, multi); }
                     hkp = &hk;
                 }
             if (nt == 2) {
@@ -1261,8 +1308,8 @@ done:
     }
     cg_fill_stats(sb, st_b);
     if (st_b) { st_b->n_ax = (int)(c->cnt.n_ax - ax0); st_b->n_atx = (int)(c->cnt.n_atx - atx0); }
-    (void)hipStreamSynchronize(s);
-    cleanup();
+    if (rc) (void)hipStreamSynchronize(s);
+    cleanup();          // (views into the context's slab: nothing is released, so the host need not wait for the last kernels)
     return rc;
 }
 

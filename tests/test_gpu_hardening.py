@@ -326,7 +326,13 @@ def test_gathered_dots_equal_their_own_launches_bit_for_bit(N, M):
         sh.synth_bed(1)
         sh.compute_markers_statistics()
         a, b, c = (sh.vecM(rng.standard_normal(M)) for _ in range(3))
-        u, v = (sh.vecN(rng.standard_normal(N) * 1e3) for _ in range(2))
+        npad = 4 * ((N + 3) // 4)                      # N-space handles hold 4 * mbytes entries, the tail at zero
+
+        def nvec():
+            h = np.zeros(npad)
+            h[:N] = rng.standard_normal(N) * 1e3
+            return sh.vecN(h)
+        u, v = nvec(), nvec()
         tM, tM2, tN = sh.vecM(), sh.vecM(), sh.vecN()
         want = []
         sh.axpby(tN, 1.0, u, -1.0, v)
