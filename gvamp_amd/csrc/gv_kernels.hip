@@ -777,13 +777,26 @@ constexpr int CGX_STATUS = 8;   // doubles per system in the mailbox: active, it
 __global__ __launch_bounds__(256) void k_cgx_decide(CgxDecide a, double gam2, int max_iter, int* __restrict__ go, double* mailbox,
                                                     unsigned long long* flag, unsigned long long seq) {
     __shared__ int any;
-    __shared__ double shr[256];
+    __shared__ double shr[3][256];
     __shared__ double qs[2][3];
-    for (int v = 0; v < a.nsys; v++)
-        for (int k = 0; k < 3; k++) {
-            const double q = a.part[v] ? sum_partials_256(a.part[v], a.part_nb, 3, k, shr) : a.red[v][k];
-            if (threadIdx.x == 0) qs[v][k] = q;
-        }
+    for (int v = 0; v < a.nsys; v++) {
+        if (a.part[v]) {       // the three sums of system v side by side, each in the order of k_finalize (sum_partials_256)
+            double s3[3] = {0.0, 0.0, 0.0};
+            for (int b = threadIdx.x; b < a.part_nb; b += 256)
+                for (int k = 0; k < 3; k++) s3[k] += a.part[v][(int64_t)b * 3 + k];
+            __syncthreads();
+            for (int k = 0; k < 3; k++) shr[k][threadIdx.x] = s3[k];
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (threadIdx.x < off)
+                    for (int k = 0; k < 3; k++) shr[k][threadIdx.x] += shr[k][threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0)
+                for (int k = 0; k < 3; k++) qs[v][k] = shr[k][0];
+        } else if (threadIdx.x == 0)
+            for (int k = 0; k < 3; k++) qs[v][k] = a.red[v][k];
+    }
     if (threadIdx.x == 0) {
         any = 0;
         // the rider rode in this step if it was pending and exactly one system had finished before the step (the flags

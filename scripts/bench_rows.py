@@ -72,20 +72,22 @@ def pvals_row(N, M):
 
 
 def main():
-    rows = [
-        vamp_row("config 2: linear N=100k x M=500k, CG-max-iter 50, fuse-solves 4", 100000, 500000, 5, fuse_solves=4),
-        vamp_row("one shard of the 8-GPU headline job on its own: N=400k x M=125k (no exchange), fuse-solves 4", 400000, 125000, 6,
-                 fuse_solves=4),
-        vamp_row("config 4: probit N=100k x M=500k, fuse-solves 4", 100000, 500000, 5, fuse_solves=4, model="bin_class",
-                 gam1=1e-8, gamw=1.0),
-        vamp_row("config 5: --use-XXT-denoiser 1 (matrix-free N-space CG) N=50k x M=200k, fuse-solves 4", 50000, 200000, 4,
-                 use_XXT_denoiser=1, raw_rows=True, fuse_solves=4),
-        vamp_row("config 5 as the reference sequences it (fuse-solves 0)", 50000, 200000, 4, use_XXT_denoiser=1,
-                 raw_rows=True, fuse_solves=0),
-        pvals_row(400000, 1000000),
+    only = sys.argv[1] if len(sys.argv) > 1 else ""          # e.g. "config 5": the rows whose name contains it
+    specs = [
+        ("config 2: linear N=100k x M=500k, CG-max-iter 50, fuse-solves 4", lambda n: vamp_row(n, 100000, 500000, 5, fuse_solves=4)),
+        ("one shard of the 8-GPU headline job on its own: N=400k x M=125k (no exchange), fuse-solves 4",
+         lambda n: vamp_row(n, 400000, 125000, 6, fuse_solves=4)),
+        ("config 4: probit N=100k x M=500k, fuse-solves 4",
+         lambda n: vamp_row(n, 100000, 500000, 5, fuse_solves=4, model="bin_class", gam1=1e-8, gamw=1.0)),
+        ("config 5: --use-XXT-denoiser 1 (matrix-free N-space CG) N=50k x M=200k, fuse-solves 4",
+         lambda n: vamp_row(n, 50000, 200000, 4, use_XXT_denoiser=1, raw_rows=True, fuse_solves=4)),
+        ("config 5 as the reference sequences it (fuse-solves 0)",
+         lambda n: vamp_row(n, 50000, 200000, 4, use_XXT_denoiser=1, raw_rows=True, fuse_solves=0)),
+        ("p-values LOO", lambda n: pvals_row(400000, 1000000)),
     ]
-    for r in rows:
-        print(json.dumps(r), flush=True)
+    for name, fn in specs:
+        if only in name:
+            print(json.dumps(fn(name)), flush=True)
 
 
 if __name__ == "__main__":
