@@ -862,7 +862,6 @@ void free_dataset(gv_ctx* c) {
     F(c->aat_slab);
     c->aat_slab_cap = 0;
     c->cgx_relcap = 0;
-    if (c->cgx_pin) { (void)hipHostFree(c->cgx_pin); c->cgx_pin = nullptr; }
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
     for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p, &c->w_n2,

@@ -1,6 +1,7 @@
 # Regenerates profiles/<R>_* on a GPU box (development).  Two calls (each fits a 20-minute gpurun call):
 #   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r3 a     bench line, kernel statistics, PMC traffic
 #   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r3 b     rows, ingest, kernel timelines, mid-size counter passes
+#   gpurun --timeout 600  -- bash scripts/refresh_profiles.sh r3 c     the kernel timelines only
 # Outputs go to gpurun_out/prof_refresh_<part>/ ; copy them into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r3}; PART=${2:-a}
@@ -21,10 +22,12 @@ for d in pmc_fetch pmc_write; do f=$(find $O/$d -name "*counter_collection.csv" 
 python3 scripts/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/$R > /dev/null
 rm -rf $O/stats $O/stats2 $O/pmc_fetch $O/pmc_write $O/tune_cache
 else
+if [ "$PART" = b ]; then
 python3 scripts/bench_rows.py > $O/${R}_rows.json 2>$O/rows.err
 GV_LAYOUT=2 python3 scripts/bench_rows.py > $O/${R}_rows_tile.json 2>$O/rows_tile.err
 python3 scripts/ingest_rate.py > $O/${R}_ingest.json 2>$O/ingest.err
 python3 scripts/hostptr_probe.py > $O/${R}_hostptr_probe.txt 2>&1
+fi
 run() {  # name N M iters fuse xxt last-streaming-launches
   rocprofv3 --kernel-trace --output-format csv -d $O/$1 -o t -- python3 scripts/trace_run.py $2 $3 $4 $5 $6 > $O/$1.out 2>$O/$1.err
   f=$(find $O/$1 -name "*kernel_trace.csv" | head -1)
@@ -34,6 +37,7 @@ run() {  # name N M iters fuse xxt last-streaming-launches
 run cfg5 50000 200000 6 4 1 -27        # the last three iterations (9 passes each): steady state, set-up excluded
 run shard125k 400000 125000 6 4 0 -10
 run cfg2 100000 500000 6 4 0 -18
+[ "$PART" = c ] && { ls -la $O; exit 0; }      # part c: the three kernel timelines only
 # counter passes of the four streaming-kernel classes on 12.5 GB shards (FETCH_SIZE against the algorithmic bytes)
 bash scripts/diag_twovec.sh 400000 125000 > /dev/null 2>&1
 bash scripts/diag_twovec.sh 100000 500000 > /dev/null 2>&1

@@ -16,9 +16,18 @@ seg = ev[lo:hi + 1]
 span = seg[-1][1] - seg[0][0]
 by = collections.defaultdict(lambda: [0, 0])
 busy_end, idle, gaps = seg[0][0], 0, []
+t_stream = t_small = n_small = 0
 for s, e, n in seg:
     k = re.sub(r"\(anonymous namespace\)::", "", n)
     k = re.sub(r"^void ", "", k).split("(")[0][:70]
+    streaming = "k_mfma_matvec" in n or "k_mfma_tile" in n
+    if streaming and e - s <= 20000:
+        k += "  [dropped on the device: enqueued after every system had finished]"
+    if streaming and e - s > 20000:
+        t_stream += e - s
+    else:
+        t_small += e - s
+        n_small += 1
     by[k][0] += e - s
     by[k][1] += 1
     if s > busy_end:
@@ -27,6 +36,8 @@ for s, e, n in seg:
     busy_end = max(busy_end, e)
 nstream = sum(1 for e in seg if ("k_mfma_matvec" in e[2] or "k_mfma_tile" in e[2]) and e[1] - e[0] > 20000)
 print("span %.3f ms, %d streaming launches, idle %.3f ms (%.1f %%)" % (span / 1e6, nstream, idle / 1e6, 100.0 * idle / span))
+print("streaming kernels %.3f ms (%.1f %%), %d other launches %.3f ms (%.1f %%), idle %.1f %%" % (
+    t_stream / 1e6, 100.0 * t_stream / span, n_small, t_small / 1e6, 100.0 * t_small / span, 100.0 * idle / span))
 for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0]):
     print("%8.3f ms %5.1f %% %6d x %7.1f us  %s" % (t / 1e6, 100.0 * t / span, c, t / c / 1e3, k))
 gaps.sort()
