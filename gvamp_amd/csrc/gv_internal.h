@@ -180,7 +180,7 @@ void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, doubl
               double gam2, int64_t n, double* partial, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc = nullptr,
               const double* at_p = nullptr, int64_t m = 0, const double* other_st = nullptr, int* go = nullptr,
-              const int* ride = nullptr, int* ride_mark = nullptr, bool p_update = true);
+              const int* ride = nullptr, int* ride_mark = nullptr, bool p_update = true, bool dq_done = false);
 void ride_copy(hipStream_t s, double* out, const double* w0, const double* w1, const double* st0, const double* st1,
                const int* ride, int64_t n);
 void cg_step_a(hipStream_t s, double* mu, const double* p, double alpha, const double* v, int64_t n,

@@ -1233,17 +1233,18 @@ void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_
     hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
 }
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
-// Three launches (four with the search-direction update): every reduction is added up by the kernel that consumes it
+// Three launches (two when the Ax epilogue has taken k_aat_dq along, one more with the search-direction update): every reduction is added up by the kernel that consumes it
 // (sum_partials_256), A^T mu += alpha A^T p (at_p = the first half of this application) rides in k_aat_ab -- before
 // k_aat_decide may clear ST_ACTIVE -- and p <- z + beta p is left to the k_prep_atx of the next pass when p_update == false.
 void aat_step(hipStream_t s, double* st, double* mu, double* p, double* r, double* d, double* z, const double* diag, double tau,
               double gam2, int64_t n, double* partial, double* relres, int max_iter, double* mailbox,
               unsigned long long* flag, unsigned long long seq, double* at_acc, const double* at_p, int64_t m, const double* other_st,
-              int* go, const int* ride, int* ride_mark, bool p_update) {
+              int* go, const int* ride, int* ride_mark, bool p_update, bool dq_done) {
     const int nb = red_blocks(n, 256);
     double* part_dq = partial;                       // <d,p>: nb doubles
     double* part_ab = partial + 2 * RED_BLOCKS;      // <r,z>, <r,r>: 2 nb doubles (clear of the sums its own blocks still read)
-    hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, part_dq);
+    // (dq_done: the Ax epilogue of the pass has left d = tau d + gam2 p and these partials already -- gvm::CgHook::dq_p)
+    if (!dq_done) hipLaunchKernelGGL(k_aat_dq, dim3(nb), dim3(256), 0, s, d, p, tau, gam2, n, part_dq);
     hipLaunchKernelGGL(k_aat_ab, dim3(nb), dim3(256), 0, s, st, mu, p, r, d, z, diag, part_dq, nb, n, part_ab,
                        (at_acc && m > 0) ? at_acc : nullptr, at_p, m);
     hipLaunchKernelGGL(k_aat_decide, dim3(1), dim3(256), 0, s, st, part_ab, nb, relres, max_iter, mailbox, flag, seq, other_st, go,

@@ -48,6 +48,12 @@ struct CgHook {
     double* ride_out = nullptr;              // != NULL: the Ax epilogue writes the rider's product there itself (no k_ride_copy)
     double* dot_part[2] = {nullptr, nullptr};
     double* dot_out[2] = {nullptr, nullptr};
+    // Ax side (k_fin_ax), slot v closing an application of tau A A^T + gam2 I to dq_p[v] (gv_cg_solve_aat2w, one rank, vectors of at
+    // most RED_BLOCKS * 256 entries): out = dq_tau * product + dq_gam2 * dq_p and the block partials of <out, dq_p> in dq_part[v],
+    // while the system state[v] is running -- gvk::aat_step is then told that its k_aat_dq has been done (dq_done)
+    const double* dq_p[2] = {nullptr, nullptr};
+    double* dq_part[2] = {nullptr, nullptr};
+    double dq_tau = 0.0, dq_gam2 = 0.0;
     bool dot_self = false;                   // the consumer adds the block partials of <out, addx> up itself: no gvk::finalize launch
 };
 

@@ -1209,37 +1209,58 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
 // data::Ax epilogue (data.cpp:972, :998-1005): out[n] = mask (T scale - K0) * post, post = 1/sqrt(N) or 1 (multi-rank)
 // ride / st / ride_out (gvm::CgHook::ride_out): the slot the rider took on the way in (k_prep_ax, same test on the same flags)
 // delivers its product straight into ride_out
-struct FinAx { double* out[2]; const int* ride; const double* st[2]; double* ride_out; };
+// dq_p / dq_part (gvm::CgHook::dq_p): slot v closes an application of tau A A^T + gam2 I to p (gv_cg_solve_aat2w, one rank): while
+// its system is running, out = tau * product + gam2 * p and the block partials of <out, p> -- what gvk::aat_step's k_aat_dq does in
+// a launch of its own, bit for bit (one entry per thread there too when the vector fits RED_BLOCKS blocks, which the caller checks)
+struct FinAx { double* out[2]; const int* ride; const double* st[2]; double* ride_out; const double* dq_p[2]; double* dq_part[2];
+               double tau, gam2; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
                                                 int64_t nkb, int64_t skL, int qshift, int64_t piv) {
     // the streaming kernel has already added the r'.c and miss.e products: one plane per vector and piece, ppk = number of
     // vectors of the pass (1: MODE 1, 4; 2: MODE 3)
+    __shared__ double sh[4];
     const int v = blockIdx.y;
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
-    if (a.ride_out && a.ride && *a.ride == 1 && a.st[v] && a.st[v][gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] &&
-        a.st[1 - v][gvm::ST_ACTIVE] != 0.0)
-        out = a.ride_out;
+    const bool sys_done = a.st[v] && a.st[v][gvm::ST_ACTIVE] == 0.0;
+    if (a.ride_out && a.ride && *a.ride == 1 && sys_done && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) out = a.ride_out;
+    const bool dq = a.dq_p[v] && !sys_done;          // (uniform over the launch slice)
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= npad) return;
-    const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
-    if (!present || n >= rows_p) {
-        out[n] = 0.0;
+    double val = 0.0;
+    if (n < npad) {
+        const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+        if (present && n < rows_p) {
+            long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
+            ksplit = pieces_of(n, ksplit, nkb, skL, qshift, piv);
+            for (int ks = 0; ks < ksplit; ks++) {
+                const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
+                int4 x0 = px[0], x1 = px[1];
+                sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+            }
+            long long xh, xl;
+            combine(sx, xh, xl);
+            const double T = ((double)xh * 4294967296.0 + (double)xl) * scal[3];
+            val = (T - scal[1]) * post;
+        }
+    }
+    if (!dq) {
+        if (n < npad) out[n] = val;
         return;
     }
-    long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
-    ksplit = pieces_of(n, ksplit, nkb, skL, qshift, piv);
-    for (int ks = 0; ks < ksplit; ks++) {
-        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
-        int4 x0 = px[0], x1 = px[1];
-        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
+    double s = 0.0;
+    if (n < npad) {
+        const double pi = a.dq_p[v][n];
+        const double di = fma(a.tau, val, a.gam2 * pi);
+        out[n] = di;
+        s = fma(di, pi, s);
     }
-    long long xh, xl;
-    combine(sx, xh, xl);
-    const double T = ((double)xh * 4294967296.0 + (double)xl) * scal[3];
-    out[n] = (T - scal[1]) * post;
+    s = wave_sum_d(s);   // gvk's block_sum_256: wave butterflies, then the four wave sums in order
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.dq_part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
@@ -1468,8 +1489,13 @@ static void quant_ax(hipStream_t s, const Plan& pl, int nv, const double* red_pa
 }
 static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64_t npad, const uint32_t* mask2, double post,
                    double* outa, double* outb, const CgHook* cg = nullptr, int64_t n0 = 0) {
-    FinAx f{{outa, outb}, nullptr, {nullptr, nullptr}, nullptr};
+    FinAx f{{outa, outb}, nullptr, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, {nullptr, nullptr}, 0.0, 0.0};
     if (cg && cg->ride_out && nv == 2) { f.ride = cg->ride; f.st[0] = cg->state[0]; f.st[1] = cg->state[1]; f.ride_out = cg->ride_out + n0; }
+    if (cg && n0 == 0)
+        for (int v = 0; v < nv; v++)
+            if (cg->dq_p[v]) {     // (whole-vector launches only: the block partials are those of a launch over all of npad)
+                f.st[v] = cg->state[v]; f.dq_p[v] = cg->dq_p[v]; f.dq_part[v] = cg->dq_part[v]; f.tau = cg->dq_tau; f.gam2 = cg->dq_gam2;
+            }
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad,
                        pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8, piv_of(d, (pl.nrg_n + 3) / 4));
 }

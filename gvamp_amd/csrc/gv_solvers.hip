@@ -1114,6 +1114,10 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                             }
                         } else {                                // Y: d_a = A MA | w_n = A p_b (p_b <- z_b + beta p_b on the way in)
                             if (slotA) hk.state[0] = stA;       // (for the rider's sake: no search direction to advance in this slot)
+                            // one rank, a vector that fits RED_BLOCKS blocks: the epilogue of the pass leaves d_a = tau d_a + gam2 p_a
+                            // and the block partials of <d_a, p_a> itself (k_aat_dq's work, bit for bit)
+                            const bool dq_fused = slotA && hostA && !multi && M > 0 && (n + 255) / 256 <= RED_BLOCKS;
+                            if (dq_fused) { hk.dq_p[0] = p; hk.dq_part[0] = c->red_partial; hk.dq_tau = tau; hk.dq_gam2 = gam2; }
                             if (slotB) { hk.state[iB] = stB; hk.p[iB] = sb.p; hk.z[iB] = sb.z; }
                             const bool may_ride = ride_pending && slotA && slotB;
                             // one rank: the epilogue delivers the rider's product itself; sharded: it is copied out of the slot behind the
@@ -1130,7 +1134,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                                 const unsigned long long seq = ++c->mbox_seq;
                                 gvk::aat_step(s, stA, mu, p, r, d, z, DG->d, tau, gam2, n, c->red_partial,
                                               relres_a ? c->cgx_rel : nullptr, max_iter, c->mbox_dev, flag_dev, seq, at_acc, MA->d, M, stB,
-                                              c->cgx_go, d_ride, may_ride ? d_ride : nullptr, false);
+                                              c->cgx_go, d_ride, may_ride ? d_ride : nullptr, false, dq_fused);
                                 MIX_HIP(hipGetLastError());
                                 steps.push_back(StepRec{0, seq, (int)passes.size() - 1});
                             }
