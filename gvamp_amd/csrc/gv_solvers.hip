@@ -1022,6 +1022,8 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
 
         const char* pe = getenv("GV_AAT_PIPELINE");
         const bool pipe_on = !(pe && atoi(pe) == 0);
+        const char* de = getenv("GV_AAT_DQ_FUSE");             // 0: k_aat_dq stays a launch of its own (A/B switch)
+        const bool dq_on = !(de && atoi(de) == 0);
         bool pipelined = false;
         for (;;) {
             // ---- the steady state, enqueued ahead of its statuses (GV_AAT_PIPELINE=0: the host-paced loop below only) -------------
@@ -1116,7 +1118,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                             if (slotA) hk.state[0] = stA;       // (for the rider's sake: no search direction to advance in this slot)
                             // one rank, a vector that fits RED_BLOCKS blocks: the epilogue of the pass leaves d_a = tau d_a + gam2 p_a
                             // and the block partials of <d_a, p_a> itself (k_aat_dq's work, bit for bit)
-                            const bool dq_fused = slotA && hostA && !multi && M > 0 && (n + 255) / 256 <= RED_BLOCKS;
+                            const bool dq_fused = slotA && hostA && !multi && M > 0 && (n + 255) / 256 <= RED_BLOCKS && dq_on;
                             if (dq_fused) { hk.dq_p[0] = p; hk.dq_part[0] = c->red_partial; hk.dq_tau = tau; hk.dq_gam2 = gam2; }
                             if (slotB) { hk.state[iB] = stB; hk.p[iB] = sb.p; hk.z[iB] = sb.z; }
                             const bool may_ride = ride_pending && slotA && slotB;
