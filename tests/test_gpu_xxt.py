@@ -1,5 +1,7 @@
 """--use-XXT-denoiser 1 (denoiserXXT.cpp; BASELINE config 5, matrix-free form): people statistics, the N-space CG and a
 full run of the product against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,3 +174,49 @@ def test_xxt_sharded_run_vs_oracle(oracle, fuse):
     assert rel(x, ref.x_est) < 1e-7
     assert [t["cg_iters"] for t in results[0].trace] == [int(t["cg_iters"]) for t in ref.trace]
     assert all([t["gamw"] for t in r.trace] == [t["gamw"] for t in results[0].trace] for r in results)
+
+
+@pytest.mark.parametrize("N,M", [(300032, 6000), (3000, 9000)])
+def test_pipelined_joint_solver_equals_the_host_paced_loop_bit_for_bit(N, M):
+    """gv_cg_solve_aat2w in the form the VAMP loop uses (A^T mu accumulated, right-hand side completed inside, a rider): its steady
+    state is enqueued ahead of its statuses, a step's reductions are added up by their consumers and the Ax epilogue takes the
+    first update of the N-space step along -- against GV_AAT_PIPELINE=0 (host-paced) and GV_AAT_DQ_FUSE=0 (k_aat_dq a launch of its
+    own): every output and every counter bit for bit.  N = 300 032 is above the 262 144 entries a reduction covers with one entry per
+    thread: there the block partials run over 1024 blocks and the epilogue fusion is off by construction."""
+    rng = np.random.default_rng(N + M)
+    npad = 4 * ((N + 3) // 4)
+    v = np.zeros(npad)
+    v[:N] = rng.standard_normal(N)
+    u = np.where(rng.random(M) < 0.5, -1.0, 1.0) / np.sqrt(M)
+    x1, r2 = rng.standard_normal(M) * 0.1, rng.standard_normal(M) * 0.1
+    tau, gam2 = 1.5, 0.6
+    keys = ("n_ax", "n_atx", "n_ax_pass", "n_atx_pass")
+    outs = []
+    with capi.Shard(N, M) as sh:
+        sh.synth_bed(91, 5000)
+        sh.compute_markers_statistics()
+        sh.compute_people_statistics()
+        du, dx1, dr2 = sh.vecM(u), sh.vecM(x1), sh.vecM(r2)
+        for env in ({}, {"GV_AAT_PIPELINE": "0"}, {"GV_AAT_DQ_FUSE": "0"}):
+            for k, val in env.items():
+                os.environ[k] = val
+            try:
+                dv = sh.vecN(v)
+                mu, at, mb, aat, ata, ro, po = sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecN(), sh.vecN()
+                sh.counters(reset=True)
+                (sa, ra), (sb, rb) = sh.cg_solve_aat2(dv, None, du, tau, gam2, 12, mu, at, mb, aat_mu_a=aat, ata_mu_b=ata,
+                                                      accumulate_at_mu_a=True, pre_x=dr2, pre_out=po, ride_x=dx1, ride_out=ro)
+                c = sh.counters()
+                outs.append(((sa.iters, sa.converged, sb.iters, sb.converged) + tuple(c[k] for k in keys),
+                             [ra, rb] + [q.download() for q in (dv, mu, at, mb, aat, ata, ro, po)]))
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        assert outs[0][0][0] >= 2 and outs[0][0][2] >= 2, outs[0][0]
+        for other in outs[1:]:
+            assert other[0] == outs[0][0], (outs[0][0], other[0])
+            for a_, b_ in zip(outs[0][1], other[1]):
+                assert np.array_equal(a_, b_, equal_nan=True)
+        # and the products themselves: the rider and the completed right-hand side against plain matvecs
+        assert rel(outs[0][1][8], sh.Ax(x1)) < 1e-12
+        assert rel(outs[0][1][9], sh.Ax(r2)) < 1e-12
