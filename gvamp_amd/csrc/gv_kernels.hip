@@ -748,6 +748,22 @@ struct StateInit { double q[gvm::ST_SIZE]; };
 __global__ void k_state_init(double* __restrict__ dst, StateInit a) {
     if (threadIdx.x < gvm::ST_SIZE) dst[threadIdx.x] = a.q[threadIdx.x];
 }
+// ... or built on the device from the block partials of the solve's two opening reductions (one rank: nothing to all-reduce, so
+// nothing for the host to read): ST_RZ = scalar k_rz of part_rz, ST_NORMV = ||v|| (sqrt_norm) or ||v||^2 from part_vv; the other
+// entries as given.  Sums in k_finalize's order, what the host used to read back.
+__global__ __launch_bounds__(256) void k_state_from_partials(double* __restrict__ dst, StateInit a, const double* __restrict__ part_rz,
+                                                             int nb_rz, int K_rz, int k_rz, const double* __restrict__ part_vv,
+                                                             int nb_vv, int sqrt_norm) {
+    __shared__ double shr[256];
+    const double rz = sum_partials_256(part_rz, nb_rz, K_rz, k_rz, shr);
+    const double vv = sum_partials_256(part_vv, nb_vv, 1, 0, shr);
+    if (threadIdx.x < gvm::ST_SIZE) {
+        double q = a.q[threadIdx.x];
+        if (threadIdx.x == gvm::ST_RZ) q = rz;
+        if (threadIdx.x == gvm::ST_NORMV) q = sqrt_norm ? sqrt(vv) : vv;
+        dst[threadIdx.x] = q;
+    }
+}
 __global__ void k_set_ints(int* __restrict__ dst, int a, int b) {
     if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
 }
@@ -1106,7 +1122,7 @@ void cg_step_b_diag(hipStream_t s, double* r, const double* d, double alpha, con
                     double* partial, double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cg_b_diag, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, n, partial);
-    launch_finalize(s, partial, nb, 2, out);
+    if (out) launch_finalize(s, partial, nb, 2, out);      // (out == NULL: the consumer adds the block partials up itself)
 }
 
 void probit_denoise(hipStream_t s, const double* p1, const double* y, const double* m_cov, int64_t N, int64_t npad,
@@ -1190,7 +1206,7 @@ void dots(hipStream_t s, int K, const double* const* x, const double* const* y, 
     }
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_dots, dim3(nb), dim3(256), 0, s, a, K, n, partial);
-    launch_finalize(s, partial, nb, K, out);
+    if (out) launch_finalize(s, partial, nb, K, out);
 }
 
 void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const* xb, const double* const* ya,
@@ -1265,6 +1281,13 @@ void state_init(hipStream_t s, double* dst, const double* q) {
     for (int i = 0; i < gvm::ST_SIZE; i++) a.q[i] = q[i];
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, s, dst, a);
 }
+void state_from_partials(hipStream_t s, double* dst, const double* q, const double* part_rz, int K_rz, int k_rz, const double* part_vv,
+                         int64_t n, bool sqrt_norm) {
+    StateInit a;
+    for (int i = 0; i < gvm::ST_SIZE; i++) a.q[i] = q[i];
+    const int nb = red_blocks(n, 256);        // both reductions ran over n entries
+    hipLaunchKernelGGL(k_state_from_partials, dim3(1), dim3(256), 0, s, dst, a, part_rz, nb, K_rz, k_rz, part_vv, nb, sqrt_norm ? 1 : 0);
+}
 void set_ints(hipStream_t s, int* dst, int a, int b) { hipLaunchKernelGGL(k_set_ints, dim3(1), dim3(64), 0, s, dst, a, b); }
 void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride) {
     hipLaunchKernelGGL(k_ride_mark, dim3(1), dim3(64), 0, s, st0, st1, ride);
@@ -1296,7 +1319,7 @@ void cg_step_b(hipStream_t s, double* r, const double* d, double alpha, double d
                int64_t n, double* partial, double* out) {
     int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cg_b, dim3(nb), dim3(256), 0, s, r, d, alpha, diag, z, mu, n, partial);
-    launch_finalize(s, partial, nb, 4, out);
+    if (out) launch_finalize(s, partial, nb, 4, out);
 }
 
 void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_prior& pr, double* x1, double* dd,

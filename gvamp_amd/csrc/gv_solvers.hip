@@ -946,22 +946,72 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         sb.keep_resid = ata_mu_b != nullptr;
         gvk::fill(s, sb.mu, M, 0.0);
         MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
-        MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
-        if (max_iter <= 0) sb.active = false;
         if (wm->ata_v_b) { sb.ata_v = wm->ata_v_b->d; sb.ata_v_known = wm->have_ata_v_b != 0; }
-        // (A^T A v_b at hand: the first step of solve b without its Ax + ATx; the residual trace of a device run lives on the
-        // device, its first entry goes there)
-        double rel0 = 0;
-        double* keep_rel = sb.relres;
-        if (dev && sb.relres) sb.relres = &rel0;
-        MIX_TRY(cg_first_step_from_known_product(c, sb, tau, gam2, diag_b, max_iter, multi));
-        sb.relres = keep_rel;
-        if (dev && keep_rel && sb.n_relres > 0) gvk::fill(s, c->cgx_rel + c->cgx_relcap, 1, rel0);
-        if (dev) MIX_TRY(cgx_upload_sys(c, 1, sb));
+        if (dev && !multi && M > 0) {
+            // One rank, scalars on the device: nothing of the opening needs the host.  z = r / diag with <r,z> and ||v||^2 stay
+            // block partials, the state block is built from them on the device (k_state_from_partials), and with A^T A v_b at
+            // hand the first step -- d = (tau / diag) A^T A v + gam2 p, no pass -- is a device step like every later one.  ONE
+            // status read-back where the host-driven opening took four (cg_finish_init, then <d,p>, <v,mu> and the norms).
+            double* stB = c->cgx_state + gvm::ST_SIZE;
+            gvk::cg_step_b(s, sb.r, sb.d, 0.0, diag_b, sb.z, sb.mu, M, c->red_partial, nullptr);
+            const double* vv[1] = {sb.v};
+            gvk::dots(s, 1, vv, vv, M, c->red_partial + 4 * RED_BLOCKS, nullptr);
+            MIX_HIP(hipMemcpyAsync(sb.p, sb.z, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+            sb.phase = 1; sb.req = sb.p; sb.res = sb.d;
+            double q[gvm::ST_SIZE];
+            for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+            q[gvm::ST_ACTIVE] = 1.0;                        // (dev implies max_iter > 0)
+            gvk::state_from_partials(s, stB, q, c->red_partial, 4, 0, c->red_partial + 4 * RED_BLOCKS, M, true);
+            if (sb.ata_v && sb.ata_v_known) {
+                gvk::axpby(s, sb.d, tau / diag_b, sb.ata_v, gam2, sb.p, M);
+                const double *xs[1] = {sb.d}, *ys[1] = {sb.p};
+                gvk::dots(s, 1, xs, ys, M, c->red_partial, nullptr);
+                double *a_st[1] = {stB}, *a_mu[1] = {sb.mu}, *a_r[1] = {sb.r}, *a_z[1] = {sb.z},
+                       *a_part[1] = {c->red_partial + 4 * RED_BLOCKS}, *a_red[1] = {c->red_out};
+                const double *a_p[1] = {sb.p}, *a_v[1] = {sb.v}, *a_d[1] = {sb.d}, *a_dp[1] = {c->red_out}, *a_dpp[1] = {c->red_partial};
+                const int nb_ab = gvk::cgx_ab(s, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag_b, M, a_dpp,
+                                              gvm::atx_dot_blocks(c->plan));
+                const double* c_red[1] = {c->red_out};
+                const double* c_part[1] = {a_part[0]};
+                double* c_rel[1] = {sb.relres ? c->cgx_rel + c->cgx_relcap : nullptr};
+                const unsigned long long seq = ++c->mbox_seq;
+                gvk::cgx_decide(s, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
+                                reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), seq, nullptr, nullptr, nullptr, c_part, nb_ab);
+                MIX_HIP(hipGetLastError());
+                CgxStatus s2[2];
+                MIX_TRY(cgx_wait(c, seq, s2));
+                sb.iters = (int)s2[0].iters; sb.converged = (int)s2[0].conv; sb.onsager = s2[0].ons; sb.n_relres = (int)s2[0].nrel;
+                sb.rel_err = s2[0].rel; sb.active = s2[0].active != 0.0;
+            }
+        } else {
+            MIX_TRY(cg_finish_init(c, sb, diag_b, multi));
+            if (max_iter <= 0) sb.active = false;
+            // (A^T A v_b at hand: the first step of solve b without its Ax + ATx; the residual trace of a device run lives on the
+            // device, its first entry goes there)
+            double rel0 = 0;
+            double* keep_rel = sb.relres;
+            if (dev && sb.relres) sb.relres = &rel0;
+            MIX_TRY(cg_first_step_from_known_product(c, sb, tau, gam2, diag_b, max_iter, multi));
+            sb.relres = keep_rel;
+            if (dev && keep_rel && sb.n_relres > 0) gvk::fill(s, c->cgx_rel + c->cgx_relcap, 1, rel0);
+            if (dev) MIX_TRY(cgx_upload_sys(c, 1, sb));
+        }
     }
     {
         auto a_init_scalars = [&]() -> int {   // z = r / diag (:76-77), <r,z>, ||v||^2, p = z
-            if (aat_init_scalars(c, r, d, DG->d, z, v_a->d, &a_rz, &a_vn2)) return 1;
+            if (dev) {      // the scalars stay on the device: the state block is built from the block partials (no read-back; N-space
+                            // sums are not all-reduced, so this holds for a sharded job too)
+                gvk::cg_step_b_diag(s, r, d, 0.0, DG->d, z, n, c->red_partial, nullptr);
+                const double* vv[1] = {v_a->d};
+                gvk::dots(s, 1, vv, vv, n, c->red_partial + 2 * RED_BLOCKS, nullptr);
+                double q[gvm::ST_SIZE];
+                for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+                q[gvm::ST_ACTIVE] = 1.0;
+                q[gvm::ST_DENOISER] = 1.0;
+                gvk::state_from_partials(s, c->cgx_state, q, c->red_partial, 2, 0, c->red_partial + 2 * RED_BLOCKS, n, false);
+                if (hipGetLastError() != hipSuccess) return 1;
+            } else if (aat_init_scalars(c, r, d, DG->d, z, v_a->d, &a_rz, &a_vn2))
+                return 1;
             if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
             return 0;
         };
@@ -990,7 +1040,6 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 gvk::axpby(s, r, 1.0, v_a->d, -tau, aat_mu_start_a->d, n);
                 gvk::axpby(s, r, 1.0, r, -gam2, mu_start_a->d, n);
                 if (a_init_scalars()) return 1;
-                if (dev && cgx_upload_state(c, 0, a_rz, a_vn2, 1, true)) return 1;
                 a_phase = 1;
                 if (max_iter > 0) a_post(p, d); else a_finish();
             } else if (mu_start_a) {
@@ -1001,7 +1050,6 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 gvk::fill(s, mu, n, 0.0);
                 if (hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
                 if (a_init_scalars()) return 1;
-                if (dev && cgx_upload_state(c, 0, a_rz, a_vn2, 1, true)) return 1;
                 a_phase = 1;
                 if (max_iter > 0) a_post(p, d); else a_finish();
             }
@@ -1252,7 +1300,6 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 if (a_phase == 0) {                                                // r = v - Q mu0 (:71-73)
                     gvk::axpby(s, r, 1.0, v_a->d, -1.0, r, n);
                     MIX_TRY(a_init_scalars());
-                    if (dev) MIX_TRY(cgx_upload_state(c, 0, a_rz, a_vn2, 1, true));
                     a_phase = 1;
                     if (max_iter > 0) a_post(p, d); else a_finish();
                     continue;

@@ -232,9 +232,14 @@ def run_case(seed0, k):
         for key in ("xr1", "xr2", "xr3"):
             assert trace_close(d[key], h[key], 1e-13 * kappa ** 2 + 1e-9), (key, info, d[key][:5], h[key][:5])
         okx = (short or (d["xit"][1] and h["xit"][1]), short or (d["xit"][3] and h["xit"][3] and d["xit"][5] and h["xit"][5]))
+        # (seed 2718, case 318: N = 64, M = 63, 38 steps to the 1e-4 stopping rule -- both runs are 1.2e-4 from the exact solution
+        # and 2.8e-6 from each other: in the lost-orthogonality regime two roundings may differ by a fraction of the stopping rule)
+        tolx = loose * (1e-13 * kappa ** 2 + 1e-9)
+        if loose > 1.0:
+            tolx = max(tolx, 1e-5)
         for key, ok in (("mn", okx[0]), ("mn2", okx[1]), ("atm", okx[1]), ("mb2", okx[1]), ("aat", okx[1]), ("ata2", okx[1])):
             if ok:
-                assert close(d[key], h[key], loose * (1e-13 * kappa ** 2 + 1e-9)), (key, info, rel(d[key], h[key]), kappa)
+                assert close(d[key], h[key], tolx), (key, info, rel(d[key], h[key]), kappa)
     # ---- B: marker shards in one process
     nr = int(rng.integers(2, 5))
     cuts = sorted(int(c) for c in rng.integers(0, M + 1, size=nr - 1))
