@@ -89,60 +89,82 @@ __global__ __launch_bounds__(256) void k_stripes_n(const uint8_t* __restrict__ r
     stripes[(ng * nkb + kb0 + kbl) * 256 + t] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// ---- compute_markers_statistics (data.cpp:451-484) from stripes_m: one wave per tile of 16 markers -------------
+// ---- compute_markers_statistics (data.cpp:451-484) from stripes_m: one wave per row group of 64 markers -------------
+// A wave reads the whole 4 KiB supertile of its row group per K-block -- four 1 KiB tiles of 16 markers, the access pattern of the
+// matvec kernels -- and keeps the three genotype counts of its four tiles.  (One wave per TILE, the first form of this kernel, had
+// the four waves of a workgroup pick the 1 KiB pieces of a supertile at different times: 4.5-5.0 TB/s where the matvec kernels
+// stream at 6.6.)
 __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__ stripes, const uint32_t* __restrict__ mask2,
                                                        int64_t M, int64_t nkb, int64_t P4, double nonas,
                                                        double alpha_scale, double* __restrict__ mave,
                                                        double* __restrict__ msig, uint32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // global 16-row tile
-    if (tile * 16 >= M) return;
-    const int64_t rg = tile >> 2, i = tile & 3;
-    uint32_t n2 = 0, n1 = 0, n0 = 0;
+    const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // row group of 64 markers
+    if (rg * 64 >= M) return;
+    uint32_t n2[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n0[4] = {0, 0, 0, 0};
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    auto count = [&](const v4u& v, int64_t kb) {
-        const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
-        uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+    struct Tiles { v4u t[4]; };
+    auto load = [&](Tiles& a, const v4u* p) {
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint32_t pm = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
-            uint32_t lo = ws[d] & 0x55555555u, hi = (ws[d] >> 1) & 0x55555555u;
-            n2 += __popc(hi & ~lo & pm);
-            n1 += __popc(~hi & lo & pm);
-            n0 += __popc(~hi & ~lo & pm);
+        for (int i = 0; i < 4; i++) a.t[i] = __builtin_nontemporal_load(p + i * 64);
+    };
+    auto count = [&](const Tiles& a, int64_t kb) {
+        const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
+        uint32_t pm[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) pm[d] = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ws[4] = {a.t[i].x, a.t[i].y, a.t[i].z, a.t[i].w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t lo = ws[d] & 0x55555555u, hi = (ws[d] >> 1) & 0x55555555u;
+                n2[i] += __popc(hi & ~lo & pm[d]);
+                n1[i] += __popc(~hi & lo & pm[d]);
+                n0[i] += __popc(~hi & ~lo & pm[d]);
+            }
         }
     };
-    // four K-blocks per trip: 4 KiB of independent non-temporal loads in flight per wave (one load at a time streamed the shard
-    // at 4.5 TB/s where the matvec kernels reach 6.6)
-    const v4u* src = reinterpret_cast<const v4u*>(stripes) + rg * nkb * 256 + i * 64 + lane;
+    // two K-blocks per trip: 8 KiB of independent non-temporal loads in flight per wave
+    const v4u* src = reinterpret_cast<const v4u*>(stripes) + rg * nkb * 256 + lane;
     int64_t kb = 0;
-    for (; kb + 4 <= nkb; kb += 4) {
-        const v4u v0 = __builtin_nontemporal_load(src + (kb + 0) * 256), v1 = __builtin_nontemporal_load(src + (kb + 1) * 256),
-                    v2 = __builtin_nontemporal_load(src + (kb + 2) * 256), v3 = __builtin_nontemporal_load(src + (kb + 3) * 256);
-        count(v0, kb); count(v1, kb + 1); count(v2, kb + 2); count(v3, kb + 3);
+    for (; kb + 2 <= nkb; kb += 2) {
+        Tiles a, b;
+        load(a, src + kb * 256);
+        load(b, src + (kb + 1) * 256);
+        count(a, kb);
+        count(b, kb + 1);
     }
-    for (; kb < nkb; kb++) count(__builtin_nontemporal_load(src + kb * 256), kb);
-    // sum over the 4 lanes (g) that share row r
-    n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);
-    n1 += __shfl_xor(n1, 16, 64); n1 += __shfl_xor(n1, 32, 64);
-    n0 += __shfl_xor(n0, 16, 64); n0 += __shfl_xor(n0, 32, 64);
-    const int64_t m = tile * 16 + r;
-    if (g == 0 && m < M) {
-        double suma = 2.0 * n2 + 1.0 * n1, sumb = (double)n0 + (double)n1 + (double)n2;
-        double mu = (sumb != 0) ? suma / sumb : 0.0;
-        double sumsqr = n2 * ((2.0 - mu) * (2.0 - mu)) + n1 * ((1.0 - mu) * (1.0 - mu)) + n0 * (mu * mu);
-        double sg;
-        if (sumsqr != 0) {
-            if (alpha_scale == 1.0) sg = 1.0 / sqrt(sumsqr / (nonas - 1.0));
-            else sg = 1.0 / pow(sqrt(sumsqr / (nonas - 1.0)), alpha_scale);
-        } else
-            sg = 1.0;
-        mave[m] = mu;
-        msig[m] = sg;
-        if (counts) {
-            counts[3 * m] = n2;
-            counts[3 * m + 1] = n1;
-            counts[3 * m + 2] = n0;
+    for (; kb < nkb; kb++) {
+        Tiles a;
+        load(a, src + kb * 256);
+        count(a, kb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // sum over the 4 lanes (g) that share row r of tile i
+        uint32_t c2 = n2[i], c1 = n1[i], c0 = n0[i];
+        c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+        c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
+        c0 += __shfl_xor(c0, 16, 64); c0 += __shfl_xor(c0, 32, 64);
+        const int64_t m = rg * 64 + 16 * i + r;
+        if (g == 0 && m < M) {
+            double suma = 2.0 * c2 + 1.0 * c1, sumb = (double)c0 + (double)c1 + (double)c2;
+            double mu = (sumb != 0) ? suma / sumb : 0.0;
+            double sumsqr = c2 * ((2.0 - mu) * (2.0 - mu)) + c1 * ((1.0 - mu) * (1.0 - mu)) + c0 * (mu * mu);
+            double sg;
+            if (sumsqr != 0) {
+                if (alpha_scale == 1.0) sg = 1.0 / sqrt(sumsqr / (nonas - 1.0));
+                else sg = 1.0 / pow(sqrt(sumsqr / (nonas - 1.0)), alpha_scale);
+            } else
+                sg = 1.0;
+            mave[m] = mu;
+            msig[m] = sg;
+            if (counts) {
+                counts[3 * m] = c2;
+                counts[3 * m + 1] = c1;
+                counts[3 * m + 2] = c0;
+            }
         }
     }
 }
@@ -1369,7 +1391,7 @@ void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t m
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
                         int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(k_stats_stripes, dim3(nblk((M + 15) / 16, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M,
+    hipLaunchKernelGGL(k_stats_stripes, dim3(nblk((M + 63) / 64, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M,
                        nkb, P4, nonas, alpha_scale, mave, msig, counts);
 }
 
