@@ -855,6 +855,11 @@ void free_dataset(gv_ctx* c) {
         p = nullptr;
     };
     F(c->bed); F(c->mask2); F(c->mave); F(c->msig); F(c->t3); F(c->ax_partial); F(c->counts);
+    if (c->stripes_slab) {
+        (void)hipFree(c->stripes_slab);
+        c->stripes_slab = nullptr;
+        c->plan.stripes_m = c->plan.stripes_n = nullptr;
+    }
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.tiles); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
     F(c->plan.cv2); F(c->plan.ev2);
     F(c->plan.scal); F(c->plan.partial);
@@ -1212,6 +1217,11 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     const int want_layout = c->want_tile ? 1 : 0;
     if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
         // (re)build the geometry and the buffers of the MFMA family for the layout asked for
+        if (c->stripes_slab) {       // the two stripe sets are views into one allocation
+            (void)hipFree(c->stripes_slab);
+            c->stripes_slab = nullptr;
+            pl.stripes_m = pl.stripes_n = nullptr;
+        }
         for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
                          (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
@@ -1220,8 +1230,25 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         if (want_layout) {
             HIPCHK(c, hipMalloc(&pl.tiles, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
         } else {
-            HIPCHK(c, hipMalloc(&pl.stripes_m, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
-            HIPCHK(c, hipMalloc(&pl.stripes_n, (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096));
+            // ONE allocation for the two stripe sets, stripes_n (the Ax side) first.  Where the driver places a 100 GB allocation
+            // moves the kernel that streams it by 1.5-3.5 % (nine ingests on one box, Ax 14.9-15.6 ms and
+            // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
+            // mode in every ingest measured (Ax 14.89-14.99 ms) and the second near it (ATx 14.95-15.08, once 15.5), whichever set
+            // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.
+            const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
+                         sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
+            const char* se = getenv("GV_STRIPE_SLAB");
+            void* slab = nullptr;
+            const size_t al = (size_t)1 << 30, off_m = (sz_n + al - 1) / al * al;
+            if (!(se && atoi(se) == 0) && hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
+                c->stripes_slab = slab;
+                pl.stripes_n = slab;
+                pl.stripes_m = (char*)slab + off_m;
+            } else {
+                (void)hipGetLastError();
+                HIPCHK(c, hipMalloc(&pl.stripes_m, sz_m));
+                HIPCHK(c, hipMalloc(&pl.stripes_n, sz_n));
+            }
         }
         HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
         HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));

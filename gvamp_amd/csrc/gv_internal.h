@@ -80,6 +80,7 @@ struct gv_ctx {
     int* cgx_go = nullptr;
     double* cgx_rel = nullptr;
     int cgx_relcap = 0;
+    void* stripes_slab = nullptr;  // owner of plan.stripes_n | plan.stripes_m when the two stripe sets share one allocation (ingest)
     double* aat_slab = nullptr;    // work vectors of the N-space solvers (gv_solvers.hip: aat_scratch), kept between calls
     size_t aat_slab_cap = 0;
     gv_vec *mave_p = nullptr, *msig_p = nullptr, *numb_p = nullptr;   // people statistics (gv_people_stats), N-space
