@@ -353,3 +353,35 @@ def test_gathered_dots_equal_their_own_launches_bit_for_bit(N, M):
         assert np.allclose(got, ref, rtol=1e-12, atol=1e-9)
         with pytest.raises(capi.GvError, match="one space"):
             sh.dots_ex([(a, u, a, u, 0)])
+
+
+def test_stripe_sets_in_one_allocation_or_two_give_the_same_bits_and_survive_a_reingest():
+    """The two stripe sets are views into one allocation by default (gv_capi.hip: where the driver places a large allocation moves
+    the kernel that streams it); GV_STRIPE_SLAB=0 keeps one allocation per set.  Same products either way, a second ingest into
+    the same context (which releases and re-allocates) included."""
+    N, M = 5003, 20011
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(M)
+    p = np.zeros(4 * ((N + 3) // 4))
+    p[:N] = rng.standard_normal(N)
+    out = []
+    for env in (None, "0"):
+        if env is not None:
+            os.environ["GV_STRIPE_SLAB"] = env
+        try:
+            with capi.Shard(N, M) as sh:
+                sh.synth_bed(3, 5000)
+                sh.compute_markers_statistics()
+                a1, t1 = sh.Ax(x), sh.ATx(p)
+                sh.synth_bed(4, 5000)                      # re-ingest: the resident layouts are rebuilt in place
+                sh.compute_markers_statistics()
+                a2, t2 = sh.Ax(x), sh.ATx(p)
+                sh.synth_bed(3, 5000)
+                sh.compute_markers_statistics()
+                a3, t3 = sh.Ax(x), sh.ATx(p)
+                assert np.array_equal(a1, a3) and np.array_equal(t1, t3) and not np.array_equal(a1, a2)
+                out.append((a1, t1, a2, t2))
+        finally:
+            os.environ.pop("GV_STRIPE_SLAB", None)
+    for u, v in zip(out[0], out[1]):
+        assert np.array_equal(u, v)
