@@ -1689,6 +1689,7 @@ static int marker_sums_p_p2(gv_ctx* c, const double* p, double* p2_scratch, doub
     gvk::mul(c->stream, p2_scratch, p, p, c->npad);
     if (c->kernel_mode == 1 && c->M > 0) {
         NEED(c, c->have_stripes, "p-values: kernel mode 1 needs the stripe layouts");
+        if (!c->ks_tuned && autotune_ks(c)) return 1;      // (a p-value call may be the first streaming pass of a context)
         gvm::marker_sums2(c->stream, c->plan, p, p2_scratch, c->npad, c->red_partial, out4_dev);
     } else {
         NEED(c, c->have_raw, "p-values: kernel mode 0 needs the raw row layout");
