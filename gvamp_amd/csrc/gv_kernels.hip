@@ -4,6 +4,7 @@
 // 2-bit codes, individual 4j+k in bits 2k..2k+1 of byte j (data.cpp:201-234 keeps the same bytes, unpadded).
 // A 32-bit word of a row therefore holds 16 consecutive individuals, individual q at bits 2q..2q+1.
 // Decode (dotp_lut.hpp:3,1030): code 00 -> a=2, 10 -> a=1, 11 -> a=0, 01 -> missing (a=0, b=0).
+#include <cstdlib>
 #include "gv_internal.h"
 
 namespace {
@@ -980,6 +981,64 @@ __global__ __launch_bounds__(64) void k_prior_estep(const double* __restrict__ r
         }
     }
 }
+// The same E-step with the per-thread accumulators in registers, for priors of at most LC + 1 components (the usual case: the
+// kernel above parks 3 x (GV_LMAX - 1) x 64 doubles in LDS, 47 KB per 64-thread block, so three waves per CU -- 31 us for 200k
+// markers; this one runs at full occupancy).  Same operations in the same order per thread, same block partials: same bits.
+template <int LC>
+__global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict__ r1, int64_t n, double gam1, double lambda,
+                                                        gv_prior pr, double* __restrict__ partial) {
+    const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
+    const double noise_var = 1 / gam1;
+    double max_sigma = pr.vars[0];
+    for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
+    double c_exp[LC], c_pre[LC], c_gain[LC], c_var[LC], accR[LC], accG[LC], num[LC];
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        const double v = j < Lm1 ? pr.vars[j + 1] : 1.0;
+        c_exp[j] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
+        c_pre[j] = j < Lm1 ? lambda * pr.probs[j + 1] / sqrt(v + noise_var) / sqrt(2 * M_PI) : 0.0;
+        c_gain[j] = gam1 / (1 / v + gam1);
+        c_var[j] = 1.0 / (1.0 / v + gam1);
+        accR[j] = accG[j] = 0.0;
+    }
+    const double c0 = (1 - lambda) / sqrt(2 * M_PI * noise_var);
+    const double e0 = 0.5 * max_sigma / noise_var / (noise_var + max_sigma);
+    double acc_pin = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
+        const double r = r1[i], r2 = r * r;
+        double sum_of_elems = 0.0;
+#pragma unroll
+        for (int j = 0; j < LC; j++)
+            if (j < Lm1) {
+                num[j] = c_pre[j] * exp(-r2 * c_exp[j]);
+                sum_of_elems += num[j];
+            }
+        const double inv = 1 / sum_of_elems;
+        const double pin = 1 / (1 + c0 * exp(-r2 * e0) * inv);
+        acc_pin += pin;
+#pragma unroll
+        for (int j = 0; j < LC; j++)
+            if (j < Lm1) {
+                const double beta = num[j] * inv;
+                const double gm = c_gain[j] * r;
+                accR[j] += beta * pin;
+                accG[j] += beta * (gm * gm + c_var[j]) * pin;
+            }
+    }
+    double* o = partial + (int64_t)blockIdx.x * K;
+    const double s = wave_sum(acc_pin);
+    if (t == 0) o[0] = s;
+#pragma unroll
+    for (int j = 0; j < LC; j++)
+        if (j < Lm1) {
+            const double a = wave_sum(accR[j]), b = wave_sum(accG[j]);
+            if (t == 0) {
+                o[1 + 2 * j] = a;
+                o[2 + 2 * j] = b;
+            }
+        }
+}
 
 // ---- p-values: the per-marker regression test of data::pvals_calc / pvals_calc_LOCO (data.cpp:1150-1226, :1290-1353) --
 // Student-t two-sided tail P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2): Lentz continued fraction of the incomplete beta
@@ -1333,7 +1392,11 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
                  double* partial, double* out) {
     int nb = red_blocks(n, 64);
     int K = 1 + 2 * (pr.L - 1);
-    hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    const char* force_lds = getenv("GV_ESTEP_LDS");      // (test switch: the LDS form for every prior)
+    if (force_lds && atoi(force_lds)) hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    else if (pr.L - 1 <= 3) hipLaunchKernelGGL(k_prior_estep_reg<3>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    else if (pr.L - 1 <= 8) hipLaunchKernelGGL(k_prior_estep_reg<8>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    else hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
     launch_finalize(s, partial, nb, K, out);
 }
 

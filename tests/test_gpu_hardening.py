@@ -385,3 +385,32 @@ def test_stripe_sets_in_one_allocation_or_two_give_the_same_bits_and_survive_a_r
             os.environ.pop("GV_STRIPE_SLAB", None)
     for u, v in zip(out[0], out[1]):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 6, 9, 12])
+def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
+    """gv_prior_estep keeps its per-thread accumulators in registers for priors of up to 9 components (full occupancy; the LDS form
+    parks 47 KB per 64-thread block) -- same operations in the same order, same block partials: the same bits (GV_ESTEP_LDS=1 forces
+    the LDS form)."""
+    M = 70001
+    rng = np.random.default_rng(L)
+    r1 = rng.standard_normal(M) * 0.3
+    vars_ = np.concatenate([[0.0], np.sort(10.0 ** rng.uniform(-4, -1, L - 1))])
+    probs = np.concatenate([[0.9], rng.dirichlet(np.ones(L - 1)) * 0.1])
+    lam = 1 - probs[0]
+    omegas = probs.copy()
+    omegas[1:] /= lam
+    out = []
+    with capi.Shard(2000, M) as sh:
+        sh.synth_bed(1)
+        sh.compute_markers_statistics()
+        dr = sh.vecM(r1)
+        for env in (None, "1"):
+            if env:
+                os.environ["GV_ESTEP_LDS"] = env
+            try:
+                out.append(np.array(sh.prior_estep(dr, 2.5, lam, omegas, vars_)))
+            finally:
+                os.environ.pop("GV_ESTEP_LDS", None)
+    assert out[0].shape == (1 + 2 * (L - 1),) and np.all(np.isfinite(out[0]))
+    assert [float(v).hex() for v in out[0]] == [float(v).hex() for v in out[1]]
