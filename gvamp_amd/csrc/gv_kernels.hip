@@ -981,28 +981,31 @@ __global__ __launch_bounds__(64) void k_prior_estep(const double* __restrict__ r
         }
     }
 }
-// The same E-step with the per-thread accumulators in registers, for priors of at most LC + 1 components (the usual case: the
-// kernel above parks 3 x (GV_LMAX - 1) x 64 doubles in LDS, 47 KB per 64-thread block, so three waves per CU -- 31 us for 200k
-// markers; this one runs at full occupancy).  Same operations in the same order per thread, same block partials: same bits.
+// The same E-step with the per-thread accumulators in registers, for priors of at most LC + 1 components.  The kernel above parks
+// 3 x (GV_LMAX - 1) x 64 doubles in LDS -- 47 KB per 64-thread block whatever L is, so three waves per CU: 32 us for 200k markers
+// and 53 us for 500k; here only the per-component constants (uniform over the block) stay in LDS.  Same operations in the same
+// order per thread, same block partials: same bits (tests/test_gpu_hardening.py holds the two against each other).
 template <int LC>
 __global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict__ r1, int64_t n, double gam1, double lambda,
                                                         gv_prior pr, double* __restrict__ partial) {
+    __shared__ double c_exp[GV_LMAX - 1], c_pre[GV_LMAX - 1], c_gain[GV_LMAX - 1], c_var[GV_LMAX - 1];
     const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
     const double noise_var = 1 / gam1;
     double max_sigma = pr.vars[0];
     for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
-    double c_exp[LC], c_pre[LC], c_gain[LC], c_var[LC], accR[LC], accG[LC], num[LC];
-#pragma unroll
-    for (int j = 0; j < LC; j++) {
-        const double v = j < Lm1 ? pr.vars[j + 1] : 1.0;
-        c_exp[j] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
-        c_pre[j] = j < Lm1 ? lambda * pr.probs[j + 1] / sqrt(v + noise_var) / sqrt(2 * M_PI) : 0.0;
-        c_gain[j] = gam1 / (1 / v + gam1);
-        c_var[j] = 1.0 / (1.0 / v + gam1);
-        accR[j] = accG[j] = 0.0;
+    if (t < Lm1) {
+        const double v = pr.vars[t + 1];
+        c_exp[t] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
+        c_pre[t] = lambda * pr.probs[t + 1] / sqrt(v + noise_var) / sqrt(2 * M_PI);
+        c_gain[t] = gam1 / (1 / v + gam1);
+        c_var[t] = 1.0 / (1.0 / v + gam1);
     }
     const double c0 = (1 - lambda) / sqrt(2 * M_PI * noise_var);
     const double e0 = 0.5 * max_sigma / noise_var / (noise_var + max_sigma);
+    double accR[LC], accG[LC], num[LC];
+#pragma unroll
+    for (int j = 0; j < LC; j++) accR[j] = accG[j] = 0.0;
+    __syncthreads();
     double acc_pin = 0.0;
     const int64_t stride = (int64_t)gridDim.x * 64;
     for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
@@ -1393,10 +1396,15 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
     int nb = red_blocks(n, 64);
     int K = 1 + 2 * (pr.L - 1);
     const char* force_lds = getenv("GV_ESTEP_LDS");      // (test switch: the LDS form for every prior)
+    const int Lm1 = pr.L - 1;
+#define GV_ESTEP(LCV) hipLaunchKernelGGL(k_prior_estep_reg<LCV>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial)
     if (force_lds && atoi(force_lds)) hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
-    else if (pr.L - 1 <= 3) hipLaunchKernelGGL(k_prior_estep_reg<3>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
-    else if (pr.L - 1 <= 8) hipLaunchKernelGGL(k_prior_estep_reg<8>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
-    else hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
+    else if (Lm1 <= 4) GV_ESTEP(4);
+    else if (Lm1 <= 8) GV_ESTEP(8);
+    else if (Lm1 <= 16) GV_ESTEP(16);
+    else if (Lm1 <= 24) GV_ESTEP(24);
+    else GV_ESTEP(GV_LMAX - 1);
+#undef GV_ESTEP
     launch_finalize(s, partial, nb, K, out);
 }
 

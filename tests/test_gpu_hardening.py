@@ -387,11 +387,11 @@ def test_stripe_sets_in_one_allocation_or_two_give_the_same_bits_and_survive_a_r
         assert np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("L", [2, 3, 4, 6, 9, 12])
+@pytest.mark.parametrize("L", [2, 3, 5, 6, 9, 12, 17, 18, 23, 26, 32])
 def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
-    """gv_prior_estep keeps its per-thread accumulators in registers for priors of up to 9 components (full occupancy; the LDS form
-    parks 47 KB per 64-thread block) -- same operations in the same order, same block partials: the same bits (GV_ESTEP_LDS=1 forces
-    the LDS form)."""
+    """gv_prior_estep keeps its per-thread accumulators in registers (instantiations for up to 5, 9, 17, 25 and 32 components; the
+    LDS form parks 47 KB per 64-thread block, three waves per CU) -- same operations in the same order, same block partials: the same
+    bits (GV_ESTEP_LDS=1 forces the LDS form)."""
     M = 70001
     rng = np.random.default_rng(L)
     r1 = rng.standard_normal(M) * 0.3
