@@ -1233,7 +1233,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             // ONE allocation for the two stripe sets, stripes_n (the Ax side) first.  Where the driver places a 100 GB allocation
             // moves the kernel that streams it by 1.5-3.5 % (nine ingests on one box, Ax 14.9-15.6 ms and
             // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
-            // mode in every ingest measured (Ax 14.89-14.99 ms) and the second near it (ATx 14.95-15.08, once 15.5), whichever set
+            // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
             // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.
             const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
                          sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
