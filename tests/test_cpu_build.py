@@ -221,6 +221,8 @@ int main(void) {
     printf("gv_cg_extras %zu %zu %zu\\n", sizeof(gv_cg_extras), offsetof(gv_cg_extras, a_mu_a), offsetof(gv_cg_extras, ata_mu_b));
     printf("gv_cg_warm %zu %zu %zu\\n", sizeof(gv_cg_warm), offsetof(gv_cg_warm, ata_v_b), offsetof(gv_cg_warm, have_ata_v_b));
     printf("gv_aat_warm %zu %zu %zu\\n", sizeof(gv_aat_warm), offsetof(gv_aat_warm, accumulate_at_mu_a), offsetof(gv_aat_warm, have_ata_v_b));
+    printf("gv_dot_spec %zu %zu %zu\\n", sizeof(gv_dot_spec), offsetof(gv_dot_spec, ya), offsetof(gv_dot_spec, sync));
+    printf("gv_decomp_info %zu %zu %zu\\n", sizeof(gv_decomp_info), offsetof(gv_decomp_info, balanced_cells), offsetof(gv_decomp_info, whole_quads));
     return 0;
 }
 """)
@@ -232,5 +234,7 @@ int main(void) {
         "gv_cg_extras": (C.sizeof(capi.CgExtras), capi.CgExtras.a_mu_a.offset, capi.CgExtras.ata_mu_b.offset),
         "gv_cg_warm": (C.sizeof(capi.CgWarm), capi.CgWarm.ata_v_b.offset, capi.CgWarm.have_ata_v_b.offset),
         "gv_aat_warm": (C.sizeof(capi.AatWarm), capi.AatWarm.accumulate_at_mu_a.offset, capi.AatWarm.have_ata_v_b.offset),
+        "gv_dot_spec": (C.sizeof(capi.DotSpec), capi.DotSpec.ya.offset, capi.DotSpec.sync.offset),
+        "gv_decomp_info": (C.sizeof(capi.DecompInfo), capi.DecompInfo.balanced_cells.offset, capi.DecompInfo.whole_quads.offset),
     }
     assert got == want
