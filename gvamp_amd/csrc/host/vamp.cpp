@@ -9,6 +9,7 @@
 #include <cstring>
 #include <iostream>
 #include <random>
+#include <stdexcept>
 
 #include "utilities.hpp"
 
@@ -431,6 +432,7 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         // travel in ONE launch and ONE read-back (gv_vec_dots_ex) instead of six; each is bit-identical to its own axpby + dot
         struct { gv_dot_spec spec[8]; int* slot[8]; int n = 0; } tail;
         auto want = [&](int* slot, const gv_vec* xa, const gv_vec* xb, const gv_vec* ya, const gv_vec* yb, int sync) {
+            if (tail.n >= 8) throw std::runtime_error("infere_linear: more than eight gathered inner products (gv_vec_dots_ex takes 8)");
             tail.spec[tail.n] = gv_dot_spec{xa, xb, ya, yb, sync};
             tail.slot[tail.n++] = slot;
         };
