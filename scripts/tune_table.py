@@ -32,7 +32,10 @@ for N, M in SHAPES:
                 sh.set_layout(False, layout)
                 sh.synth_bed(1234, 5000)
                 sh.compute_markers_statistics()
-                sh.Ax(np.ones(M))                      # the first matvec measures
+                # the first matvec measures -- on a representative operand: a constant vector has one non-zero digit plane, the
+                # MFMA pipe idles and the ranking of the candidates changes (measured: 7 of 7 votes for a uniform split on
+                # ones where a normal vector gives the hybrid by 3 %)
+                sh.Ax(np.random.default_rng(N + M).standard_normal(M))
                 assert sh.tune_info()[1] == "measured", sh.tune_info()
                 d = (capi.DecompInfo * 4)()
                 sh._ck(sh.L.gv_get_decomp(sh.h, d))
