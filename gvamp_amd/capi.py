@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgvamp.so")
 _LIB = None
 
 SPACE_M, SPACE_N = 0, 1
+ABI_VERSION = 2          # GV_ABI_VERSION of include/gvamp.h this module's ctypes structs were written against
 
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
@@ -77,6 +78,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GvError("libgvamp.so is not built: run `python gvamp_amd/build.py` (needs hipcc)")
     L = C.CDLL(LIB_PATH)
+    if L.gv_abi_version() != ABI_VERSION:
+        raise GvError("libgvamp.so speaks ABI %d, this binding %d: rebuild (python gvamp_amd/build.py --force)" % (L.gv_abi_version(), ABI_VERSION))
     vp, dp, up = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
     i64 = C.c_int64
     L.gv_create.argtypes = [C.c_int, C.POINTER(vp)]

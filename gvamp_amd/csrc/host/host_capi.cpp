@@ -24,6 +24,7 @@ static thread_local std::string g_host_err;
 extern "C" {
 
 const char* gvh_last_error(void) { return g_host_err.c_str(); }
+int gvh_abi_version(void) { return GVH_ABI_VERSION; }
 
 // sim.cpp:78-79,153,183-218 on an already-resident shard: beta (local M), y (N).  Every rank draws the same beta /
 // noise streams; data::Ax carries the cross-rank all-reduce when a communicator is attached.

@@ -35,6 +35,9 @@ class Iter(C.Structure):
                 ("tau1_next", C.c_double), ("seconds", C.c_double), ("seconds_io", C.c_double), ("probe_product", C.c_int)]
 
 
+HOST_ABI_VERSION = 2     # GVH_ABI_VERSION of include/gvamp_host.h (gvh_opts / gvh_iter below)
+
+
 def load():
     global _LIB
     if _LIB is None:
@@ -42,6 +45,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise capi.GvError("libgvamp_host.so is not built: run `make -C gvamp_amd/csrc/host`")
         L = C.CDLL(LIB_PATH)
+        if L.gvh_abi_version() != HOST_ABI_VERSION:
+            raise capi.GvError("libgvamp_host.so speaks ABI %d, this binding %d: rebuild (make -C gvamp_amd/csrc/host)" % (L.gvh_abi_version(), HOST_ABI_VERSION))
         dp, up = C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
         L.gvh_sim_phen.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_ulong, dp, dp]
         L.gvh_infere_linear.argtypes = [C.c_void_p, C.POINTER(Opts), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, up,

@@ -26,7 +26,11 @@ extern "C" {
 typedef struct gv_ctx gv_ctx;
 typedef struct gv_vec gv_vec;
 
-#define GV_ABI_VERSION 1
+/* Bumped whenever a struct of this header grows or a default changes, so that a binding compiled against an older header fails
+ * its version check instead of overrunning a buffer.  History: 1 rounds 1-2; 2 round 3 (gv_decomp_info grew by whole_quads,
+ * the context defaults became kernel mode 1 / no raw rows / layout auto) and round 4 (gv_ingest_info2, gv_set_expected_passes).
+ * A binding checks  gv_abi_version() == GV_ABI_VERSION  once, before anything else (INTEGRATION.md section B does). */
+#define GV_ABI_VERSION 2
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int gv_abi_version(void);

@@ -10,6 +10,10 @@
 extern "C" {
 #endif
 
+/* libgvamp_host.so has its own version: gvh_opts / gvh_iter grow with the host classes (2: reanchor_every, probe_product). */
+#define GVH_ABI_VERSION 2
+int gvh_abi_version(void);
+
 typedef struct {                 /* the knobs vamp reads from Options (options.hpp:91-142) and its constructor */
     int iterations, CG_max_iter, EM_max_iter;
     double EM_err_thr, stop_criteria_thr, rho;

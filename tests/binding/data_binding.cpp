@@ -29,6 +29,10 @@ data::data(unsigned char* bed_slab, const unsigned char* mask4_or_null, int nona
 // data.cpp: end of read_genotype_data()  (data.cpp:201-234) -- hand the slab to the GPU, keep or free bed_data
 void data::read_genotype_data() {
     int dev = rank % gpus_per_node;
+    if (gv_abi_version() != GV_ABI_VERSION) {   // a library built from another header: structs and defaults may differ
+        printf("libgvamp.so speaks ABI %d, this binding was compiled against %d\n", gv_abi_version(), GV_ABI_VERSION);
+        exit(EXIT_FAILURE);
+    }
     if (gv_create(dev, &gv) || gv_set_dims(gv, N, M, Mt, S) ||
         gv_set_mask(gv, vector_ctor ? NULL : mask4.data(), nonas) ||   // after read_phen(); NULL for the vector ctor
         gv_upload_bed(gv, bed_data, size_t(M) * mbytes)) { puts(gv_last_error(gv)); exit(EXIT_FAILURE); }

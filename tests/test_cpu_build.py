@@ -32,7 +32,7 @@ def test_libgvamp_exports_every_declared_symbol(built):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert set(names) == set(capi.EXPORTS), set(names) ^ set(capi.EXPORTS)
-    assert L.gv_abi_version() == 1
+    assert L.gv_abi_version() == capi.ABI_VERSION == 2
 
 
 def test_libgvamp_host_exports(built):
@@ -55,7 +55,7 @@ def test_integration_section_b_is_the_compiled_binding(built):
     code = code[:code.index("```")]
     assert code == block
     called = set(re.findall(r"\b(gv_[a-z0-9_]+)\s*\(", re.sub(r"//.*", "", block)))
-    assert called == {"gv_create", "gv_set_dims", "gv_set_mask", "gv_upload_bed", "gv_last_error", "gv_comm_unique_id",
+    assert called == {"gv_abi_version", "gv_create", "gv_set_dims", "gv_set_mask", "gv_upload_bed", "gv_last_error", "gv_comm_unique_id",
                       "gv_comm_init", "gv_comm_init_callback", "gv_marker_stats", "gv_get_marker_stats", "gv_ax", "gv_atx",
                       "gv_destroy"}, called
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "binding", "libgvbinding.so"))
