@@ -23,7 +23,7 @@ EXPORTS = [
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
-    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
+    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_set_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
 
@@ -64,7 +64,7 @@ class Counters(C.Structure):
 
 class DecompInfo(C.Structure):
     _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int),
-                ("whole_quads", C.c_int64)]
+                ("whole_quads", C.c_int64), ("geo", C.c_float)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
@@ -158,6 +158,7 @@ def load():
     L.gv_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.gv_reset_counters.argtypes = [vp]
     L.gv_get_decomp.argtypes = [vp, C.POINTER(DecompInfo)]
+    L.gv_set_decomp.argtypes = [vp, C.c_int, C.POINTER(DecompInfo)]
     L.gv_tune_info.argtypes = [vp, dp, C.POINTER(C.c_int)]
     L.gv_ingest_info.argtypes = [vp, dp, dp]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
@@ -548,8 +549,16 @@ class Shard:
         self._ck(self.L.gv_get_decomp(self.h, d))
         names = ("atx", "atx2", "ax", "ax2")
         return {n: (({"balanced_cells": int(x.balanced_cells)} | ({"whole_quads": int(x.whole_quads)} if x.whole_quads > 0 else {}))
-                    if x.balanced_cells > 0 else {"ks": x.ks, "taper": round(float(x.taper), 2)}) | {"prio": x.prio, "tuned": bool(x.tuned)}
+                    if x.balanced_cells > 0 else ({"ks": x.ks, "taper": round(float(x.taper), 2)} | ({"geo": round(float(x.geo), 2)} if x.geo > 0 else {})))
+                | {"prio": x.prio, "tuned": bool(x.tuned)}
                 for n, x in zip(names, d)}
+
+    def set_decomp(self, cls, ks=1, balanced_cells=0, whole_quads=0, prio=0, taper=0.0, geo=0.0):
+        """pins the decomposition of one streaming-kernel class (gv_set_decomp); cls: 0 atx, 1 atx2, 2 ax, 3 ax2 or its name"""
+        if isinstance(cls, str):
+            cls = ("atx", "atx2", "ax", "ax2").index(cls)
+        d = DecompInfo(ks, balanced_cells, prio, taper, 0, whole_quads, geo)
+        self._ck(self.L.gv_set_decomp(self.h, cls, C.byref(d)))
 
     def synchronize(self):
         self._ck(self.L.gv_synchronize(self.h))

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -325,11 +326,27 @@ int xfer_stage(gv_ctx* c) {
 }
 int to_host(gv_ctx* c, void* dst, const void* src_dev, size_t nbytes) {
     if (xfer_stage(c)) return 1;
+    // pieces of 2 MiB: the host's copy of piece k into the caller's buffer runs while pieces k + 1 ... cross PCIe (one event per
+    // piece; a whole staging buffer of device-to-host copy followed by a whole buffer of memcpy cost 1.8 ms per 8 MB, of which
+    // 0.3 ms were the link)
+    constexpr size_t PIECE = (size_t)2 << 20;
+    constexpr int NP = (int)(XFER_BYTES / PIECE);
+    for (int k = 0; k < NP; k++)
+        if (!c->xfer_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->xfer_ev[k], hipEventDisableTiming));
     for (size_t off = 0; off < nbytes; off += XFER_BYTES) {
         const size_t n = nbytes - off < XFER_BYTES ? nbytes - off : XFER_BYTES;
-        HIPCHK(c, hipMemcpyAsync(c->xfer_pin, (const char*)src_dev + off, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        CopyPool::get().copy((char*)dst + off, c->xfer_pin, n);
+        int np = 0;
+        for (size_t q = 0; q < n; q += PIECE, np++) {
+            const size_t len = n - q < PIECE ? n - q : PIECE;
+            HIPCHK(c, hipMemcpyAsync((char*)c->xfer_pin + q, (const char*)src_dev + off + q, len, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->xfer_ev[np], c->stream));
+        }
+        np = 0;
+        for (size_t q = 0; q < n; q += PIECE, np++) {
+            const size_t len = n - q < PIECE ? n - q : PIECE;
+            HIPCHK(c, hipEventSynchronize(c->xfer_ev[np]));
+            CopyPool::get().copy((char*)dst + off + q, (char*)c->xfer_pin + q, len);
+        }
     }
     if (nbytes == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -382,7 +399,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
 // accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
-constexpr int GV_TUNE_VERSION = 5;   // bump when the candidate set or the line format changes shape
+constexpr int GV_TUNE_VERSION = 6;   // bump when the candidate set or the line format changes shape
 #ifndef GV_KERNEL_SRC_HASH
 #error "build with -DGV_KERNEL_SRC_HASH=\"...\" (gvamp_amd/build.py computes it from the streaming-kernel sources)"
 #endif
@@ -420,7 +437,7 @@ static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
         if (d.ks < 1 || d.ks > 64 || d.ks > nkb || d.ks < min_ks || d.piv != 0) return false;
         pieces = d.ks;
     }
-    if (!(d.taper >= 0.f && d.taper < 1.f) || (d.prio != 0 && d.prio != 1)) return false;
+    if (!(d.taper >= 0.f && d.taper < 1.f) || !(d.geo >= 0.f && d.geo < 1.f) || (d.geo > 0.f && d.skL > 0) || (d.prio != 0 && d.prio != 1)) return false;
     return (size_t)pieces * 4 * nrg * (side ? pl.rows_n : 64) * 8 * 4 <= pl.partial_bytes;
 }
 static bool tune_cache_load(gv_ctx* c) {
@@ -435,9 +452,9 @@ static bool tune_cache_load(gv_ctx* c) {
         if (strncmp(line, key.c_str(), key.size()) != 0) continue;
         gvm::Decomp d[4];
         long long sk[4], pv[4];
-        if (sscanf(line + key.size(), "%d %lld %lld %d %f %d %lld %lld %d %f %d %lld %lld %d %f %d %lld %lld %d %f", &d[0].ks, &sk[0],
-                   &pv[0], &d[0].prio, &d[0].taper, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[2].ks, &sk[2], &pv[2],
-                   &d[2].prio, &d[2].taper, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper) != 20)
+        if (sscanf(line + key.size(), "%d %lld %lld %d %f %f %d %lld %lld %d %f %f %d %lld %lld %d %f %f %d %lld %lld %d %f %f", &d[0].ks, &sk[0],
+                   &pv[0], &d[0].prio, &d[0].taper, &d[0].geo, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[1].geo, &d[2].ks, &sk[2], &pv[2],
+                   &d[2].prio, &d[2].taper, &d[2].geo, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper, &d[3].geo) != 24)
             continue;
         for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; d[k].piv = pv[k]; got[k] = d[k]; }
         have = true;
@@ -478,8 +495,8 @@ static void tune_cache_store(gv_ctx* c) {
     char buf[1024];
     int n = snprintf(buf, sizeof(buf), "%s", key.c_str());
     for (int k = 0; k < 4; k++)
-        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
-                      d[k]->taper);
+        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f %.2f ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
+                      d[k]->taper, d[k]->geo);
     n += snprintf(buf + n, sizeof(buf) - n, "\n");
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
     if (fd < 0) return;
@@ -567,8 +584,8 @@ int autotune_ks(gv_ctx* c) {
             if (!solo && timed(dual, 0, 1) < 0) return -1.0;   // untimed: the first launch of a new grid shape
             const double t = timed(dual, side, reps);
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f : %.4f ms / %s\n", cls, cd.ks,
-                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, t, solo ? "product" : "pair");
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f : %.4f ms / %s\n", cls, cd.ks,
+                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, cd.geo, t, solo ? "product" : "pair");
             return t;
         };
         gvm::Decomp best = cand[0];
@@ -583,7 +600,8 @@ int autotune_ks(gv_ctx* c) {
         bool any_plain = false;
         for (const gvm::Decomp& cd : cand) any_plain |= cd.skL <= 0 && cd.prio == 0;
         for (const gvm::Decomp& cd : cand) {
-            if (cd.skL <= 0 && cd.prio != 0 && any_plain) continue;
+            if (cd.skL <= 0 && cd.prio != 0 && cd.geo == 0.f && any_plain) continue;
+            if (cd.geo > 0.f && !getenv("GV_TUNE_GEO")) continue;     // (listed so that the partial-sum buffer has room: gv_set_decomp)
             if (consider(cd)) { d = cand[0]; KCHK(c); return done(1); }
         }
         // stage B on the winner: priority, then taper
@@ -604,8 +622,8 @@ int autotune_ks(gv_ctx* c) {
         }
         d = best;
         if (verbose)
-            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f\n", cls, d.ks, (long long)d.skL,
-                    (long long)d.piv, d.prio, d.taper);
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f\n", cls, d.ks, (long long)d.skL,
+                    (long long)d.piv, d.prio, d.taper, d.geo);
     }
     KCHK(c);
     c->tune_source = 1;
@@ -964,7 +982,7 @@ static int plan_decomps(gv_ctx* c) {
         h.ks = 1; h.skL = L; h.piv = piv; h.prio = 1;
         return h;
     };
-    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, int64_t rows, bool balanced_ok, std::vector<gvm::Decomp>& out) {
+    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, int64_t rows, bool balanced_ok, int64_t min_ks_u, std::vector<gvm::Decomp>& out) {
         out.clear();
         for (int prio = 0; prio < 2; prio++) {
             if (prio_only >= 0 && prio != prio_only) continue;
@@ -974,6 +992,15 @@ static int plan_decomps(gv_ctx* c) {
                 out.push_back(d);
             }
         }
+        // geometric splits (big first): ks segments per quad, segment j = geo^j of segment 0, every one at least 8 K-blocks long
+        if (prio_only != 0)
+            for (const auto& gk : {std::pair<int, float>{4, 0.5f}, {6, 0.6f}, {8, 0.65f}}) {
+                double tot = 0.0, wlast = 1.0;
+                for (int j = 0; j < gk.first; j++) { tot += wlast; if (j + 1 < gk.first) wlast *= gk.second; }
+                if ((double)nkb * wlast / tot < 8.0 || gk.first < min_ks_u) continue;
+                gvm::Decomp d; d.ks = gk.first; d.skL = 0; d.prio = 1; d.geo = gk.second;
+                out.push_back(d);
+            }
         if (balanced_ok && prio_only != 0 && nkb >= 2) {
             // hybrid: whole rounds of the 768 resident workgroups go one quad per workgroup (in step over K), the quads that are
             // left over are cut into 768 balanced ranges -- for quad counts just above a multiple of 768 (gv_mfma.hip).  Listed
@@ -986,21 +1013,22 @@ static int plan_decomps(gv_ctx* c) {
             }
         }
     };
-    build(ks3_m, pl.nrg_m, pl.nkb_m, 64, true, c->dec_cand_m);
-    build(ks3_n, pl.nrg_n, pl.nkb_n, pl.rows_n, min_ks_n <= 1, c->dec_cand_n);
+    build(ks3_m, pl.nrg_m, pl.nkb_m, 64, true, 1, c->dec_cand_m);
+    build(ks3_n, pl.nrg_n, pl.nkb_n, pl.rows_n, min_ks_n <= 1, min_ks_n, c->dec_cand_n);
     c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
     // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
     // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
     // first candidate
     auto fix = [&](std::vector<gvm::Decomp>& cand, bool& fixed, gvm::Decomp d) { cand.assign(1, d); fixed = true; };
     const float taper_env = getenv("GV_TAPER") ? (float)atof(getenv("GV_TAPER")) : 0.f;
+    const float geo_env = getenv("GV_GEO") ? (float)atof(getenv("GV_GEO")) : 0.f;
     if (const char* e = getenv("GV_KS_M")) {
         int v = atoi(e);
-        if (v >= 1 && v <= pl.nkb_m && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_m, c->ks_fixed_m, d); }
+        if (v >= 1 && v <= pl.nkb_m && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; d.geo = geo_env; fix(c->dec_cand_m, c->ks_fixed_m, d); }
     }
     if (const char* e = getenv("GV_KS_N")) {
         int v = atoi(e);
-        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; fix(c->dec_cand_n, c->ks_fixed_n, d); }
+        if (v >= min_ks_n && v >= 1 && v <= pl.nkb_n && v <= 64) { gvm::Decomp d; d.ks = v; d.prio = prio_only == 1; d.taper = taper_env; d.geo = geo_env; fix(c->dec_cand_n, c->ks_fixed_n, d); }
     }
     if (const char* e = getenv("GV_SK_M")) {
         gvm::Decomp d; d.skL = skL_of(pl.nrg_m, pl.nkb_m, atoi(e)); d.prio = prio_only != 0;
@@ -1112,6 +1140,7 @@ void gv_destroy(gv_ctx* c) {
     if (c->mbox) (void)hipHostFree(c->mbox);
     if (c->pub_counter) (void)hipFree(c->pub_counter);
     if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
+    for (hipEvent_t e : c->xfer_ev) if (e) (void)hipEventDestroy(e);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1683,18 +1712,15 @@ int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double*
 }
 
 // ---- p-values: data::pvals_calc (data.cpp:1108-1226) and pvals_calc_LOCO (:1235-1353), one estimator ----------------
-// (the per-marker regression test and its Student-t tail: k_pvals_test, gv_kernels.hip)
-// out4[4m..] = {sum a p, sum b p, sum a p^2, sum b p^2} for the N-space device vector p (one pass in kernel mode 1)
-static int marker_sums_p_p2(gv_ctx* c, const double* p, double* p2_scratch, double* out4_dev) {
+// Kernel mode 1: per call ONE pass over the shard whose epilogue runs the per-marker regression test (gvm::marker_pvals: operands,
+// digits, stream, test -- four launches, no allocation: the operands live in the context's N-space scratch, the p-values in an
+// M-space work vector until they are copied out).  Kernel mode 0 (fp64 family, parity anchor): the sums of k_marker_sums2_f64, then
+// the stand-alone test kernel.
+// out4[4m..] = {sum a p, sum b p, sum a p^2, sum b p^2} for the N-space device vector p, fp64 family
+static int marker_sums_p_p2_f64(gv_ctx* c, const double* p, double* p2_scratch, double* out4_dev) {
+    NEED(c, c->have_raw, "p-values: kernel mode 0 needs the raw row layout");
     gvk::mul(c->stream, p2_scratch, p, p, c->npad);
-    if (c->kernel_mode == 1 && c->M > 0) {
-        NEED(c, c->have_stripes, "p-values: kernel mode 1 needs the stripe layouts");
-        if (!c->ks_tuned && autotune_ks(c)) return 1;      // (a p-value call may be the first streaming pass of a context)
-        gvm::marker_sums2(c->stream, c->plan, p, p2_scratch, c->npad, c->red_partial, out4_dev);
-    } else {
-        NEED(c, c->have_raw, "p-values: kernel mode 0 needs the raw row layout");
-        gvk::marker_sums2_f64(c->stream, c->bed, c->M, c->pitch, p, p2_scratch, out4_dev);
-    }
+    gvk::marker_sums2_f64(c->stream, c->bed, c->M, c->pitch, p, p2_scratch, out4_dev);
     KCHK(c);
     return 0;
 }
@@ -1704,36 +1730,51 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
                       double* pvals, double* chrom_pred = nullptr) {
     NEED(c, z1->space == GV_SPACE_N && y->space == GV_SPACE_N && x1_hat->space == GV_SPACE_M, "gv_pvals: bad vector spaces");
     NEED(c, c->have_stats, "gv_pvals: marker statistics must be computed first");
-    if (ensure_work(c)) return 1;
+    if (ensure_work(c) || ensure_w2(c)) return 1;
     const int64_t M = c->M;
     const double sqrtN = sqrt((double)c->N);
+    const bool fused = c->kernel_mode == 1;
+    if (fused && M > 0) {
+        NEED(c, c->have_stripes, "p-values: kernel mode 1 needs the stripe layouts");
+        if (!c->ks_tuned && autotune_ks(c)) return 1;      // (a p-value call may be the first streaming pass of a context)
+    }
     gv_vec *ymod = nullptr, *ych = nullptr, *sq = nullptr, *xch = nullptr;
-    double *sums_dev = nullptr, *pv_dev = nullptr;
+    double* sums_dev = nullptr;
     int* chrom_dev = nullptr;
     int rc = 0;
     const size_t Mn = (size_t)(M > 0 ? M : 1);
     auto cleanup = [&]() {
         for (gv_vec* v : {ymod, ych, sq, xch}) vec_del(c, v);
         if (sums_dev) (void)hipFree(sums_dev);
-        if (pv_dev) (void)hipFree(pv_dev);
         if (chrom_dev) (void)hipFree(chrom_dev);
     };
 #define PV_TRY(expr) do { if ((rc = (expr)) != 0) { cleanup(); return rc; } } while (0)
 #define PV_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    PV_TRY(vec_new(c, GV_SPACE_N, &ymod));
-    PV_TRY(vec_new(c, GV_SPACE_N, &sq));
-    PV_HIP(hipMalloc(&sums_dev, sizeof(double) * 4 * Mn));
-    PV_HIP(hipMalloc(&pv_dev, sizeof(double) * Mn));
-    PV_HIP(hipMemsetAsync(pv_dev, 0, sizeof(double) * Mn, c->stream));
-    gvk::axpby(c->stream, ymod->d, 1.0, y->d, -1.0, z1->d, c->npad);            // y_mod = y - z1 (data.cpp:1117-1119)
-    // the reference masks every term of the regression sums with na_lut[mask4] (data.cpp:1155-1175); the sums here are
-    // matvec-shaped and need zeros at NA / pad slots instead, whatever the caller left there (an unfiltered y holds DBL_MAX)
-    gvk::mask_copy(c->stream, ymod->d, ymod->d, c->mask2, c->npad);
+    double* pv_dev = c->cg_d->d;                // an M-space work vector: nothing else runs between here and the copy-out
+    double *pa = c->w_n->d, *pb = c->w_n2->d;   // operands of the fused pass: p and p^2
+    gvm::PvArgs pva{c->counts, nullptr, 0.0, nullptr, 0};
+    if (!fused) {
+        PV_TRY(vec_new(c, GV_SPACE_N, &ymod));
+        PV_TRY(vec_new(c, GV_SPACE_N, &sq));
+        PV_HIP(hipMalloc(&sums_dev, sizeof(double) * 4 * Mn));
+        gvk::axpby(c->stream, ymod->d, 1.0, y->d, -1.0, z1->d, c->npad);            // y_mod = y - z1 (data.cpp:1117-1119)
+        // the reference masks every term of the regression sums with na_lut[mask4] (data.cpp:1155-1175); the sums here are
+        // matvec-shaped and need zeros at NA / pad slots instead, whatever the caller left there (an unfiltered y holds DBL_MAX)
+        gvk::mask_copy(c->stream, ymod->d, ymod->d, c->mask2, c->npad);
+    }
     if (!chrom) {
-        PV_TRY(marker_sums_p_p2(c, ymod->d, sq->d, sums_dev));
         // y_mark = y_mod + gen_part * x1_hat[k] (data.cpp:1145-1148): the marker's own column, c = x1_hat[k] / sqrt(N)
-        gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, x1_hat->d, 1.0 / sqrtN, nullptr, 0, M, pv_dev);
+        if (fused) {
+            pva.xself = x1_hat->d;
+            pva.self_scale = 1.0 / sqrtN;
+            if (M > 0)      // (an empty shard has no marker to test)
+                gvm::marker_pvals(c->stream, c->plan, y->d, z1->d, nullptr, c->mask2, c->npad, c->mave, c->msig, pa, pb, c->red_partial, pva, pv_dev);
+        } else if (M > 0) {
+            PV_TRY(marker_sums_p_p2_f64(c, ymod->d, sq->d, sums_dev));
+            gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, x1_hat->d, 1.0 / sqrtN, nullptr, 0, M, pv_dev);
+        }
     } else {
+        PV_HIP(hipMemsetAsync(pv_dev, 0, sizeof(double) * Mn, c->stream));      // markers of chromosomes outside 1..23 keep 0
         PV_TRY(vec_new(c, GV_SPACE_N, &ych));
         PV_TRY(vec_new(c, GV_SPACE_M, &xch));
         PV_HIP(hipMalloc(&chrom_dev, sizeof(int) * Mn));
@@ -1749,15 +1790,23 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
             PV_TRY(ax_device(c, xch->d, ych->d));                                // chromosome predictor, all ranks (:1268-1272)
             if (chrom_pred)                                                      // the vector the reference dumps (:1276-1281)
                 PV_TRY(to_host(c, chrom_pred + (size_t)(ch - 1) * 4 * c->mbytes, ych->d, sizeof(double) * 4 * c->mbytes));
-            gvk::axpby(c->stream, ych->d, 1.0, ych->d, 1.0, ymod->d, c->npad);   // + y_mod (:1284)
-            PV_TRY(marker_sums_p_p2(c, ych->d, sq->d, sums_dev));
-            gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, nullptr, 0.0, chrom_dev, ch, M, pv_dev);
+            if (fused) {                                                         // p = chromosome predictor + y_mod (:1284)
+                pva.chrom = chrom_dev;
+                pva.ch = ch;
+                if (M > 0)
+                    gvm::marker_pvals(c->stream, c->plan, y->d, z1->d, ych->d, c->mask2, c->npad, c->mave, c->msig, pa, pb, c->red_partial, pva, pv_dev);
+            } else if (M > 0) {
+                gvk::axpby(c->stream, ych->d, 1.0, ych->d, 1.0, ymod->d, c->npad);
+                PV_TRY(marker_sums_p_p2_f64(c, ych->d, sq->d, sums_dev));
+                gvk::pvals_test(c->stream, c->counts, c->mave, c->msig, sums_dev, nullptr, 0.0, chrom_dev, ch, M, pv_dev);
+            }
         }
     }
     KCHK(c);
     if (M > 0) PV_TRY(to_host(c, pvals, pv_dev, sizeof(double) * M));
 #undef PV_TRY
 #undef PV_HIP
+    if (ymod || ych || sq || xch || sums_dev || chrom_dev) HIPCHK(c, hipStreamSynchronize(c->stream));
     cleanup();
     return 0;
 }
@@ -1921,8 +1970,20 @@ int gv_get_decomp(gv_ctx* c, gv_decomp_info* out4) {
         out4[k].whole_quads = d[k]->skL > 0 ? d[k]->piv : 0;
         out4[k].prio = d[k]->prio;
         out4[k].taper = d[k]->taper;
+        out4[k].geo = d[k]->geo;
         out4[k].tuned = c->ks_tuned ? 1 : 0;
     }
+    return 0;
+}
+int gv_set_decomp(gv_ctx* c, int cls, const gv_decomp_info* in) {
+    NEED(c, cls >= 0 && cls <= 3 && in != nullptr, "gv_set_decomp: class 0..3 and a decomposition are required");
+    NEED(c, c->have_stripes, "gv_set_decomp: no re-encoded layout resident yet (call it after the ingest)");
+    gvm::Decomp d;
+    d.ks = in->ks; d.skL = in->balanced_cells; d.piv = in->balanced_cells > 0 ? in->whole_quads : 0; d.prio = in->prio;
+    d.taper = in->taper; d.geo = in->geo;
+    if (d.skL > 0) d.ks = 1;
+    NEED(c, decomp_ok(c, d, cls >> 1), "gv_set_decomp: the decomposition is not admissible for this shard (range, or too many pieces for the partial-sum buffer)");
+    (cls >> 1 ? c->plan.dn : c->plan.dm)[cls & 1] = d;
     return 0;
 }
 int gv_copy_bandwidth(gv_ctx* c, size_t nbytes, int reps, double* gbps) {

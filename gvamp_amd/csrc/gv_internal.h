@@ -74,6 +74,7 @@ struct gv_ctx {
     bool pub_armed = false;
     unsigned long long pub_seq = 0;
     void* xfer_pin = nullptr;      // 8 MiB pinned staging buffer of the whole-vector host transfers (to_host / to_device)
+    hipEvent_t xfer_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // to_host: one per 2 MiB piece of the staging buffer
     // device-resident CG (cg_run_device): 2 state blocks of gvm::ST_SIZE doubles, the `go` / rider flags, residual traces
     // (2 x cgx_relcap doubles), a pinned staging block for the initial states
     double* cgx_state = nullptr;

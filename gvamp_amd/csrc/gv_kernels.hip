@@ -6,6 +6,7 @@
 // Decode (dotp_lut.hpp:3,1030): code 00 -> a=2, 10 -> a=1, 11 -> a=0, 01 -> missing (a=0, b=0).
 #include <cstdlib>
 #include "gv_internal.h"
+#include "gv_pval_dev.h"
 
 namespace {
 
@@ -1043,55 +1044,7 @@ __global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict
         }
 }
 
-// ---- p-values: the per-marker regression test of data::pvals_calc / pvals_calc_LOCO (data.cpp:1150-1226, :1290-1353) --
-// Student-t two-sided tail P(|T_nu| > t) = I_{nu/(nu+t^2)}(nu/2, 1/2): Lentz continued fraction of the incomplete beta
-// function (DLMF 8.17.22); the reference calls Boost's students_t (utilities.cpp:330-331).
-__device__ double beta_cf(double a, double b, double x) {
-    const double tiny = 1e-300;
-    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
-    if (fabs(d) < tiny) d = tiny;
-    d = 1.0 / d;
-    double h = d;
-    for (int m = 1; m <= 100000; m++) {
-        const double m2 = 2.0 * m;
-        double num = m * (b - m) * x / ((a - 1.0 + m2) * (a + m2));
-        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        h *= d * c;
-        num = -(a + m) * (a + b + m) * x / ((a + m2) * (a + 1.0 + m2));
-        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        const double delta = d * c;
-        h *= delta;
-        if (fabs(delta - 1.0) < 1e-16) break;
-    }
-    return h;
-}
-__device__ double t_two_sided(double t, double nu) {
-    if (isnan(t) || !(nu > 0)) return NAN;
-    if (t == 0) return 1.0;
-    if (isinf(t)) return 0.0;
-    const double a = 0.5 * nu, b = 0.5, w = t * t / nu, x = 1.0 / (1.0 + w);
-    double lnB;   // -ln B(a, 1/2); asymptotic series of lgamma(a + 1/2) - lgamma(a) for large a (DLMF 5.11.13)
-    if (a >= 30.0) {
-        const double ia = 1.0 / a, ia2 = ia * ia;
-        lnB = 0.5 * log(a) - ia * (1.0 / 8 - ia2 * (1.0 / 192 - ia2 * (1.0 / 640 - ia2 * (17.0 / 14336)))) - lgamma(0.5);
-    } else
-        lnB = lgamma(a + b) - lgamma(a) - lgamma(b);
-    const double front = exp(lnB - a * log1p(w) + b * (log(w) - log1p(w)));
-    if (x < (a + 1.0) / (a + b + 2.0)) return front * beta_cf(a, b, x) / a;
-    return 1.0 - front * beta_cf(b, a, w / (1.0 + w)) / b;
-}
-// utilities.cpp:321-334
-__device__ double reg1d_pval(double sumx, double sumsqx, double sumxy, double sumy, double sumsqy, double n) {
-    const double s2y = (sumsqy - sumy * sumy / n) / (n - 1), s2x = (sumsqx - sumx * sumx / n) / (n - 1);
-    const double sxy = (sumxy - sumx * sumy / n) / (n - 1);
-    const double rxy = sxy / sqrt(s2x * s2y);
-    const double t = rxy * sqrt((n - 2) / (1 - rxy * rxy));
-    return t_two_sided(fabs(t), n - 2);
-}
+// ---- p-values: the per-marker regression test (device functions in gv_pval_dev.h) ----------------------------------------
 // One marker per thread.  sums4[4k..] = {sum a p, sum b p, sum a p^2, sum b p^2} of the phenotype residual p over the
 // marker's column (one two-vector pass); the column's own sums are exact, from the genotype counts.  xself != NULL
 // (leave-one-out): the marker's own effect c = xself[k] * self_scale is added back analytically (data.cpp:1145-1148).
@@ -1105,16 +1058,8 @@ __global__ __launch_bounds__(128) void k_pvals_test(const uint32_t* __restrict__
     if (k >= M) return;
     if (chrom && chrom[k] != ch) return;
     const double cself = xself ? xself[k] * self_scale : 0.0;
-    const double n2 = cnt[3 * k], n1 = cnt[3 * k + 1], n0 = cnt[3 * k + 2], mu = mave[k], sg = msig[k];
-    const double count = n0 + n1 + n2;
-    const double sumx = sg * (2.0 * n2 + n1 - mu * count);
-    const double sumsqx = sg * sg * (n2 * (2.0 - mu) * (2.0 - mu) + n1 * (1.0 - mu) * (1.0 - mu) + n0 * mu * mu);
-    const double* s4 = sums4 + 4 * k;
-    const double svy = sg * (s4[0] - mu * s4[1]);                            // sum value * y
-    const double sumxy = svy + cself * sumsqx;
-    const double sumy = s4[1] + cself * sumx;
-    const double sumsqy = s4[3] + 2.0 * cself * svy + cself * cself * sumsqx;
-    pvals[k] = reg1d_pval(sumx, sumsqx, sumxy, sumy, sumsqy, count);
+    const double s4[4] = {sums4[4 * k], sums4[4 * k + 1], sums4[4 * k + 2], sums4[4 * k + 3]};
+    pvals[k] = gvp::marker_pval(cnt[3 * k], cnt[3 * k + 1], cnt[3 * k + 2], mave[k], msig[k], s4, cself);
 }
 
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }

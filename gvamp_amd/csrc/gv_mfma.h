@@ -13,6 +13,9 @@ struct Decomp {
     int prio = 0;        // 1: waves lower their issue priority as they progress (k_mfma_matvec)
     float taper = 0.f;   // uniform split only: K-segment j is (1 + taper (ks-1-2j)/(ks-1)) times the mean length, so the
                          // workgroups dispatched last (the last segment) are the shortest and the launch's tail is short
+    float geo = 0.f;     // uniform split only, 0 < geo < 1: K-segment j is geo^j times segment 0 (big first, geometrically
+                         // smaller behind): the dispatcher hands the short workgroups out as slots free up, which evens out
+                         // the 10-20 % spread in the time equal shares take (takes precedence over taper)
 };
 
 // workgroups of a launch over nq quads x nkb K-blocks, and pieces (int32 partial sums per row) the epilogues add up at most
@@ -95,9 +98,19 @@ void stats_from_tiles(hipStream_t s, const void* tiles, const uint32_t* mask2, i
 // counts (may be NULL): 3 per marker = present individuals with a = 2, 1, 0
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
                         int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts);
-// one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2} (raw, unscaled)
-void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
-                  double* out4);
+// The p-value pass (data::pvals_calc / pvals_calc_LOCO): p = mask (y - z1) + add (add may be NULL) and p^2 go through ONE pass over
+// the marker-major layout, the per-marker regression test runs in the epilogue: pvals[m] for every local marker (chrom == NULL) or
+// for the markers of chromosome ch.  pa / pb: npad doubles of scratch each (they receive p and p^2).
+struct PvArgs {
+    const uint32_t* cnt;      // 3 per marker: present individuals with a = 2, 1, 0 (marker statistics)
+    const double* xself;      // leave-one-out: the marker's own effect x1_hat[m] * self_scale is added back; NULL: none
+    double self_scale;
+    const int* chrom;         // LOCO: chromosome of every marker, or NULL
+    int ch;
+};
+void marker_pvals(hipStream_t s, const Plan& pl, const double* y, const double* z1, const double* add, const uint32_t* mask2,
+                  int64_t npad, const double* mave, const double* msig, double* pa, double* pb, double* red_partial, const PvArgs& a,
+                  double* pvals);
 // out[M] = data::ATx(p); p has npad entries (zero at NA / pad slots)
 // addx != NULL: out = tau * ATx(p) + gam2 * addx, the whole of vamp::lmmse_mult's epilogue (vamp.cpp:1112-1116)
 void atx(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig,

@@ -22,8 +22,11 @@
 // and the vector digits are stored in the same (d, g, s, t) order (k_quant).  Two stripe sets are resident:
 //   stripes_m : rows = markers,     K = individuals  (ATx)
 //   stripes_n : rows = individuals, K = markers      (Ax; the 2-bit transpose)
+#include <cstdlib>
+
 #include "gv_internal.h"
 #include "gv_mfma.h"
+#include "gv_pval_dev.h"
 
 namespace {
 
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void k_stripes_n(const uint8_t* __restrict__ r
 // matvec kernels -- and keeps the three genotype counts of its four tiles.  (One wave per TILE, the first form of this kernel, had
 // the four waves of a workgroup pick the 1 KiB pieces of a supertile at different times: 4.5-5.0 TB/s where the matvec kernels
 // stream at 6.6.)
+template <int UNR>
 __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__ stripes, const uint32_t* __restrict__ mask2,
                                                        int64_t M, int64_t nkb, int64_t P4, double nonas,
                                                        double alpha_scale, double* __restrict__ mave,
@@ -101,7 +105,10 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // row group of 64 markers
     if (rg * 64 >= M) return;
-    uint32_t n2[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n0[4] = {0, 0, 0, 0};
+    // per tile: nh = codes with the high bit set (a = 2 or missing), nl = with the low bit set (a = 1 or missing), nb = both
+    // (missing), all among the individuals with a phenotype; np = those individuals in this lane's K slices.  Then n2 = nh - nb,
+    // n1 = nl - nb, n0 = np - nh - nl + nb: nine vector instructions per dword instead of fourteen for the three masked counts
+    uint32_t nh[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, np = 0;
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     struct Tiles { v4u t[4]; };
     auto load = [&](Tiles& a, const v4u* p) {
@@ -110,30 +117,33 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
     };
     auto count = [&](const Tiles& a, int64_t kb) {
         const int64_t w0 = kb * 16 + g * 4;   // mask2 word of entries 256kb + 64g
-        uint32_t pm[4];
+        uint32_t pm[4];                       // both bits of a pair are set for an individual with a phenotype
 #pragma unroll
-        for (int d = 0; d < 4; d++) pm[d] = (w0 + d < P4) ? (mask2[w0 + d] & 0x55555555u) : 0u;
+        for (int d = 0; d < 4; d++) {
+            pm[d] = (w0 + d < P4) ? mask2[w0 + d] : 0u;
+            np += __popc(pm[d] & 0x55555555u);
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t ws[4] = {a.t[i].x, a.t[i].y, a.t[i].z, a.t[i].w};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                const uint32_t lo = ws[d] & 0x55555555u, hi = (ws[d] >> 1) & 0x55555555u;
-                n2[i] += __popc(hi & ~lo & pm[d]);
-                n1[i] += __popc(~hi & lo & pm[d]);
-                n0[i] += __popc(~hi & ~lo & pm[d]);
+                const uint32_t wm = ws[d] & pm[d];
+                nh[i] += __popc(wm & 0xAAAAAAAAu);
+                nl[i] += __popc(wm & 0x55555555u);
+                nb[i] += __popc(wm & (wm >> 1) & 0x55555555u);
             }
         }
     };
-    // two K-blocks per trip: 8 KiB of independent non-temporal loads in flight per wave
+    // UNR K-blocks per trip: UNR x 4 KiB of independent non-temporal loads in flight per wave
     const v4u* src = reinterpret_cast<const v4u*>(stripes) + rg * nkb * 256 + lane;
     int64_t kb = 0;
-    for (; kb + 2 <= nkb; kb += 2) {
-        Tiles a, b;
-        load(a, src + kb * 256);
-        load(b, src + (kb + 1) * 256);
-        count(a, kb);
-        count(b, kb + 1);
+    for (; kb + UNR <= nkb; kb += UNR) {
+        Tiles a[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; j++) load(a[j], src + (kb + j) * 256);
+#pragma unroll
+        for (int j = 0; j < UNR; j++) count(a[j], kb + j);
     }
     for (; kb < nkb; kb++) {
         Tiles a;
@@ -143,10 +153,12 @@ __global__ __launch_bounds__(256) void k_stats_stripes(const uint4* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         // sum over the 4 lanes (g) that share row r of tile i
-        uint32_t c2 = n2[i], c1 = n1[i], c0 = n0[i];
-        c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
-        c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
-        c0 += __shfl_xor(c0, 16, 64); c0 += __shfl_xor(c0, 32, 64);
+        uint32_t ch = nh[i], cl = nl[i], cb = nb[i], cp = np;
+        ch += __shfl_xor(ch, 16, 64); ch += __shfl_xor(ch, 32, 64);
+        cl += __shfl_xor(cl, 16, 64); cl += __shfl_xor(cl, 32, 64);
+        cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64);
+        cp += __shfl_xor(cp, 16, 64); cp += __shfl_xor(cp, 32, 64);
+        const uint32_t c2 = ch - cb, c1 = cl - cb, c0 = cp - ch - cl + cb;
         const int64_t m = rg * 64 + 16 * i + r;
         if (g == 0 && m < M) {
             double suma = 2.0 * c2 + 1.0 * c1, sumb = (double)c0 + (double)c1 + (double)c2;
@@ -330,6 +342,33 @@ __global__ __launch_bounds__(256) void k_prep_atx(PrepAtx a, int64_t n, double* 
         s += val;
     }
     prep_block_partials(partial + v * PREP_STRIDE, mx, s, shm, shs);
+}
+
+// The two operands of the p-value pass in one sweep: p = mask (y - z1) + add (add may be NULL; LOCO: the chromosome's predictor,
+// data.cpp:1284) and p^2, with the block partials of both (slot 0: p, slot 1: p^2) -- what k_axpby, k_mask_copy, k_mul and
+// k_prep_atx did in four launches.  The regression sums are matvec-shaped: they need zeros at NA / pad slots, whatever the caller
+// left there (an unfiltered y holds DBL_MAX, data.cpp:147).
+__global__ __launch_bounds__(256) void k_prep_pv(const double* __restrict__ y, const double* __restrict__ z1,
+                                                 const double* __restrict__ add, const uint32_t* __restrict__ mask2, int64_t n,
+                                                 double* __restrict__ pa, double* __restrict__ pb, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
+    double mx = 0.0, s = 0.0, mx2 = 0.0, s2 = 0.0;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t present = (mask2[i >> 4] >> (2 * (i & 15))) & 1u;
+        double v = present ? y[i] - z1[i] : 0.0;
+        if (add) v = add[i] + v;
+        const double v2 = v * v;
+        pa[i] = v;
+        pb[i] = v2;
+        mx = isfinite(v) ? fmax(mx, fabs(v)) : inf;
+        mx2 = isfinite(v2) ? fmax(mx2, v2) : inf;
+        s += v;
+        s2 += v2;
+    }
+    prep_block_partials(partial, mx, s, shm, shs);
+    __syncthreads();
+    prep_block_partials(partial + PREP_STRIDE, mx2, s2, shm, shs);
 }
 
 // fixed-point digits of v in MFMA B-operand order.  Thread = (kb, g, d, s): 4 entries k = 256kb+64g+16d+4t+s (t=0..3)
@@ -1103,14 +1142,19 @@ __global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t
 
 __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
 
-// Raw per-marker sums of TWO N-vectors from one pass over stripes_m (MODE 2):
-//   out[4m + 0] = sum_n a p1, [4m + 1] = sum_n b p1, [4m + 2] = sum_n a p2, [4m + 3] = sum_n b p2
-// (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N): the ingredients of data::pvals_calc, data.cpp:1150-1170)
-__global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
-                                                   const double* __restrict__ scal1, const double* __restrict__ scal2,
-                                                   double* __restrict__ out, int64_t nkb, int64_t skL, int64_t piv) {
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// The p-value pass (data::pvals_calc, data.cpp:1150-1226; pvals_calc_LOCO, :1290-1353): ONE pass over stripes_m for the two
+// N-vectors p = y_mod and p^2 (MODE 2), and in its epilogue, per marker, the four raw sums
+//   {sum_n a p, sum_n b p, sum_n a p^2, sum_n b p^2}     (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N))
+// recombined from the digit planes and handed straight to the regression test (gvp::marker_pval) -- the sums never go through
+// memory (32 MB written and read back at M = 1M when the test was a launch of its own).
+struct FinPvals { const uint32_t* cnt; const double* mave; const double* msig; const double* xself; double self_scale;
+                  const int* chrom; int ch; double* pvals; };
+__global__ __launch_bounds__(128) void k_fin_pvals(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
+                                                   const double* __restrict__ scal1, const double* __restrict__ scal2, FinPvals a,
+                                                   int64_t nkb, int64_t skL, int64_t piv) {
+    const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (m >= M) return;
+    if (a.chrom && a.chrom[m] != a.ch) return;          // LOCO: only the markers of chromosome ch are tested and written
     ksplit = pieces_of(m, ksplit, nkb, skL, 8, piv);
     long long s[4][7];
 #pragma unroll
@@ -1126,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ p
             s[pl][4] += x1.x; s[pl][5] += x1.y; s[pl][6] += x1.z;
         }
     }
+    double s4[4];
 #pragma unroll
     for (int v = 0; v < 2; v++) {
         long long xh, xl, yh, yl;
@@ -1134,9 +1179,11 @@ __global__ __launch_bounds__(256) void k_fin_sums2(const int32_t* __restrict__ p
         const double* sc = v ? scal2 : scal1;
         const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * sc[3];
         const double sm = ((double)yh * 4294967296.0 + (double)yl) * sc[3];
-        out[4 * m + 2 * v] = sa;
-        out[4 * m + 2 * v + 1] = sc[1] - sm;
+        s4[2 * v] = sa;
+        s4[2 * v + 1] = sc[1] - sm;
     }
+    const double cself = a.xself ? a.xself[m] * a.self_scale : 0.0;
+    a.pvals[m] = gvp::marker_pval(a.cnt[3 * m], a.cnt[3 * m + 1], a.cnt[3 * m + 2], a.mave[m], a.msig[m], s4, cself);
 }
 
 // exact digit recombination: sum_c s_c 256^c as (hi, lo) with value = hi * 2^32 + lo
@@ -1315,12 +1362,17 @@ static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb) {
     KBounds kb{};
     if (d.skL <= 0) {
         const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
-        double acc = 0.0;
+        // cumulative segment lengths, every segment at least one K-block (ks <= nkb): geometric (big first), tapered, or equal
+        double w[GV_MAX_KS], tot = 0.0, acc = 0.0;
+        for (int j = 0; j < ks; j++) {
+            if (d.geo > 0.f && ks > 1) w[j] = j ? w[j - 1] * (double)d.geo : 1.0;
+            else w[j] = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
+            tot += w[j];
+        }
         kb.b[0] = 0;
         for (int j = 0; j < ks; j++) {
-            const double w = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
-            acc += w;
-            int64_t e = (int64_t)((double)nkb * acc / (double)ks + 0.5);
+            acc += w[j];
+            int64_t e = (int64_t)((double)nkb * acc / tot + 0.5);
             const int64_t lo = (int64_t)kb.b[j] + 1, hi = nkb - (ks - 1 - j);
             e = e < lo ? lo : (e > hi ? hi : e);
             kb.b[j + 1] = (uint32_t)e;
@@ -1344,21 +1396,7 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = gvm::grid_of(d, nq, nkb);
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
-    KBounds kb{};
-    if (d.skL <= 0) {
-        const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
-        double acc = 0.0;
-        kb.b[0] = 0;
-        for (int j = 0; j < ks; j++) {      // cumulative tapered lengths, every segment at least one K-block (ks <= nkb)
-            const double w = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
-            acc += w;
-            int64_t e = (int64_t)((double)nkb * acc / (double)ks + 0.5);
-            const int64_t lo = (int64_t)kb.b[j] + 1, hi = nkb - (ks - 1 - j);
-            e = e < lo ? lo : (e > hi ? hi : e);
-            kb.b[j + 1] = (uint32_t)e;
-        }
-        kb.b[ks] = (uint32_t)nkb;
-    }
+    const KBounds kb = make_bounds(d, nkb);
 #define GV_LAUNCH_MV(SKV, GOV)                                                                                             \
     hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,         \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go,        \
@@ -1391,8 +1429,12 @@ void stripes_n_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t m
 void stats_from_stripes(hipStream_t s, const void* stripes_m, const uint32_t* mask2, int64_t M, int64_t nkb,
                         int64_t P4, double nonas, double alpha_scale, double* mave, double* msig, uint32_t* counts) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(k_stats_stripes, dim3(nblk((M + 63) / 64, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M,
-                       nkb, P4, nonas, alpha_scale, mave, msig, counts);
+    // K-blocks in flight per wave: 4 (16 KiB) measured best on the 100 GB shard (GV_STATS_UNROLL = 2 / 3 / 4: development)
+    static const int unr = getenv("GV_STATS_UNROLL") ? atoi(getenv("GV_STATS_UNROLL")) : 4;
+#define GV_STATS(U) hipLaunchKernelGGL(k_stats_stripes<U>, dim3(nblk((M + 63) / 64, 4)), dim3(256), 0, s, (const uint4*)stripes_m, mask2, M, \
+                                       nkb, P4, nonas, alpha_scale, mave, msig, counts)
+    if (unr == 2) GV_STATS(2); else if (unr == 3) GV_STATS(3); else GV_STATS(4);
+#undef GV_STATS
 }
 
 // Blocks of a prep launch (every block of the quantisation launch behind it adds their partials up: prep_scalars)
@@ -1473,17 +1515,25 @@ void atx2(hipStream_t s, const Plan& pl, const double* pa, const double* pb, int
                        pl.scal, mave, msig, inv_sqrt_n, f, tau, gam2, 4, pl.nkb_m, pl.dm[1].skL, piv_of(pl.dm[1], (pl.nrg_m + 3) / 4));
 }
 
-// one pass over stripes_m for two N-vectors: out4[4m..] = {sum a p1, sum b p1, sum a p2, sum b p2}
-void marker_sums2(hipStream_t s, const Plan& pl, const double* p1, const double* p2, int64_t npad, double* red_partial,
-                  double* out4) {
-    prep_quant_atx(s, pl, p1, p2, npad, red_partial);
+// the p-value pass: operands (k_prep_pv), digits, ONE pass over stripes_m, per-marker test in the epilogue (k_fin_pvals)
+void marker_pvals(hipStream_t s, const Plan& pl, const double* y, const double* z1, const double* add, const uint32_t* mask2,
+                  int64_t npad, const double* mave, const double* msig, double* pa, double* pb, double* red_partial, const PvArgs& a,
+                  double* pvals) {
+    const int nb = prep_blocks(npad);
+    hipLaunchKernelGGL(k_prep_pv, dim3(nb), dim3(256), 0, s, y, z1, add, mask2, npad, pa, pb, red_partial);
+    QuantArgs q{};
+    q.nblocks = nb;
+    q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0; q.part[0] = red_partial; q.wr[0] = 1;
+    q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8; q.part[1] = red_partial + PREP_STRIDE; q.wr[1] = 1;
+    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), 2), dim3(256), 0, s, q, npad, pl.nkb_m, 16);
     {
-        gvm::Plan q = pl;      // no roofline events around the p-value pass
-        q.ev0 = q.ev1 = nullptr;
-        launch_stream<2>(s, q, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
+        gvm::Plan q2 = pl;      // no roofline events around the p-value pass
+        q2.ev0 = q2.ev1 = nullptr;
+        launch_stream<2>(s, q2, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, pl.dm[1]);
     }
-    hipLaunchKernelGGL(k_fin_sums2, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M,
-                       pl.scal, pl.scal + 4, out4, pl.nkb_m, pl.dm[1].skL, piv_of(pl.dm[1], (pl.nrg_m + 3) / 4));
+    FinPvals f{a.cnt, mave, msig, a.xself, a.self_scale, a.chrom, a.ch, pvals};
+    hipLaunchKernelGGL(k_fin_pvals, dim3(nblk(pl.M, 128)), dim3(128), 0, s, pl.partial, pl.dm[1].ks, pl.nrg_m * 64, pl.M, pl.scal,
+                       pl.scal + 4, f, pl.nkb_m, pl.dm[1].skL, piv_of(pl.dm[1], (pl.nrg_m + 3) / 4));
 }
 
 // operands cv / ev (and cv2 / ev2) -> digit buffers of the Ax side.  Two stripe sets: one vector dig0 = [c | e], two vectors

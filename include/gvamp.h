@@ -344,11 +344,18 @@ typedef struct {
     int tuned;               /* 1 once the pick has been made (measured or read from the cache) */
     int64_t whole_quads;     /* balanced only, > 0: hybrid -- that many groups of four row groups go one per workgroup over the
                               * whole K range, only the remaining ones are cut into ranges of balanced_cells cells */
+    float geo;               /* uniform split, 0 < geo < 1: segment j is geo^j times segment 0 (big first; replaces taper) */
 } gv_decomp_info;
 /* Wall time of the last ingest (gv_upload_bed / gv_upload_bed_file / gv_synth_bed), split into allocating the resident
  * layouts (hipMalloc of 100+ GB: the driver maps and wipes the pages; 0 when the buffers were reused) and filling them. */
 int gv_ingest_info(gv_ctx* ctx, double* alloc_seconds, double* fill_seconds);
 int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
+/* Pins the decomposition of class cls (0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax), e.g. one a deployment measured itself:
+ * `tuned` is ignored, balanced_cells > 0 selects a balanced / hybrid grid (ks unused), else a uniform split of ks segments with
+ * taper or geo.  Call it after the ingest; a first matvec that tunes (gv_tune_info source 1 / 2 / 4) overwrites it, one that has
+ * already happened does not.  Refused when the decomposition needs more partial-sum pieces than the context holds room for.
+ * Never changes a bit of output (exact integer accumulation). */
+int gv_set_decomp(gv_ctx* ctx, int cls, const gv_decomp_info* in);
 /* How the picks were made: *source = -1 not yet (the first matvec in kernel mode 1 makes them), 0 the cost model's first
  * candidate (tuning impossible), 1 measured on the device now (*seconds of wall time), 2 read from the cache an earlier run on
  * the same (device, N, M, kernel sources) left ($GV_TUNE_CACHE_DIR, $XDG_CACHE_HOME/gvamp_amd or ~/.cache/gvamp_amd;

@@ -1,0 +1,63 @@
+"""Development: in-process A/B of work decompositions of one streaming-kernel class on ONE resident shard (what differs between
+processes -- the placement of the resident allocations, +-3 % -- cancels).   python scripts/ab_decomp.py N M cls [layout] -- spec ...
+cls: atx | atx2 | ax | ax2;  spec: "ks=4,geo=0.5,prio=1" | "cells=995,prio=1" | "cells=218,quads=1536,prio=1" | "tuned" (the library's pick)
+Candidates are run round-robin, `--rounds` times `--reps` products each (HIP events around the whole product, prep / finalise included)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gvamp_amd import capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("N", type=int)
+ap.add_argument("M", type=int)
+ap.add_argument("cls")
+ap.add_argument("--layout", type=int, default=1)
+ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--reps", type=int, default=6)
+ap.add_argument("specs", nargs="+")
+a = ap.parse_args()
+cls = ("atx", "atx2", "ax", "ax2").index(a.cls)
+with capi.Shard(a.N, a.M) as sh:
+    sh.set_layout(False, a.layout)
+    sh.synth_bed(1234, 5000)
+    sh.compute_markers_statistics()
+    rng = np.random.default_rng(0)
+    x, x2, p, p2, w, w2 = sh.vecM(rng.standard_normal(a.M)), sh.vecM(rng.standard_normal(a.M)), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM()
+    sh.ax_dev(x, p); sh.ax_dev(x2, p2)          # (tunes / loads the picks)
+    tuned = sh.decomp()[a.cls]
+    print("library pick:", tuned, sh.tune_info(), flush=True)
+    f = {0: lambda: sh.atx_dev(p, w), 2: lambda: sh.ax_dev(x, p), 1: lambda: sh.atx2_dev(p, p2, w, w2), 3: lambda: sh.ax2_dev(x, x2, p, p2)}[cls]
+    other = {0: lambda: sh.ax_dev(x, p), 1: lambda: sh.ax2_dev(x, x2, p, p2), 2: lambda: sh.atx_dev(p, w), 3: lambda: sh.atx2_dev(p, p2, w, w2)}[cls]
+    key = "ms_atx" if cls < 2 else "ms_ax"
+
+    def apply(spec):
+        if spec == "tuned":
+            kw = dict(ks=tuned.get("ks", 1), balanced_cells=tuned.get("balanced_cells", 0), whole_quads=tuned.get("whole_quads", 0),
+                      prio=tuned["prio"], taper=tuned.get("taper", 0.0), geo=tuned.get("geo", 0.0))
+        else:
+            d = dict(kv.split("=") for kv in spec.split(","))
+            kw = dict(ks=int(d.get("ks", 1)), balanced_cells=int(d.get("cells", 0)), whole_quads=int(d.get("quads", 0)), prio=int(d.get("prio", 0)),
+                      taper=float(d.get("taper", 0)), geo=float(d.get("geo", 0)))
+        sh.set_decomp(cls, **kw)
+
+    f(); ref = w.download() if cls < 2 else p.download()
+    res = {s: [] for s in a.specs}
+    sh.set_timing(1)
+    for r in range(a.rounds):
+        for s in a.specs:
+            apply(s)
+            other(); f()                                      # the pair the solvers issue; first launch of a new grid shape untimed
+            sh.counters(reset=True)
+            for _ in range(a.reps):
+                other(); f()
+            res[s].append(sh.counters()[key] / a.reps)
+            got = w.download() if cls < 2 else p.download()
+            assert np.array_equal(got, ref), "decomposition changed the result: " + s
+    mb = (a.N + 3) // 4
+    nbytes = a.M * mb + 24 * a.M + 32 * mb
+    for s in a.specs:
+        v = np.array(res[s])
+        print("%-40s ms mean %.4f min %.4f max %.4f   %.0f GB/s" % (s, v.mean(), v.min(), v.max(), nbytes / v.mean() / 1e6))

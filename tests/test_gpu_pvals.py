@@ -79,3 +79,26 @@ def test_gvamp_sim_store_pvals_files(tmp_path, oracle):
         want = oracle.ax(bed, N, M, mave, msig, np.where(chrom == ch, x1, 0.0))
         assert pred.shape == want.shape and np.allclose(pred, want, rtol=2e-5, atol=1e-9), ch
     assert np.all(np.loadtxt(out + "s_LOCO_chr_15.csv") == 0)
+
+
+@pytest.mark.parametrize("N,M", [(26, 70), (60000, 300)])
+def test_student_t_tail_branches_vs_oracle(oracle, N, M):
+    """The two evaluations of the Student-t tail in gv_pval_dev.h against the oracle's continued fraction: a sample small enough
+    for the Lentz fraction (nu / 2 < 15) and one deep in the large-sample expansion (nu / 2 = 3e4: three terms), with effects strong
+    enough for p-values down to 1e-100 and below -- the relative error has to hold in the far tail, not only near 1."""
+    rng = np.random.default_rng(N)
+    bed = synth.synth_bed(N, M, seed=77, miss_ppm=8000)
+    x1 = np.zeros(M)
+    x1[:: max(1, M // 12)] = np.linspace(0.5, 30.0 if N > 1000 else 2.0, len(x1[:: max(1, M // 12)]))
+    mave, msig = oracle.marker_stats(bed, N, M)
+    z1 = oracle.ax(bed, N, M, mave, msig, x1)
+    y = np.zeros(4 * ((N + 3) // 4))
+    y[:N] = z1[:N] + rng.standard_normal(N)
+    ref = oracle.pvals(bed, N, M, z1, y, x1, nthreads=4)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        got = sh.pvals_calc(sh.vecN(z1), sh.vecN(y), sh.vecM(x1))
+    assert np.all(np.isfinite(got)) and np.allclose(got, ref, rtol=1e-8, atol=0), np.max(np.abs(got / np.where(ref > 0, ref, 1) - 1))
+    if N > 1000:
+        assert 0 < ref.min() < 1e-100      # (the strongest effect stays clear of the underflow threshold)
