@@ -188,6 +188,8 @@ def main():
     if not dev_ok:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    # one process per GPU: each rank on the CPUs of the NUMA node its GPU hangs off (no-op on a single-node host)
+    numa_node = capi.bind_host_numa(local_rank) if (world > 1 or os.environ.get("GVAMP_NUMA_BIND") == "1") else -1
     force_dist = os.environ.get("GVAMP_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the
     # N > 1 plumbing (rendezvous, id broadcast, RCCL communicator) on a single-GPU box under torchrun --nproc-per-node 1
     if world > 1 or force_dist:
@@ -219,10 +221,18 @@ def main():
     t_ingest = time.time() - t0
     t_alloc, t_fill = sh.ingest_info()      # hipMalloc of the resident layouts (driver: page mapping / wipe) vs generating them
     layout = sh.get_layout()                # 1 two stripe sets, 2 tile layout, 0 none (kernel mode 0)
+    ingest_stats = sh.ingest_stats()
     if world > 1 or force_dist:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         sh.comm_init(world, rank, uid[0])
+    # the automatic layout is picked per rank from its own free HBM: a leg every rank must enter together (the closing tile-layout
+    # leg starts with a barrier) is gated on what ALL ranks hold, not on this rank's pick
+    layout_everywhere = layout
+    if world > 1 or force_dist:
+        t = torch.tensor([float(layout), -float(layout)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        layout_everywhere = layout if t[0].item() == -t[1].item() else -1      # -1: the ranks hold different layouts
 
     rng = np.random.default_rng(7)          # same p on every rank's own slice
     rng_p = rng.standard_normal(Mt)[S:S + M]
@@ -339,7 +349,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     if world > 1 or force_dist:
-        out["multi_gpu"] = {"rccl_nranks": sh.L.gv_comm_size(sh.h), "exchange": "ncclAllReduce(double, sum, %d) per Ax on the "
+        out["multi_gpu"] = {"rccl_nranks": sh.L.gv_comm_size(sh.h), "rank0_numa_node": numa_node, "exchange": "ncclAllReduce(double, sum, %d) per Ax on the "
                             "context stream (data.cpp:928/:995)" % (4 * ((N + 255) // 256) * 64),
                             "ms_allreduce_per_ax": max(r["ms_allreduce_per_ax"] for r in per_rank), "per_rank": per_rank}
     else:
@@ -382,6 +392,8 @@ def main():
         # earlier run on this shape left them in the cache) + every VAMP iteration, the cold first one included
         out["vamp"]["time_to_solution_s"] = round(t_ingest + tune_s + out["vamp"]["wall_s_all_iterations"], 3)
         out["vamp"]["time_to_solution_parts"] = {"ingest_s": round(t_ingest, 3), "of_which_hipMalloc_s": round(t_alloc, 3),
+                                                 "of_which_hidden_behind_source_prep_s": round(ingest_stats["overlap_s"], 3),
+                                                 "resident_GB": round(ingest_stats["resident_GB"], 1),
                                                  "tune_s": round(tune_s, 3), "tune_source": tune_src,
                                                  "iterations_s": out["vamp"]["wall_s_all_iterations"]}
         out["vamp"]["config"] = (
@@ -485,7 +497,7 @@ def main():
     sh.close()
     # ---- the same operator on ONE resident layout (gv_set_layout(.., 2): M*N/4 bytes instead of 2 x M*N/4), measured in the same
     # process on the same box, and checked bit for bit against the two-layout result above --------------------------------
-    if a.mode == 1 and layout == 1 and not a.no_tile_leg:
+    if a.mode == 1 and layout_everywhere == 1 and not a.no_tile_leg:
         barrier()
         # this leg always MEASURES its decompositions (no cache, no shipped table): its tune_s is what a cold first contact with a
         # shape costs on this box, whatever the main leg found in the cache or in gv_tune_builtin.h
@@ -499,6 +511,7 @@ def main():
             st.synth_bed(a.seed, 5000)
             st.compute_markers_statistics()
             t_in = time.time() - t1
+            tile_ingest = st.ingest_stats()
             if world > 1 or force_dist:
                 uid = [capi.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
@@ -536,7 +549,11 @@ def main():
                 "value_GBps": round(job_bytes * nst / dt2 / 1e9, 2), "ms_per_step": round(dt2 / nst * 1e3, 4), "steps": nst,
                 "ax": {"avg_ms": round(m_ax, 4), "GBps": round(shard_bytes / (m_ax * 1e-3) / 1e9, 1) if m_ax > 0 else None},
                 "atx": {"avg_ms": round(m_atx, 4), "GBps": round(shard_bytes / (m_atx * 1e-3) / 1e9, 1) if m_atx > 0 else None},
-                "bit_identical_to_two_layouts": same, "ingest_s": round(t_in, 2), "tune_s": round(tt_s, 3), "tune_source": tt_src,
+                "bit_identical_to_two_layouts": same, "ingest_s": round(t_in, 2), "ingest_alloc_s": round(tile_ingest["alloc_s"], 2),
+                "ingest_fill_s": round(tile_ingest["fill_s"], 2), "resident_GB": round(tile_ingest["resident_GB"], 1),
+                "note": "what gv_set_layout(.., 3) picks when gv_set_expected_passes says the run is short (< 1000 ATx passes): half the "
+                        "bytes to allocate and fill",
+                "tune_s": round(tt_s, 3), "tune_source": tt_src,
                 "decomposition": st.decomp()}
         for k, v in cold_env.items():
             if v is None:

@@ -22,8 +22,8 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots", "gv_vec_dots_ex",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_set_timing",
-    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_set_decomp", "gv_tune_info", "gv_ingest_info", "gv_copy_bandwidth", "gv_read_bandwidth",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_bind_host_numa", "gv_set_timing",
+    "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_set_decomp", "gv_tune_info", "gv_ingest_info", "gv_ingest_info2", "gv_set_expected_passes", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
 
@@ -62,12 +62,26 @@ class Counters(C.Structure):
                 ("n_atx_pass", C.c_int64), ("n_allreduce", C.c_int64)]
 
 
+class IngestStats(C.Structure):      # gv_ingest_stats
+    _fields_ = [("alloc_seconds", C.c_double), ("fill_seconds", C.c_double), ("overlap_seconds", C.c_double),
+                ("resident_bytes", C.c_double), ("layout", C.c_int), ("expected_passes", C.c_int64)]
+
+
 class DecompInfo(C.Structure):
     _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int),
                 ("whole_quads", C.c_int64), ("geo", C.c_float)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+
+
+def bind_host_numa(device):
+    """gv_bind_host_numa: this process onto the CPUs next to its GPU; returns the NUMA node or -1 (nothing changed)"""
+    L = load()
+    node = C.c_int(-1)
+    if L.gv_bind_host_numa(int(device), C.byref(node)):
+        raise GvError(L.gv_last_error(None).decode())
+    return node.value
 
 
 def load():
@@ -161,6 +175,9 @@ def load():
     L.gv_set_decomp.argtypes = [vp, C.c_int, C.POINTER(DecompInfo)]
     L.gv_tune_info.argtypes = [vp, dp, C.POINTER(C.c_int)]
     L.gv_ingest_info.argtypes = [vp, dp, dp]
+    L.gv_ingest_info2.argtypes = [vp, C.POINTER(IngestStats)]
+    L.gv_set_expected_passes.argtypes = [vp, C.c_int64]
+    L.gv_bind_host_numa.argtypes = [C.c_int, C.POINTER(C.c_int)]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.gv_read_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     _LIB = L
@@ -536,6 +553,16 @@ class Shard:
         a, f = C.c_double(), C.c_double()
         self._ck(self.L.gv_ingest_info(self.h, C.byref(a), C.byref(f)))
         return a.value, f.value
+
+    def ingest_stats(self):
+        """gv_ingest_info2 of the last ingest as a dict"""
+        st = IngestStats()
+        self._ck(self.L.gv_ingest_info2(self.h, C.byref(st)))
+        return {"alloc_s": st.alloc_seconds, "fill_s": st.fill_seconds, "overlap_s": st.overlap_seconds,
+                "resident_GB": st.resident_bytes / 1e9, "layout": st.layout, "expected_passes": st.expected_passes}
+
+    def set_expected_passes(self, passes):
+        self._ck(self.L.gv_set_expected_passes(self.h, int(passes)))
 
     def tune_info(self):
         """(seconds spent picking the decompositions, source: 'pending' / 'model' / 'measured' / 'cache' / 'fixed' / 'builtin')"""

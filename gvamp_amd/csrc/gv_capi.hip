@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <condition_variable>
+#include <cctype>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -15,6 +16,7 @@
 #include <utility>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -251,12 +253,18 @@ class CopyPool {
     struct Job { char* dst; const char* src; size_t n; };
     std::vector<std::thread> th;
     std::vector<Job> jobs;
+    std::unique_ptr<std::atomic<int>[]> taken;      // 1: somebody (the helper it was meant for, or the caller) has claimed job i
     std::mutex mu;
     std::condition_variable cv;
     std::atomic<unsigned long> gen{0};
     std::atomic<int> pending{0};
     bool stop = false;
     pid_t owner = 0;
+    void run(int i) {
+        const Job j = jobs[i];
+        if (j.n) memcpy(j.dst, j.src, j.n);
+        pending.fetch_sub(1, std::memory_order_acq_rel);
+    }
     void work(int id) {
         unsigned long seen = 0;
         for (;;) {
@@ -275,9 +283,8 @@ class CopyPool {
             }
             seen = gen.load(std::memory_order_acquire);
             if (stop) return;
-            const Job j = jobs[id];
-            if (j.n) memcpy(j.dst, j.src, j.n);
-            pending.fetch_sub(1, std::memory_order_acq_rel);
+            int expect = 0;
+            if (taken[id].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) run(id);   // else the caller took it
         }
     }
 public:
@@ -286,14 +293,25 @@ public:
         return *p;
     }
     CopyPool() {
+        // helpers = min(3, CPUs this process may run on - 1); none when it has two CPUs or fewer (a cgroup of one core, several
+        // ranks pinned to few cores: the caller would spin on the core its helpers need).  GV_XFER_THREADS overrides (0 = none).
         int n = 3;
+        cpu_set_t cs;
+        if (sched_getaffinity(0, sizeof(cs), &cs) == 0) {
+            const int ncpu = CPU_COUNT(&cs);
+            n = ncpu <= 2 ? 0 : (ncpu - 1 < 3 ? ncpu - 1 : 3);
+        }
         if (const char* e = getenv("GV_XFER_THREADS")) n = atoi(e) < 0 ? 0 : (atoi(e) > 15 ? 15 : atoi(e));
         owner = getpid();
         jobs.assign(n, Job{nullptr, nullptr, 0});
+        taken.reset(new std::atomic<int>[n > 0 ? n : 1]);
+        for (int i = 0; i < n; i++) taken[i].store(1);
         for (int i = 0; i < n; i++) th.emplace_back(&CopyPool::work, this, i);
     }
     // dst <- src, n bytes, shared among the caller and the helpers (below 256 KiB, or in a forked child whose helpers did not
     // survive the fork, the caller copies alone).  Calls are serialised by copy_mu: contexts of several threads share the pool.
+    // The caller never just waits: after its own part it takes over whatever a helper has not claimed yet (a helper that is
+    // descheduled, or gone, cannot stall the call), and yields the core while claimed parts finish.
     std::mutex copy_mu;
     void copy(void* dst, const void* src, size_t n) {
         const int nh = (int)th.size();
@@ -306,15 +324,21 @@ public:
                 const size_t off = per * (size_t)(i + 1);
                 const size_t len = off >= n ? 0 : (i == nh - 1 ? n - off : (off + per > n ? n - off : per));
                 jobs[i] = Job{(char*)dst + off, (const char*)src + off, len};
+                taken[i].store(0, std::memory_order_relaxed);
             }
             pending.store(nh, std::memory_order_release);
             gen.fetch_add(1, std::memory_order_release);
         }
         cv.notify_all();
         memcpy(dst, src, per < n ? per : n);
-        while (pending.load(std::memory_order_acquire) != 0) {
+        for (int i = nh - 1; i >= 0; i--) {      // work stealing, from the far end (the helpers start from their own slots)
+            int expect = 0;
+            if (taken[i].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) run(i);
+        }
+        for (unsigned long spins = 0; pending.load(std::memory_order_acquire) != 0; spins++) {
+            if (spins > 4000) sched_yield();
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+            else __builtin_ia32_pause();
 #endif
         }
     }
@@ -1236,15 +1260,21 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         c->want_tile = pl.layout == 1;
     } else if (c->want_auto && c->want_stripes) {
         // gv_set_layout(.., 3): two stripe sets (the faster ATx, by 2-5 %) when they fit the free HBM with room for the
-        // vectors and scratch, else the one tile layout (half the bytes)
+        // vectors and scratch AND the run is long enough to earn the second set back, else the one tile layout (half the bytes)
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         const double one = (double)((M + 63) / 64) * (double)((c->N + 255) / 256) * 4096.0;
         const double other = (c->want_raw ? (double)M * (double)P : 32768.0 * (double)P) + 64.0 * (double)(M + c->npad) + 2.0e9;
         c->want_tile = 2.0 * one + other > 0.92 * (double)free_b;
+        // Time-aware part (gv_set_expected_passes; 0 = unknown: memory decides alone).  The second stripe set costs its bytes once
+        // more at ingest -- allocated at 25-400 GB/s depending on whether the driver is still wiping freed memory, filled at
+        // ~400 GB/s: 0.5-4.3 s per 100 GB measured -- and returns ~3 % of one ATx pass (bytes / 6.5 TB/s) per pass: break-even
+        // between 500 and 9 000 passes.  Below 1 000 expected passes the one-layout ingest wins the run.
+        if (!c->want_tile && c->expected_passes > 0 && c->expected_passes < 1000) c->want_tile = true;
     }
     const int want_layout = c->want_tile ? 1 : 0;
-    if (c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m))) {
+    const bool rebuild = c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m));
+    if (rebuild) {
         // (re)build the geometry and the buffers of the MFMA family for the layout asked for
         if (c->stripes_slab) {       // the two stripe sets are views into one allocation
             (void)hipFree(c->stripes_slab);
@@ -1255,52 +1285,69 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
                          (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         if (plan_decomps(c)) return 1;
-        const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
-        if (want_layout) {
-            HIPCHK(c, hipMalloc(&pl.tiles, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096));
-        } else {
-            // ONE allocation for the two stripe sets, stripes_n (the Ax side) first.  Where the driver places a 100 GB allocation
-            // moves the kernel that streams it by 1.5-3.5 % (nine ingests on one box, Ax 14.9-15.6 ms and
-            // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
-            // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
-            // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.
-            const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
-                         sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
-            const char* se = getenv("GV_STRIPE_SLAB");
-            void* slab = nullptr;
-            const size_t al = (size_t)1 << 30, off_m = (sz_n + al - 1) / al * al;
-            if (!(se && atoi(se) == 0) && hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
-                c->stripes_slab = slab;
-                pl.stripes_n = slab;
-                pl.stripes_m = (char*)slab + off_m;
-            } else {
-                (void)hipGetLastError();
-                HIPCHK(c, hipMalloc(&pl.stripes_m, sz_m));
-                HIPCHK(c, hipMalloc(&pl.stripes_n, sz_n));
-            }
-        }
-        HIPCHK(c, hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
-        HIPCHK(c, hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096));
-        HIPCHK(c, hipMalloc(&pl.cv, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.ev, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.cv2, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.ev2, sizeof(double) * (M > 0 ? M : 1)));
-        HIPCHK(c, hipMalloc(&pl.scal, sizeof(double) * 8));
-        auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
-            int k = 1;
-            for (const gvm::Decomp& d : cand) {
-                const int p = (int)gvm::pieces_max(d, nkb);
-                if (p > k) k = p;
-            }
-            return k;
-        };
-        const int km = pieces(c->dec_cand_m, pl.nkb_m), kn = pieces(c->dec_cand_n, pl.nkb_n);
-        size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * pl.rows_n * 8 * 4;
-        pl.partial_bytes = pa > pb ? pa : pb;
-        HIPCHK(c, hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4));
     }
-    HIPCHK(c, hipDeviceSynchronize());
-    const auto t_in1 = std::chrono::steady_clock::now();      // the layouts are allocated (the driver maps / wipes 100+ GB)
+    // The allocation of the resident layout -- seconds when the driver is still wiping what an earlier process freed -- runs on a
+    // helper thread while this one gets the source ready: pinned staging buffers, the chunk buffer, and for a file source the
+    // first two chunks read from the file system.  Wall = max(allocate, prepare) instead of their sum (gv_ingest_info2: overlap_s).
+    std::string alloc_err;
+    double alloc_secs = 0.0;
+    auto alloc_layout = [&]() {
+        const auto ta = std::chrono::steady_clock::now();
+        auto A = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && alloc_err.empty()) alloc_err = std::string(what) + ": " + hipGetErrorString(e);
+            return e == hipSuccess;
+        };
+        if (!A(hipSetDevice(c->device), "hipSetDevice")) return;
+        if (rebuild) {
+            const int64_t nkbmax = pl.nkb_m > pl.nkb_n ? pl.nkb_m : pl.nkb_n;
+            if (want_layout) {
+                if (!A(hipMalloc(&pl.tiles, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096), "hipMalloc(tile layout)")) return;
+            } else {
+                // ONE allocation for the two stripe sets, stripes_n (the Ax side) first.  Where the driver places a 100 GB allocation
+                // moves the kernel that streams it by 1.5-3.5 % (nine ingests on one box, Ax 14.9-15.6 ms and
+                // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
+                // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
+                // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.
+                const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
+                             sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
+                const char* se = getenv("GV_STRIPE_SLAB");
+                void* slab = nullptr;
+                const size_t al = (size_t)1 << 30, off_m = (sz_n + al - 1) / al * al;
+                if (!(se && atoi(se) == 0) && hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
+                    c->stripes_slab = slab;
+                    pl.stripes_n = slab;
+                    pl.stripes_m = (char*)slab + off_m;
+                } else {
+                    (void)hipGetLastError();
+                    if (!A(hipMalloc(&pl.stripes_m, sz_m), "hipMalloc(stripes_m)")) return;
+                    if (!A(hipMalloc(&pl.stripes_n, sz_n), "hipMalloc(stripes_n)")) return;
+                }
+            }
+            const size_t Mn = (size_t)(M > 0 ? M : 1);
+            if (!A(hipMalloc(&pl.dig0, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096), "hipMalloc(dig0)")) return;
+            if (!A(hipMalloc(&pl.dig1, (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096), "hipMalloc(dig1)")) return;
+            if (!A(hipMalloc(&pl.cv, sizeof(double) * Mn), "hipMalloc(cv)")) return;
+            if (!A(hipMalloc(&pl.ev, sizeof(double) * Mn), "hipMalloc(ev)")) return;
+            if (!A(hipMalloc(&pl.cv2, sizeof(double) * Mn), "hipMalloc(cv2)")) return;
+            if (!A(hipMalloc(&pl.ev2, sizeof(double) * Mn), "hipMalloc(ev2)")) return;
+            if (!A(hipMalloc(&pl.scal, sizeof(double) * 8), "hipMalloc(scal)")) return;
+            auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
+                int k = 1;
+                for (const gvm::Decomp& d : cand) {
+                    const int p = (int)gvm::pieces_max(d, nkb);
+                    if (p > k) k = p;
+                }
+                return k;
+            };
+            const int km = pieces(c->dec_cand_m, pl.nkb_m), kn = pieces(c->dec_cand_n, pl.nkb_n);
+            size_t pa = (size_t)km * 4 * pl.nrg_m * 64 * 8 * 4, pb = (size_t)kn * 4 * pl.nrg_n * pl.rows_n * 8 * 4;
+            pl.partial_bytes = pa > pb ? pa : pb;
+            if (!A(hipMalloc(&pl.partial, pl.partial_bytes > 0 ? pl.partial_bytes : 4), "hipMalloc(partial sums)")) return;
+        }
+        alloc_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+    };
+    std::thread alloc_thr(alloc_layout);
+    const auto t_prep0 = std::chrono::steady_clock::now();
     const int64_t CH = file ? 8192 : 32768;   // file source: each pinned staging buffer is CH * mbytes bytes
     uint8_t* tmp = nullptr;
     uint8_t* stage[2] = {nullptr, nullptr};
@@ -1317,6 +1364,19 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         const hipError_t e = hipMalloc(&tmp, (size_t)(M < CH ? (M > 0 ? M : 1) : CH) * P);
         if (e != hipSuccess) rc = fail(c, "ingest: no room for the chunk buffer: %s", hipGetErrorString(e));
     }
+    // chunks 0 and 1 of a file come off the file system while the layout is still being allocated
+    int pre_read = 0, pre_io[2] = {0, 0};
+    for (int b = 0; b < 2 && file && !rc && (int64_t)b * CH < M; b++) {
+        const int64_t m0 = (int64_t)b * CH, mc = M - m0 < CH ? M - m0 : CH;
+        pre_io[b] = read_slab(fileno(file), file_off + m0 * c->mbytes, stage[b], (size_t)mc * c->mbytes);
+        pre_read = b + 1;
+    }
+    const double prep_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count();
+    alloc_thr.join();
+    if (!alloc_err.empty() && !rc) rc = fail(c, "ingest: allocating the resident layout failed: %s", alloc_err.c_str());
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "ingest: hipDeviceSynchronize failed");
+    const auto t_in1 = std::chrono::steady_clock::now();      // the layouts are allocated (the driver maps / wipes 100+ GB)
+    c->ingest_overlap_s = alloc_secs < prep_secs ? alloc_secs : prep_secs;
     int64_t chunk = 0;
     for (int64_t m0 = 0; m0 < M && !rc; m0 += CH, chunk++) {
         const int64_t mc = M - m0 < CH ? M - m0 : CH;
@@ -1329,7 +1389,8 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             const uint8_t* src = host_bed ? host_bed + (size_t)m0 * c->mbytes : stage[sb];
             if (file) {
                 if (chunk >= 2) e = hipEventSynchronize(stage_free[sb]);      // the copy of chunk - 2 has left this buffer
-                const int io = e == hipSuccess ? read_slab(fileno(file), file_off + (int64_t)m0 * c->mbytes, stage[sb], (size_t)mc * c->mbytes) : 0;
+                const int io = chunk < pre_read ? pre_io[chunk]               // (read while the layout was being allocated)
+                               : (e == hipSuccess ? read_slab(fileno(file), file_off + (int64_t)m0 * c->mbytes, stage[sb], (size_t)mc * c->mbytes) : 0);
                 if (io) {
                     rc = io < 0 ? fail(c, "ingest: the .bed file ends before marker %lld is complete (short file)", (long long)(c->S + m0 + mc - 1))
                                 : fail(c, "ingest: reading the .bed file at marker %lld failed: %s", (long long)(c->S + m0), strerror(io));
@@ -1363,6 +1424,8 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     }
     if (tmp) (void)hipFree(tmp);
     c->ingest_alloc_s = std::chrono::duration<double>(t_in1 - t_in0).count();
+    c->ingest_bytes = c->want_stripes ? (size_t)(pl.layout == 1 ? 1 : 2) * (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096 : 0;
+    if (c->want_raw) c->ingest_bytes += (size_t)(M > 0 ? M : 1) * P;
     c->ingest_fill_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in1).count();
     if (rc) return rc;
     c->have_raw = c->want_raw;
@@ -1496,7 +1559,8 @@ int gv_vec_fill(gv_ctx* c, gv_vec* v, double value) {
 }
 int gv_vec_copy(gv_ctx* c, gv_vec* dst, const gv_vec* src) {
     NEED(c, dst->space == src->space, "gv_vec_copy: space mismatch");
-    HIPCHK(c, hipMemcpyAsync(dst->d, src->d, sizeof(double) * src->cap, hipMemcpyDeviceToDevice, c->stream));
+    gvk::copy(c->stream, dst->d, src->d, src->cap);      // (a kernel: enqueued in ~3 us where hipMemcpyAsync takes the host 10-15)
+    KCHK(c);
     return 0;
 }
 int gv_vec_axpby(gv_ctx* c, gv_vec* out, double a, const gv_vec* x, double b, const gv_vec* y) {
@@ -1954,6 +2018,64 @@ int gv_get_layout(const gv_ctx* c) { return c->have_stripes ? (c->plan.layout ==
 int gv_ingest_info(gv_ctx* c, double* alloc_seconds, double* fill_seconds) {
     if (alloc_seconds) *alloc_seconds = c->ingest_alloc_s;
     if (fill_seconds) *fill_seconds = c->ingest_fill_s;
+    return 0;
+}
+// The calling thread (and the threads it starts afterwards: the staging-copy helpers, the file readers) is restricted to the CPUs of
+// the NUMA node the GPU hangs off -- /sys/bus/pci/devices/<bus id>/numa_node and /sys/devices/system/node/node<k>/cpulist --
+// intersected with the CPUs it may already run on.  The host-paced sections of a VAMP iteration and the pinned staging copies
+// cross the socket interconnect otherwise (18.9 % idle measured on a box whose host was the far socket).
+int gv_bind_host_numa(int device, int* numa_node_out) {
+    if (numa_node_out) *numa_node_out = -1;
+    if (const char* e = getenv("GVAMP_NUMA_BIND"))
+        if (atoi(e) == 0) return 0;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, "gv_bind_host_numa: no PCI bus id for device %d", device); }
+    for (char* q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+    char path[256];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    int node = -1;
+    if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return 0;                       // a single-node host (or a VM that hides the topology): nothing to do
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return 0;
+    char list[4096] = {0};
+    const bool got = fgets(list, sizeof(list), f) != nullptr;
+    fclose(f);
+    if (!got) return 0;
+    cpu_set_t want, have, both;
+    CPU_ZERO(&want);
+    for (char* q = list; *q;) {                   // "0-15,128-143"
+        char* end = nullptr;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++) CPU_SET((int)k, &want);
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
+    CPU_AND(&both, &want, &have);
+    if (CPU_COUNT(&both) == 0) return 0;          // the launcher pinned this rank elsewhere on purpose: leave it
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) return 0;
+    if (numa_node_out) *numa_node_out = node;
+    return 0;
+}
+int gv_ingest_info2(gv_ctx* c, gv_ingest_stats* out) {
+    NEED(c, out != nullptr, "gv_ingest_info2: out is NULL");
+    out->alloc_seconds = c->ingest_alloc_s;
+    out->fill_seconds = c->ingest_fill_s;
+    out->overlap_seconds = c->ingest_overlap_s;
+    out->resident_bytes = (double)c->ingest_bytes;
+    out->layout = gv_get_layout(c);
+    out->expected_passes = c->expected_passes;
+    return 0;
+}
+int gv_set_expected_passes(gv_ctx* c, int64_t passes) {
+    NEED(c, passes >= 0, "gv_set_expected_passes: passes >= 0 (0 = unknown)");
+    c->expected_passes = passes;
     return 0;
 }
 int gv_tune_info(gv_ctx* c, double* seconds, int* source) {

@@ -54,6 +54,9 @@ struct gv_ctx {
     bool ks_fixed_m = false, ks_fixed_n = false;   // an override fixed the decomposition: nothing to pick
     bool ks_tuned = false;
     double ingest_alloc_s = 0.0, ingest_fill_s = 0.0;   // last ingest: allocating the resident layouts / filling them
+    double ingest_overlap_s = 0.0;  // ... of which the allocation ran beside the preparation of the source (helper thread)
+    size_t ingest_bytes = 0;        // bytes of genotype layouts resident after the last ingest
+    int64_t expected_passes = 0;    // gv_set_expected_passes: 0 = unknown
     double tune_seconds = 0.0;      // wall time the pick cost (0 when it came from the cache)
     int tune_source = 0;            // 0 model's first candidate, 1 measured, 2 cache, 3 fixed by an override / nothing to tune
 
@@ -156,6 +159,7 @@ void arm_publish(double* mailbox, unsigned long long* flag, unsigned long long s
 void disarm_publish();
 void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n);
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad);
+void copy(hipStream_t s, double* dst, const double* src, int64_t n);                  // dst = src (kernel, not hipMemcpyAsync)
 void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n);     // p = fma(beta, p, z)
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
 void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,

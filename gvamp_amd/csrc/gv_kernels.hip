@@ -392,6 +392,10 @@ __global__ void k_axpby(double* out, double a, const double* x, double b, const 
     if (i < n) out[i] = (y ? a * x[i] + b * y[i] : a * x[i]);
 }
 // p = z + beta p (vamp.cpp:1209-1210), one rounding -- the same fma as the device-resident CG (k_prep_ax)
+__global__ void k_vcopy(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
 __global__ void k_p_update(double* p, const double* z, double beta, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = fma(beta, p[i], z[i]);
@@ -1195,6 +1199,12 @@ void axpby(hipStream_t s, double* out, double a, const double* x, double b, cons
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s, out, a, x, b, y, n);
 }
 
+// dst <- src on the stream, as a kernel: a device-to-device hipMemcpyAsync costs the HOST 10-15 us per call on this runtime (the
+// gaps around __amd_rocclr_copyBuffer in profiles/r3_cfg5_gaps.txt: 90 us per VAMP iteration at config 5), a launch ~3
+void copy(hipStream_t s, double* dst, const double* src, int64_t n) {
+    if (n <= 0 || dst == src) return;
+    hipLaunchKernelGGL(k_vcopy, dim3(nblk(n, 256)), dim3(256), 0, s, dst, src, n);
+}
 void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n) {
     if (n <= 0) return;            // an empty shard (M == 0) steps through the solver with empty vectors
     hipLaunchKernelGGL(k_p_update, dim3(nblk(n, 256)), dim3(256), 0, s, p, z, beta, n);

@@ -1142,6 +1142,47 @@ __global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t
 
 __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
 
+// Digit sums of P consecutive planes (p0 ...) of one row over its np pieces.  Four pieces are fetched before any is added: the
+// loads of a piece do not depend on the previous one, but a loop of unknown length waits for each piece in turn -- 25 round trips
+// for a row of the hybrid decomposition's remainder (k_fin_atx_dot took 18 us at M = 200k where its neighbours take 6).
+template <int P>
+__device__ __forceinline__ void gather_pieces(const int32_t* __restrict__ partial, int np, int ppk, int p0, int64_t rows_p, int64_t row,
+                                              long long (&s)[P][7]) {
+#pragma unroll
+    for (int pl = 0; pl < P; pl++)
+#pragma unroll
+        for (int c = 0; c < 7; c++) s[pl][c] = 0;
+    const int64_t pstride = (int64_t)ppk * rows_p * 8;                       // int32 from one piece to the next
+    const int32_t* base = partial + ((int64_t)p0 * rows_p + row) * 8;
+    int ks = 0;
+    for (; ks + 4 <= np; ks += 4) {
+        int4 a[4][P], b[4][P];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int pl = 0; pl < P; pl++) {
+                const int4* q = reinterpret_cast<const int4*>(base + (int64_t)(ks + j) * pstride + (int64_t)pl * rows_p * 8);
+                a[j][pl] = q[0];
+                b[j][pl] = q[1];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int pl = 0; pl < P; pl++) {
+                s[pl][0] += a[j][pl].x; s[pl][1] += a[j][pl].y; s[pl][2] += a[j][pl].z; s[pl][3] += a[j][pl].w;
+                s[pl][4] += b[j][pl].x; s[pl][5] += b[j][pl].y; s[pl][6] += b[j][pl].z;
+            }
+    }
+    for (; ks < np; ks++)
+#pragma unroll
+        for (int pl = 0; pl < P; pl++) {
+            const int4* q = reinterpret_cast<const int4*>(base + (int64_t)ks * pstride + (int64_t)pl * rows_p * 8);
+            const int4 x0 = q[0], x1 = q[1];
+            s[pl][0] += x0.x; s[pl][1] += x0.y; s[pl][2] += x0.z; s[pl][3] += x0.w;
+            s[pl][4] += x1.x; s[pl][5] += x1.y; s[pl][6] += x1.z;
+        }
+}
+
 // The p-value pass (data::pvals_calc, data.cpp:1150-1226; pvals_calc_LOCO, :1290-1353): ONE pass over stripes_m for the two
 // N-vectors p = y_mod and p^2 (MODE 2), and in its epilogue, per marker, the four raw sums
 //   {sum_n a p, sum_n b p, sum_n a p^2, sum_n b p^2}     (a, b of dotp_lut.hpp; no mean / scale / 1/sqrt(N))
@@ -1155,21 +1196,8 @@ __global__ __launch_bounds__(128) void k_fin_pvals(const int32_t* __restrict__ p
     const int64_t m = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (m >= M) return;
     if (a.chrom && a.chrom[m] != a.ch) return;          // LOCO: only the markers of chromosome ch are tested and written
-    ksplit = pieces_of(m, ksplit, nkb, skL, 8, piv);
     long long s[4][7];
-#pragma unroll
-    for (int pl = 0; pl < 4; pl++)
-#pragma unroll
-        for (int c = 0; c < 7; c++) s[pl][c] = 0;
-    for (int ks = 0; ks < ksplit; ks++) {
-#pragma unroll
-        for (int pl = 0; pl < 4; pl++) {
-            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * 4 + pl) * rows_p + m) * 8);
-            int4 x0 = px[0], x1 = px[1];
-            s[pl][0] += x0.x; s[pl][1] += x0.y; s[pl][2] += x0.z; s[pl][3] += x0.w;
-            s[pl][4] += x1.x; s[pl][5] += x1.y; s[pl][6] += x1.z;
-        }
-    }
+    gather_pieces<4>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), 4, 0, rows_p, m, s);
     double s4[4];
 #pragma unroll
     for (int v = 0; v < 2; v++) {
@@ -1205,18 +1233,11 @@ __global__ __launch_bounds__(256) void k_fin_atx(const int32_t* __restrict__ par
     double* __restrict__ out = a.out[v];
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
-    ksplit = pieces_of(m, ksplit, nkb, skL, 8, piv);
-    for (int ks = 0; ks < ksplit; ks++) {
-        const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
-        const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
-        int4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
-        sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
-        sy[0] += y0.x; sy[1] += y0.y; sy[2] += y0.z; sy[3] += y0.w; sy[4] += y1.x; sy[5] += y1.y; sy[6] += y1.z;
-    }
+    long long sxy[2][7];
+    gather_pieces<2>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), ppk, p0, rows_p, m, sxy);
     long long xh, xl, yh, yl;
-    combine(sx, xh, xl);
-    combine(sy, yh, yl);
+    combine(sxy[0], xh, xl);
+    combine(sxy[1], yh, yl);
     const double scale = scal[3], P = scal[1];
     const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
     const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
@@ -1243,18 +1264,11 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
     const double scale = scal[3], P = scal[1];
     double s = 0.0;
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
-        long long sx[7] = {0, 0, 0, 0, 0, 0, 0}, sy[7] = {0, 0, 0, 0, 0, 0, 0};
-        const int np = pieces_of(m, ksplit, nkb, skL, 8, piv);
-        for (int ks = 0; ks < np; ks++) {
-            const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 0) * rows_p + m) * 8);
-            const int4* py = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + p0 + 1) * rows_p + m) * 8);
-            int4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
-            sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
-            sy[0] += y0.x; sy[1] += y0.y; sy[2] += y0.z; sy[3] += y0.w; sy[4] += y1.x; sy[5] += y1.y; sy[6] += y1.z;
-        }
+        long long sxy[2][7];
+        gather_pieces<2>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), ppk, p0, rows_p, m, sxy);
         long long xh, xl, yh, yl;
-        combine(sx, xh, xl);
-        combine(sy, yh, yl);
+        combine(sxy[0], xh, xl);
+        combine(sxy[1], yh, yl);
         const double sa = ((double)(xh - 3 * yh) * 4294967296.0 + (double)(xl - 3 * yl)) * scale;
         const double sm = ((double)yh * 4294967296.0 + (double)yl) * scale;
         const double r = msig[m] * fma(-mave[m], P - sm, sa) * inv_sqrt_n;
@@ -1301,15 +1315,10 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     if (n < npad) {
         const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
         if (present && n < rows_p) {
-            long long sx[7] = {0, 0, 0, 0, 0, 0, 0};
-            ksplit = pieces_of(n, ksplit, nkb, skL, qshift, piv);
-            for (int ks = 0; ks < ksplit; ks++) {
-                const int4* px = reinterpret_cast<const int4*>(partial + (((int64_t)ks * ppk + v) * rows_p + n) * 8);
-                int4 x0 = px[0], x1 = px[1];
-                sx[0] += x0.x; sx[1] += x0.y; sx[2] += x0.z; sx[3] += x0.w; sx[4] += x1.x; sx[5] += x1.y; sx[6] += x1.z;
-            }
+            long long sx[1][7];
+            gather_pieces<1>(partial, pieces_of(n, ksplit, nkb, skL, qshift, piv), ppk, v, rows_p, n, sx);
             long long xh, xl;
-            combine(sx, xh, xl);
+            combine(sx[0], xh, xl);
             const double T = ((double)xh * 4294967296.0 + (double)xl) * scal[3];
             val = (T - scal[1]) * post;
         }

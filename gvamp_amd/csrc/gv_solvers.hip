@@ -80,7 +80,7 @@ static int cg_finish_init(gv_ctx* c, CgSys& s, double diag, bool multi) {
     if (multi && allreduce_scalars(c, pk, 2)) return 1;
     s.rz = pk[0];
     s.norm_v = sqrt(pk[1]);
-    HIPCHK(c, hipMemcpyAsync(s.p, s.z, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+    gvk::copy(c->stream, s.p, s.z, M);
     s.phase = 1;
     s.req = s.p;
     s.res = s.d;
@@ -101,7 +101,7 @@ static int cg_consume_all(gv_ctx* c, CgSys** act, int na, double gam2, double di
         CgSys& s = *act[k];
         if (s.phase == 0) {                                               // r = v - Q mu0 (:1142-1145)
             gvk::axpby(st, s.r, 1.0, s.v, -1.0, s.r, M);
-            if (s.az) HIPCHK(c, hipMemcpyAsync(s.az, s.wslot, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, st));   // A mu0
+            if (s.az) gvk::copy(st, s.az, s.wslot, c->npad);   // A mu0
             KCHK(c);
             if (cg_finish_init(c, s, diag, multi)) return 1;
             if (max_iter <= 0) s.active = false;
@@ -516,22 +516,22 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
         if (s.mu0 && s.ata0) {
             // r = v - Q mu0 with A^T A mu0 handed in by the caller (the previous solve left it: Q' mu0 = v' - r'), so the
             // initial residual of a warm start (vamp.cpp:1142-1145) costs no pass over the shard
-            HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            gvk::copy(c->stream, s.mu, s.mu0, M);
             gvk::axpby(c->stream, s.r, 1.0, s.v, -tau, s.ata0, M);
             gvk::axpby(c->stream, s.r, 1.0, s.r, -gam2, s.mu0, M);
             if (s.az && s.amu0 != s.az)
-                HIPCHK(c, hipMemcpyAsync(s.az, s.amu0, sizeof(double) * c->npad, hipMemcpyDeviceToDevice, c->stream));   // A mu0
+                gvk::copy(c->stream, s.az, s.amu0, c->npad);   // A mu0
             KCHK(c);
             if (cg_finish_init(c, s, diag, multi)) return 1;
         } else if (s.mu0) {
-            HIPCHK(c, hipMemcpyAsync(s.mu, s.mu0, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            gvk::copy(c->stream, s.mu, s.mu0, M);
             s.phase = 0;
             s.req = s.mu;
             s.res = s.r;
         } else {
             gvk::fill(c->stream, s.mu, M, 0.0);
             if (s.az) gvk::fill(c->stream, s.az, c->npad, 0.0);
-            HIPCHK(c, hipMemcpyAsync(s.r, s.v, sizeof(double) * M, hipMemcpyDeviceToDevice, c->stream));
+            gvk::copy(c->stream, s.r, s.v, M);
             if (cg_finish_init(c, s, diag, multi)) return 1;
         }
         if (max_iter <= 0 && s.phase == 1) s.active = false;
@@ -775,16 +775,16 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
     {
         gvk::aat_diag(s, c->mave_p->d, c->msig_p->d, c->numb_p->d, tau, gam2, (double)c->N, n, DG->d);
         if (mu_start) {
-            AAT_HIP(hipMemcpyAsync(mu, mu_start->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            gvk::copy(s, mu, mu_start->d, n);
             AAT_TRY(lmmse_aat_device(c, mu, tau, gam2, tmpM, r));
             gvk::axpby(s, r, 1.0, v->d, -1.0, r, n);                       // r = v - Q mu (:71-73)
         } else {
             gvk::fill(s, mu, n, 0.0);
-            AAT_HIP(hipMemcpyAsync(r, v->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+            gvk::copy(s, r, v->d, n);
         }
         double rz, vn2;
         AAT_TRY(aat_init_scalars(c, r, d, DG->d, z, v->d, &rz, &vn2));      // z = r / diag (:76-77), <r,z>, ||v||^2
-        AAT_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        gvk::copy(s, p, z, n);
         if (cgx_usable(c) && max_iter > 0) {      // scalars on the device, one read-back per step
             AAT_TRY(cgx_alloc(c, max_iter));
             AAT_TRY(cgx_upload_state(c, 0, rz, vn2, 1, true));
@@ -945,7 +945,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         sb.denoiser = 0; sb.relres = relres_b;
         sb.keep_resid = ata_mu_b != nullptr;
         gvk::fill(s, sb.mu, M, 0.0);
-        MIX_HIP(hipMemcpyAsync(sb.r, sb.v, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+        gvk::copy(s, sb.r, sb.v, M);
         if (wm->ata_v_b) { sb.ata_v = wm->ata_v_b->d; sb.ata_v_known = wm->have_ata_v_b != 0; }
         if (dev && !multi && M > 0) {
             // One rank, scalars on the device: nothing of the opening needs the host.  z = r / diag with <r,z> and ||v||^2 stay
@@ -956,7 +956,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
             gvk::cg_step_b(s, sb.r, sb.d, 0.0, diag_b, sb.z, sb.mu, M, c->red_partial, nullptr);
             const double* vv[1] = {sb.v};
             gvk::dots(s, 1, vv, vv, M, c->red_partial + 4 * RED_BLOCKS, nullptr);
-            MIX_HIP(hipMemcpyAsync(sb.p, sb.z, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+            gvk::copy(s, sb.p, sb.z, M);
             sb.phase = 1; sb.req = sb.p; sb.res = sb.d;
             double q[gvm::ST_SIZE];
             for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
@@ -1012,7 +1012,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 if (hipGetLastError() != hipSuccess) return 1;
             } else if (aat_init_scalars(c, r, d, DG->d, z, v_a->d, &a_rz, &a_vn2))
                 return 1;
-            if (hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+            gvk::copy(s, p, z, n);
             return 0;
         };
         auto a_post = [&](const double* src, double* dst) {   // request Q_A src -> dst
@@ -1027,7 +1027,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         if (at_acc) {
             if (wm->at_mu_start_a) {
                 if (wm->at_mu_start_a->d != at_acc)
-                    MIX_HIP(hipMemcpyAsync(at_acc, wm->at_mu_start_a->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+                    gvk::copy(s, at_acc, wm->at_mu_start_a->d, M);
             } else if (!mu_start_a)
                 gvk::fill(s, at_acc, M, 0.0);
             // (explicit warm start: the first half of its opening application is A^T mu0 -- copied when it arrives, below)
@@ -1036,19 +1036,19 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
         auto a_start = [&]() -> int {
             if (mu_start_a && aat_mu_start_a) {
                 // r = v - (tau A A^T mu0 + gam2 mu0) from the product the previous solve left (Q' mu0 = v' - r'): no pass
-                if (hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                gvk::copy(s, mu, mu_start_a->d, n);
                 gvk::axpby(s, r, 1.0, v_a->d, -tau, aat_mu_start_a->d, n);
                 gvk::axpby(s, r, 1.0, r, -gam2, mu_start_a->d, n);
                 if (a_init_scalars()) return 1;
                 a_phase = 1;
                 if (max_iter > 0) a_post(p, d); else a_finish();
             } else if (mu_start_a) {
-                if (hipMemcpyAsync(mu, mu_start_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                gvk::copy(s, mu, mu_start_a->d, n);
                 a_phase = 0;
                 a_post(mu, r);
             } else {
                 gvk::fill(s, mu, n, 0.0);
-                if (hipMemcpyAsync(r, v_a->d, sizeof(double) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                gvk::copy(s, r, v_a->d, n);
                 if (a_init_scalars()) return 1;
                 a_phase = 1;
                 if (max_iter > 0) a_post(p, d); else a_finish();
@@ -1269,7 +1269,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 HalfOp* h = todo[k];
                 if (h->stage == 0 && !h->one_half) {                               // second half still to come
                     if (h == &ha && a_phase == 0 && at_acc)                         // A^T mu0 of an explicit warm start
-                        MIX_HIP(hipMemcpyAsync(at_acc, MA->d, sizeof(double) * M, hipMemcpyDeviceToDevice, s));
+                        gvk::copy(s, at_acc, MA->d, M);
                     h->stage = 1;
                     continue;
                 }

@@ -49,6 +49,7 @@ std::vector<std::string> split_ws(const std::string& line) {
 
 void data::open_device(int device, int kernel_mode) {
     if (device < 0) device = gv_env_local_rank();
+    if (gv_env_nranks() > 1) (void)gv_bind_host_numa(device, nullptr);   // one process per GPU: stay on the CPUs next to it
     if (gv_create(device, &ctx)) die(std::string("FATAL: ") + gv_last_error(nullptr));
     ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
     // kernel mode 1: two stripe sets (1), the single tile layout (2: half the HBM, same bits), or -- the default, 3 -- two stripe
@@ -57,6 +58,7 @@ void data::open_device(int device, int kernel_mode) {
     const int stripes = kernel_mode != 0 ? ((lay && atoi(lay) >= 1 && atoi(lay) <= 3) ? atoi(lay) : 3) : 0;
     ck(ctx, gv_set_layout(ctx, kernel_mode == 0, stripes), "gv_set_layout");
     ck(ctx, gv_set_kernel_mode(ctx, kernel_mode), "gv_set_kernel_mode");
+    if (const char* ep = getenv("GVAMP_EXPECTED_PASSES")) ck(ctx, gv_set_expected_passes(ctx, atoll(ep) > 0 ? atoll(ep) : 0), "gv_set_expected_passes");
     if (kernel_mode == 0 && rank == 0)
         std::cerr << "WARNING: --kernel-mode 0 selects the fp64 VALU kernels (parity anchor, 4-9 % of the HBM roofline): "
                      "expect Ax / ATx 10-20x slower than the default --kernel-mode 1" << std::endl;
@@ -90,35 +92,15 @@ gv_ctx* gv_host_world(int device) {
         return g_world;
     }
     if (kind && strcmp(kind, "rccl") != 0) die(std::string("FATAL: GVAMP_COMM must be rccl (default) or host, not ") + kind);
-    // one process per GPU: rank 0 publishes the RCCL unique id through a file.  Its name is private to the job: the launcher's
-    // $GVAMP_RENDEZVOUS, else /tmp/gvamp_rccl_id.<MASTER_PORT>.<pid of the launcher> (all ranks are children of one launcher)
-    const char* rdv = getenv("GVAMP_RENDEZVOUS");
-    std::string path = rdv ? rdv : "/tmp/gvamp_rccl_id";
-    path += "." + std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
-    if (!rdv) path += "." + std::to_string((long)getppid());
+    // one process per GPU: rank 0 publishes the RCCL unique id through a file whose name is private to the job -- the launcher's
+    // $GVAMP_RENDEZVOUS, else derived from the launcher's job id (gvh_job_key: torchrun / Slurm / PMIx ids first, the parent's
+    // pid only as the last resort)
+    const std::string path = gvh_id_file_default();
     unsigned char id[128];
-    if (rank == 0) {
-        ck(nullptr, gv_comm_unique_id(id), "gv_comm_unique_id");
-        std::string tmp = path + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, 128, f) != 128) die("FATAL: cannot write " + tmp);
-        fclose(f);
-        rename(tmp.c_str(), path.c_str());
-    } else {
-        // a file left behind by a run that died before rank 0 removed it must not be taken for this run's id: only a
-        // file written after this process started (minus a launch skew of 30 s) counts
-        const time_t born = time(nullptr) - 30;
-        FILE* f = nullptr;
-        for (int tries = 0; tries < 6000 && !f; tries++) {
-            struct stat sb;
-            if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= born) f = fopen(path.c_str(), "rb");
-            if (!f) {
-                struct timespec ts = {0, 10000000};
-                nanosleep(&ts, nullptr);
-            }
-        }
-        if (!f || fread(id, 1, 128, f) != 128) die("FATAL: cannot read " + path);
-        fclose(f);
+    if (rank == 0) ck(nullptr, gv_comm_unique_id(id), "gv_comm_unique_id");
+    {
+        std::string err;
+        if (gvh_exchange_id_impl(path, rank, id, 60.0, err)) die("FATAL: " + err);
     }
     ck(g_world, gv_comm_init(g_world, nranks, rank, id), "gv_comm_init");   // returns after a collective: every rank has the id
     if (rank == 0) remove(path.c_str());

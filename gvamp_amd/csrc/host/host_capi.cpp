@@ -134,4 +134,17 @@ int gvh_shm_open(const char* name, int nranks, int rank, size_t cap_doubles, gvh
 }
 void gvh_shm_close(gvh_shm_comm* comm) { gvh_shm_close_impl(comm); }
 
+// the rendezvous of the RCCL drivers without RCCL (tests): the job key the ranks derive, and the id file exchange
+const char* gvh_job_key_c(void) {
+    static thread_local std::string k;
+    k = gvh_job_key();
+    return k.c_str();
+}
+int gvh_exchange_id(const char* path_or_null, int rank, unsigned char* id128, double timeout_s) {
+    std::string err;
+    const int rc = gvh_exchange_id_impl(path_or_null ? std::string(path_or_null) : gvh_id_file_default(), rank, id128, timeout_s, err);
+    if (rc) g_host_err = err;
+    return rc;
+}
+
 }  // extern "C"

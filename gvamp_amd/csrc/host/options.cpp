@@ -137,6 +137,10 @@ void Options::read_command_line_options(int argc, char** argv) {
         ss << argv[i - 1] << " " << arg << "\n";
     }
     if (rank_for_printing() == 0) std::cout << ss.str() << std::endl;
+    // [ext] what --resident-layout 3 (auto) may assume about the length of the run: every data object of the process tells the
+    // library to expect about 12 ATx passes per VAMP iteration (4-40 in the runs measured), gv_set_expected_passes -- below 1 000 passes a
+    // second stripe set does not earn its allocation back and auto takes the one tile layout.  $GVAMP_EXPECTED_PASSES overrides.
+    if (!getenv("GVAMP_EXPECTED_PASSES")) setenv("GVAMP_EXPECTED_PASSES", std::to_string((long long)iterations * 12).c_str(), 1);
 }
 
 void Options::list_phen_files() const {

@@ -17,6 +17,13 @@ gvh_shm_comm* gvh_shm_open_impl(const std::string& name, int nranks, int rank, s
 // in-place SUM of n doubles over the ranks; 0 = ok.  Signature of gv_allreduce_fn (user = the communicator).
 extern "C" int gvh_shm_allreduce(void* comm, double* buf, size_t n);
 void gvh_shm_close_impl(gvh_shm_comm* c);
-// segment name of this job: from $GVAMP_RENDEZVOUS when set (launchers hand every job a fresh one), else from MASTER_PORT and
-// the launcher's pid (all ranks of a job are children of one launcher)
+// What the ranks of one job agree on without talking: $GVAMP_RENDEZVOUS when set (launchers hand every job a fresh one), else the
+// job id of the launcher (TORCHELASTIC_RUN_ID, SLURM_JOB_ID + SLURM_STEP_ID, PMIX_NAMESPACE, PMI_JOBID, OMPI jobid) with
+// MASTER_ADDR:MASTER_PORT, and only as the last resort MASTER_PORT + the parent's pid (ranks must then be direct children of one
+// launcher).  The RCCL id file of host/data.cpp and the segment name below are both derived from it.
+std::string gvh_job_key();
 std::string gvh_shm_default_name();
+// The 128-byte RCCL unique id from rank 0 to the other ranks through a file: rank 0 writes id128 (atomically: tmp + rename), the
+// others poll for a file of this job (written after they started) and read it into id128.  0 = ok; err names the path and the key.
+std::string gvh_id_file_default();
+int gvh_exchange_id_impl(const std::string& path, int rank, unsigned char* id128, double timeout_s, std::string& err);

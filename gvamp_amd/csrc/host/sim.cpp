@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
             gv_set_layout(synth_ctx, opt.get_kernel_mode() == 0,
                           opt.get_kernel_mode() != 0 ? ((opt.get_resident_layout() >= 1 && opt.get_resident_layout() <= 3) ? opt.get_resident_layout() : 3) : 0) ||
             gv_set_kernel_mode(synth_ctx, opt.get_kernel_mode()) ||
+            gv_set_expected_passes(synth_ctx, (int64_t)opt.get_iterations() * 12) ||
             gv_synth_bed(synth_ctx, (uint64_t)opt.get_synth_seed(), opt.get_synth_miss_ppm())) {
             std::cout << "FATAL: " << gv_last_error(synth_ctx) << std::endl;
             return EXIT_FAILURE;

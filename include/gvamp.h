@@ -88,6 +88,17 @@ int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0
 /* kernel family for Ax/ATx: 1 (default) = i8 MFMA fixed-point kernels on the re-encoded layout (0.8 of the HBM roofline,
  * results within 2e-14 of fp64 sums, bit-reproducible); 0 = fp64 VALU kernels on the raw rows (parity anchor, 4-9 % of the
  * roofline; needs gv_set_layout(ctx, 1, ..) before ingest). */
+/* Accuracy contract of kernel mode 1.  A vector enters a product in fixed point with ONE exponent for the whole vector
+ * (|q| < 2^54 relative to its largest entry); the product itself is exact integer arithmetic with one final rounding.  Hence
+ *   Ax : |out[n] - exact[n]| <= M * 2^-50 * max_i |msig[i] x[i]| / sqrt(N),
+ *   ATx: |out[m] - exact[m]| <= N * 2^-50 * msig[m] * max_n |p[n]| / sqrt(N)
+ * (worst case; typical errors are sqrt(M) resp. sqrt(N) times smaller), i.e. an ABSOLUTE error relative to the vector's largest
+ * entry -- below the error of fp64 summation in relative l2 (measured <= 2e-14 against the fp64 oracle over 60 decades of overall
+ * scale), but not relative to each output entry: an entry more than 2^54 below the vector's maximum is flushed to zero, and an
+ * output that does not see the large entries (Ax at an individual whose genotype is MISSING at the one marker carrying a huge
+ * effect) is accurate to the bound above, not to its own last bits as the reference's fp64 sums are there.  The vectors of a VAMP
+ * run span a few decades and never come near this; input with more than ~2^40 of dynamic range that needs per-entry relative
+ * accuracy should use kernel mode 0.  tests/test_gpu_matvec.py asserts both bounds on such input. */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);
 int gv_get_kernel_mode(const gv_ctx* ctx);
 
@@ -315,6 +326,11 @@ int gv_comm_share(gv_ctx* ctx, const gv_ctx* owner);
  * message after the whole pass (default; also set by the environment variable GV_OVERLAP).  Bit-identical results. */
 int gv_set_overlap(gv_ctx* ctx, int tiles);
 int gv_comm_rank(const gv_ctx* ctx);
+/* One process per GPU on a multi-socket node: restricts the calling thread -- and every thread it starts afterwards -- to the
+ * CPUs of the NUMA node `device` hangs off (sysfs: the PCI device's numa_node, the node's cpulist), intersected with the CPUs it
+ * may already use.  *numa_node_out (may be NULL) = that node, or -1 when nothing was changed (single-node host, topology hidden,
+ * no CPU in common, GVAMP_NUMA_BIND=0).  Call it before the first gv_create of the process; the drivers and bench.py do. */
+int gv_bind_host_numa(int device, int* numa_node_out);
 int gv_comm_size(const gv_ctx* ctx);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
@@ -349,6 +365,22 @@ typedef struct {
 /* Wall time of the last ingest (gv_upload_bed / gv_upload_bed_file / gv_synth_bed), split into allocating the resident
  * layouts (hipMalloc of 100+ GB: the driver maps and wipes the pages; 0 when the buffers were reused) and filling them. */
 int gv_ingest_info(gv_ctx* ctx, double* alloc_seconds, double* fill_seconds);
+/* The same and more.  alloc_seconds = wall time until the resident layout was allocated AND the source prepared (the allocation
+ * runs on a helper thread beside the pinned staging buffers, the chunk buffer and, for gv_upload_bed_file, the first two chunks
+ * read from the file); overlap_seconds = how much of the allocation that preparation hid (wall = max, not sum). */
+typedef struct {
+    double alloc_seconds, fill_seconds, overlap_seconds;
+    double resident_bytes;       /* genotype bytes resident after the ingest (one or two re-encoded layouts, raw rows if asked for) */
+    int layout;                  /* gv_get_layout */
+    int64_t expected_passes;     /* what gv_set_expected_passes said (0 = unknown) */
+} gv_ingest_stats;
+int gv_ingest_info2(gv_ctx* ctx, gv_ingest_stats* out);
+/* Hint for gv_set_layout(.., 3) (auto), to be given before the ingest: how many ATx passes over the shard the caller expects to
+ * make (a VAMP run: iterations x CG steps; 0 = unknown).  The second stripe set of layout 1 costs its bytes once more at ingest
+ * (0.5-4.3 s per 100 GB, depending on whether the driver is still wiping freed memory) and makes every ATx pass ~3 % faster: it
+ * pays for itself after 500-9 000 passes.  With a hint below 1 000, auto takes the one tile layout even when two sets would fit;
+ * with 0 or >= 1 000 memory decides alone, as before.  The drivers pass iterations x 12. */
+int gv_set_expected_passes(gv_ctx* ctx, int64_t passes);
 int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
 /* Pins the decomposition of class cls (0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax), e.g. one a deployment measured itself:
  * `tuned` is ignored, balanced_cells > 0 selects a balanced / hybrid grid (ks unused), else a uniform split of ks segments with

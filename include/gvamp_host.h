@@ -72,6 +72,13 @@ typedef struct gvh_shm_comm gvh_shm_comm;
 int gvh_shm_open(const char* name, int nranks, int rank, size_t cap_doubles, gvh_shm_comm** out);
 int gvh_shm_allreduce(void* comm, double* buf, size_t n);
 void gvh_shm_close(gvh_shm_comm* comm);
+/* The rendezvous of the RCCL drivers (host/data.cpp: gv_host_world), exposed so that it can be exercised without RCCL: the key the
+ * ranks of one job derive from their environment ($GVAMP_RENDEZVOUS, else the launcher's job id -- TORCHELASTIC_RUN_ID,
+ * SLURM_JOB_ID.SLURM_STEP_ID, PMIX_NAMESPACE, PMI_JOBID, OpenMPI's jobid -- with MASTER_ADDR:MASTER_PORT, else the parent's pid), and
+ * the exchange of the 128-byte communicator id through a file (path NULL: the job's default): rank 0 writes id128, the others
+ * receive it; 0 = ok, else gvh_last_error names the path and the key. */
+const char* gvh_job_key_c(void);
+int gvh_exchange_id(const char* path_or_null, int rank, unsigned char* id128, double timeout_s);
 
 #ifdef __cplusplus
 }

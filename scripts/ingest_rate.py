@@ -38,16 +38,18 @@ with open(path, "wb") as f:
 t_write = time.perf_counter() - t0
 out = {"N": N, "M": M, "file_bytes": os.path.getsize(path), "dir": where, "write_file_s": round(t_write, 2), "source": "page cache"}
 try:
-    for name, stripes in (("two_stripe_sets", 1), ("tile_layout", 2)):
+    for name, stripes, passes in (("two_stripe_sets", 1, 0), ("tile_layout", 2, 0), ("auto_short_run_60_passes", 3, 60)):
         best = None
         for rep in range(2):
             with capi.Shard(N, M) as sh:
                 sh.set_layout(False, stripes)
+                sh.set_expected_passes(passes)
                 sh.set_kernel_mode(1)
                 t = time.perf_counter()
                 sh.upload_bed_file(path)
                 sh.synchronize()
                 dt = time.perf_counter() - t
+                st_ = sh.ingest_stats()
                 t = time.perf_counter()
                 sh.compute_markers_statistics()
                 sh.synchronize()
@@ -55,9 +57,15 @@ try:
                 if rep == 0:
                     x = np.random.default_rng(0).standard_normal(M)
                     chk = float(np.linalg.norm(sh.Ax(x)))
-            best = dt if best is None or dt < best else best
-        out[name] = {"ingest_s": round(best, 3), "GBps": round(M * mb / best / 1e9, 2), "stats_s": round(ts, 4), "norm_Ax": chk}
-    assert out["two_stripe_sets"]["norm_Ax"] == out["tile_layout"]["norm_Ax"]      # the same matrix, bit for bit
+            if best is None or dt < best:
+                best, best_st = dt, st_
+        # ingest_s is the whole call: allocation of the resident layout (on a helper thread beside the first file reads), file ->
+        # pinned staging -> PCIe -> re-encoding
+        out[name] = {"ingest_s": round(best, 3), "GBps": round(M * mb / best / 1e9, 2), "stats_s": round(ts, 4), "norm_Ax": chk,
+                     "alloc_s": round(best_st["alloc_s"], 3), "fill_s": round(best_st["fill_s"], 3), "overlap_s": round(best_st["overlap_s"], 3),
+                     "layout": best_st["layout"], "resident_GB": round(best_st["resident_GB"], 2)}
+    assert out["two_stripe_sets"]["norm_Ax"] == out["tile_layout"]["norm_Ax"] == out["auto_short_run_60_passes"]["norm_Ax"]   # the same matrix, bit for bit
+    assert out["auto_short_run_60_passes"]["layout"] == 2
 finally:
     os.remove(path)
 print(json.dumps(out))

@@ -3,6 +3,7 @@ gv_lmmse_mult and gv_prior_estep against the oracle, unfiltered phenotypes (DBL_
 gv_atx / the p-value entry points, non-finite vector entries, work-vector allocation, the --kernel-mode 0 warning."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -414,3 +415,58 @@ def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
                 os.environ.pop("GV_ESTEP_LDS", None)
     assert out[0].shape == (1 + 2 * (L - 1),) and np.all(np.isfinite(out[0]))
     assert [float(v).hex() for v in out[0]] == [float(v).hex() for v in out[1]]
+
+
+def test_auto_layout_weighs_the_length_of_the_run_and_ingest_reports_its_parts(tmp_path):
+    """gv_set_expected_passes: with the automatic layout a short run (< 1000 ATx passes) takes the one tile layout -- half the bytes
+    to allocate and fill -- although two stripe sets would fit; an unknown or long run keeps the two sets; an explicit layout is
+    never overruled; results are the same bits either way.  gv_ingest_info2: the allocation of the resident layout runs beside the
+    preparation of the source (a file: the pinned staging buffers and the first two chunks), and what that hid is reported."""
+    N, M = 4101, 20000
+    bed = synth.synth_bed(N, M, seed=9, miss_ppm=5000)
+    path = str(tmp_path / "g.bed")
+    synth.write_bed(path, bed)
+    x = np.random.default_rng(1).standard_normal(M)
+    got = {}
+    for name, lay, passes in (("unknown", 3, 0), ("short", 3, 60), ("long", 3, 5000), ("explicit", 1, 60)):
+        with capi.Shard(N, M) as sh:
+            sh.set_layout(False, lay)
+            sh.set_expected_passes(passes)
+            sh.upload_bed_file(path, offset=3)
+            st = sh.ingest_stats()
+            sh.compute_markers_statistics()
+            got[name] = (sh.get_layout(), sh.Ax(x), st)
+    assert [got[k][0] for k in ("unknown", "short", "long", "explicit")] == [1, 2, 1, 1]
+    for k in ("short", "long", "explicit"):
+        assert np.array_equal(got[k][1], got["unknown"][1])
+    mb = (N + 3) // 4
+    for k, (lay, _, st) in got.items():
+        assert st["layout"] == lay and st["alloc_s"] >= st["overlap_s"] >= 0.0 and st["fill_s"] > 0.0
+        assert st["resident_GB"] * 1e9 >= (1 if lay == 2 else 2) * M * mb        # (padded to whole 4 KiB blocks)
+    assert got["short"][2]["resident_GB"] < 0.6 * got["unknown"][2]["resident_GB"]
+    assert got["short"][2]["expected_passes"] == 60
+    with capi.Shard(N, M) as sh:
+        with pytest.raises(capi.GvError, match="passes >= 0"):
+            sh.set_expected_passes(-1)
+
+
+def test_bind_host_numa_keeps_a_usable_affinity():
+    """gv_bind_host_numa (one process per GPU on a multi-socket node): in a child process, so that the test runner keeps its own
+    CPUs.  On a single-node host it changes nothing and says so (-1); where it binds, the node's CPUs are a subset of what the
+    process had, and the library still works from there."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from gvamp_amd import capi, synth\n"
+            "before = os.sched_getaffinity(0)\n"
+            "node = capi.bind_host_numa(0)\n"
+            "after = os.sched_getaffinity(0)\n"
+            "assert after and after <= before, (before, after)\n"
+            "assert node >= -1 and (node >= 0 or after == before)\n"
+            "os.environ['GVAMP_NUMA_BIND'] = '0'\n"
+            "assert capi.bind_host_numa(0) == -1\n"
+            "with capi.Shard(300, 64) as sh:\n"
+            "    sh.upload_bed(synth.synth_bed(300, 64, seed=1)); sh.compute_markers_statistics()\n"
+            "    assert np.isfinite(sh.Ax(np.ones(64))).all()\n"
+            "print('node', node, len(before), len(after))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-600:]

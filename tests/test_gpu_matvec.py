@@ -102,6 +102,57 @@ def test_mfma_fixed_point_dynamic_range(oracle, scale):
         assert np.all(sh.Ax(np.zeros(M)) == 0) and np.all(sh.ATx(np.zeros(p.size)) == 0)
 
 
+def test_fixed_point_per_entry_bound_on_adversarial_dynamic_range(oracle):
+    """The documented accuracy contract of kernel mode 1 (include/gvamp.h, gv_set_kernel_mode): ONE exponent per vector, so every
+    output entry carries an ABSOLUTE error proportional to the vector's largest entry -- not to the output entry itself.
+      Ax : |out_n - exact_n| <= M * 2^-50 * max_i |msig_i x_i| / sqrt(N)
+      ATx: |out_m - exact_m| <= N * 2^-50 * msig_m * max_n |p_n| / sqrt(N)
+    Adversarial case for Ax: x with one entry 2^45 above the rest, on a marker with missing genotypes.  At the individuals whose
+    genotype is missing there the exact product does not see the huge entry at all (the reference's table gives those terms an exact
+    0, data.cpp:951-988), while the fixed-point product carries the quantisation of the other entries at the scale of the huge one:
+    the bound holds, and the error relative to the entry's OWN magnitude is far above fp64's -- measured and asserted here so that
+    the deviation stays on record (kernel mode 0 is the remedy for such input).  Same for ATx with one huge individual, seen from a
+    monomorphic marker whose exact output is 0."""
+    N, M = 4000, 600
+    rng = np.random.default_rng(5)
+    bed = synth.synth_bed(N, M, seed=31, miss_ppm=20000).reshape(M, N // 4).copy()
+    bed[7, :] = 0x00                                    # marker 7: monomorphic (every genotype a = 2, none missing)
+    bed = bed.reshape(-1)
+    codes = (bed.reshape(M, N // 4)[:, :, None] >> (2 * np.arange(4))) & 3
+    codes = codes.reshape(M, N)
+    j = 11
+    miss_j = codes[j] == 1                              # PLINK 01 = missing
+    assert miss_j.sum() >= 20
+    with capi.Shard(N, M, anchor=True) as sh:           # raw rows too: the fp64 family is evaluated on the same context
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        mave, msig = sh.marker_stats()
+        x = rng.standard_normal(M)
+        x[j] = 2.0 ** 45
+        ref = oracle.ax(bed, N, M, mave, msig, x)[:N]
+        sh.set_kernel_mode(0)
+        z0 = sh.Ax(x)[:N]
+        sh.set_kernel_mode(1)
+        z1 = sh.Ax(x)[:N]
+        bound = M * 2.0 ** -50 * np.max(np.abs(msig * x)) / np.sqrt(N)
+        err = np.abs(z1 - ref)
+        assert err.max() <= bound, (err.max(), bound)
+        # individuals that see the huge entry: fp64-class relative accuracy; those that do not: only the absolute bound
+        assert np.max(err[~miss_j] / np.abs(ref[~miss_j])) < 1e-12
+        rel_blind = np.max(err[miss_j] / np.abs(ref[miss_j]))
+        assert 1e-9 < rel_blind, rel_blind               # (the deviation is real: an entry's own magnitude is not the yardstick)
+        assert np.max(np.abs(z0 - ref)[miss_j] / np.abs(ref[miss_j])) < 1e-11      # the fp64 family has no such floor
+        # ATx: one individual 2^45 above the rest; the monomorphic marker's exact output is 0
+        p = np.zeros(4 * (N // 4))
+        p[:N] = rng.standard_normal(N)
+        p[123] = 2.0 ** 45
+        refT = oracle.atx(bed, N, M, mave, msig, p)
+        w1 = sh.ATx(p)
+        boundT = N * 2.0 ** -50 * msig * np.max(np.abs(p)) / np.sqrt(N)
+        assert np.all(np.abs(w1 - refT) <= boundT), np.max(np.abs(w1 - refT) / boundT)
+        assert abs(w1[7]) <= boundT[7] and abs(refT[7]) <= boundT[7]     # (the reference's own fp64 sums do not give an exact 0 either)
+
+
 @pytest.mark.parametrize("anchor", [False, True])
 def test_monomorphic_and_all_missing_markers(oracle, anchor):
     """Guards of data.cpp:462-483: sumb == 0 -> mave 0; sumsqr == 0 -> msig 1 (statistics from the re-encoded layout of the
