@@ -625,7 +625,6 @@ int autotune_ks(gv_ctx* c) {
         for (const gvm::Decomp& cd : cand) any_plain |= cd.skL <= 0 && cd.prio == 0;
         for (const gvm::Decomp& cd : cand) {
             if (cd.skL <= 0 && cd.prio != 0 && cd.geo == 0.f && any_plain) continue;
-            if (cd.geo > 0.f && !getenv("GV_TUNE_GEO")) continue;     // (listed so that the partial-sum buffer has room: gv_set_decomp)
             if (consider(cd)) { d = cand[0]; KCHK(c); return done(1); }
         }
         // stage B on the winner: priority, then taper
@@ -1006,7 +1005,7 @@ static int plan_decomps(gv_ctx* c) {
         h.ks = 1; h.skL = L; h.piv = piv; h.prio = 1;
         return h;
     };
-    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, int64_t rows, bool balanced_ok, int64_t min_ks_u, std::vector<gvm::Decomp>& out) {
+    auto build = [&](const int* ks3, int64_t nrg, int64_t nkb, int64_t rows, bool balanced_ok, int64_t min_ks_u, bool geo_side, std::vector<gvm::Decomp>& out) {
         out.clear();
         for (int prio = 0; prio < 2; prio++) {
             if (prio_only >= 0 && prio != prio_only) continue;
@@ -1016,9 +1015,11 @@ static int plan_decomps(gv_ctx* c) {
                 out.push_back(d);
             }
         }
-        // geometric splits (big first): ks segments per quad, segment j = geo^j of segment 0, every one at least 8 K-blocks long
-        if (prio_only != 0)
-            for (const auto& gk : {std::pair<int, float>{4, 0.5f}, {6, 0.6f}, {8, 0.65f}}) {
+        // geometric splits (big first): ks segments per quad, segment j = geo^j of segment 0, every one at least 8 K-blocks long.
+        // Ax side only: measured in-process against the tuner's picks (profiles/r4_decomp_ab_inprocess.txt) they gain 1-2.4 % on the
+        // Ax classes of 12.5 GB and 2.5 GB shards and lose 1-10 % on every ATx class (GV_TUNE_GEO=1 lists them there too)
+        if (prio_only != 0 && (geo_side || getenv("GV_TUNE_GEO")))
+            for (const auto& gk : {std::pair<int, float>{6, 0.6f}, {8, 0.65f}, {8, 0.8f}}) {
                 double tot = 0.0, wlast = 1.0;
                 for (int j = 0; j < gk.first; j++) { tot += wlast; if (j + 1 < gk.first) wlast *= gk.second; }
                 if ((double)nkb * wlast / tot < 8.0 || gk.first < min_ks_u) continue;
@@ -1037,8 +1038,8 @@ static int plan_decomps(gv_ctx* c) {
             }
         }
     };
-    build(ks3_m, pl.nrg_m, pl.nkb_m, 64, true, 1, c->dec_cand_m);
-    build(ks3_n, pl.nrg_n, pl.nkb_n, pl.rows_n, min_ks_n <= 1, min_ks_n, c->dec_cand_n);
+    build(ks3_m, pl.nrg_m, pl.nkb_m, 64, true, 1, false, c->dec_cand_m);
+    build(ks3_n, pl.nrg_n, pl.nkb_n, pl.rows_n, min_ks_n <= 1, min_ks_n, true, c->dec_cand_n);
     c->ks_tuned = c->ks_fixed_m = c->ks_fixed_n = false;
     // overrides (development): GV_KS_M / GV_KS_N fix a uniform K-split of the ATx / Ax kernels, GV_SK_M / GV_SK_N a balanced
     // grid of that many workgroups (both with the priority setting of GV_PRIO, default off / on), GV_AUTOTUNE=0 keeps the
@@ -1215,11 +1216,17 @@ int64_t gv_mbytes(const gv_ctx* c) { return c->mbytes; }
 
 // Ingest: fills the resident layouts chunk by chunk (markers [m0, m0+mc), m0 % 256 == 0) so that the raw rows never
 // have to be resident as a whole when only the stripes are wanted (N=400k x M=1M: 100 GB raw + 2 x 100 GB stripes).
-// nbytes of the file at `off` into the pinned staging buffer, by GV_IO_THREADS (default 4) concurrent pread streams: one
+// nbytes of the file at `off` into the pinned staging buffer, by GV_IO_THREADS (default 8) concurrent pread streams: one
 // thread copying out of the page cache moves ~9 GB/s, a fraction of what the PCIe link takes
 // returns 0 ok, -1 end of file before nbytes were read, else the errno of the failing pread (EINTR is retried)
 static int read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
-    int nt = 4;
+    // 8 concurrent pread streams (measured at config-2 size out of the page cache: 4 -> 27, 8 -> 33-34, 12 -> 32-37 GB/s including
+    // the allocation of the layout), never more than the CPUs this process may use
+    int nt = 8;
+    {
+        cpu_set_t cs;
+        if (sched_getaffinity(0, sizeof(cs), &cs) == 0 && CPU_COUNT(&cs) < nt) nt = CPU_COUNT(&cs) < 1 ? 1 : CPU_COUNT(&cs);
+    }
     if (const char* e = getenv("GV_IO_THREADS")) nt = atoi(e) < 1 ? 1 : (atoi(e) > 32 ? 32 : atoi(e));
     if (nbytes < ((size_t)8 << 20)) nt = 1;
     std::vector<int> st(nt, 0);

@@ -815,7 +815,8 @@ __device__ __forceinline__ void compute_atx_t(const ABufT& a, const u32x4* sb, i
                            (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
             accY[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B, accY[t], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);      // (no barrier, or one MFMA per seven vector instructions through sched_group_barrier: 15.53-15.61 ms
+                                                // against 15.54-15.67 at the headline, round 4 -- the vector ALU is busy, not badly ordered)
     }
 }
 
@@ -1062,29 +1063,54 @@ __global__ __launch_bounds__(256) void k_stats_tile(const uint4* __restrict__ ti
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rg >= nrg) return;
-    uint32_t n2[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n0[4] = {0, 0, 0, 0};
-    for (int64_t kb = 0; kb < nkb; kb++) {
+    // counts by inclusion-exclusion as in k_stats_stripes: nh (high bit: a = 2 or missing), nl (low bit: a = 1 or missing), nb (both:
+    // missing) among the individuals with a phenotype, np = those individuals in this lane's K slices
+    uint32_t nh[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0}, np = 0;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u* src = reinterpret_cast<const v4u*>(tiles) + rg * nkb * 256 + r * 4 + g;
+    auto count = [&](const v4u (&v)[4], int64_t kb) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint4 v = tiles[(rg * nkb + kb) * 256 + i * 64 + r * 4 + g];
             const int64_t J = kb * 16 + 4 * i + g;
-            const uint32_t pm = (J < P4) ? (mask2[J] & 0x55555555u) : 0u;
+            const uint32_t pm = (J < P4) ? mask2[J] : 0u;       // both bits of a pair are set for an individual with a phenotype
+            np += __popc(pm & 0x55555555u);
             uint32_t T[4];
-            transpose4x4_bytes(v.x, v.y, v.z, v.w, T);   // T[t] = marker 4q + t, 16 individuals of group J
+            transpose4x4_bytes(v[i].x, v[i].y, v[i].z, v[i].w, T);   // T[t] = marker 4q + t, 16 individuals of group J
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const uint32_t lo = T[t] & 0x55555555u, hi = (T[t] >> 1) & 0x55555555u;
-                n2[t] += __popc(hi & ~lo & pm);
-                n1[t] += __popc(~hi & lo & pm);
-                n0[t] += __popc(~hi & ~lo & pm);
+                const uint32_t wm = T[t] & pm;
+                nh[t] += __popc(wm & 0xAAAAAAAAu);
+                nl[t] += __popc(wm & 0x55555555u);
+                nb[t] += __popc(wm & (wm >> 1) & 0x55555555u);
             }
         }
+    };
+    int64_t kb = 0;
+    for (; kb + 2 <= nkb; kb += 2) {       // two super-blocks (8 KiB) of non-temporal loads in flight per wave
+        v4u a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = __builtin_nontemporal_load(src + kb * 256 + i * 64);
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[i] = __builtin_nontemporal_load(src + (kb + 1) * 256 + i * 64);
+        count(a, kb);
+        count(b, kb + 1);
     }
+    for (; kb < nkb; kb++) {
+        v4u a[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = __builtin_nontemporal_load(src + kb * 256 + i * 64);
+        count(a, kb);
+    }
+    uint32_t cp = np;
+    cp += __shfl_xor(cp, 16, 64); cp += __shfl_xor(cp, 32, 64);
+    uint32_t n2[4], n1[4], n0[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        n2[t] += __shfl_xor(n2[t], 16, 64); n2[t] += __shfl_xor(n2[t], 32, 64);
-        n1[t] += __shfl_xor(n1[t], 16, 64); n1[t] += __shfl_xor(n1[t], 32, 64);
-        n0[t] += __shfl_xor(n0[t], 16, 64); n0[t] += __shfl_xor(n0[t], 32, 64);
+        uint32_t ch = nh[t], cl = nl[t], cb = nb[t];
+        ch += __shfl_xor(ch, 16, 64); ch += __shfl_xor(ch, 32, 64);
+        cl += __shfl_xor(cl, 16, 64); cl += __shfl_xor(cl, 32, 64);
+        cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64);
+        n2[t] = ch - cb; n1[t] = cl - cb; n0[t] = cp - ch - cl + cb;
     }
     if (g != 0) return;
 #pragma unroll
@@ -1144,8 +1170,9 @@ __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, 
 
 // Digit sums of P consecutive planes (p0 ...) of one row over its np pieces.  Four pieces are fetched before any is added: the
 // loads of a piece do not depend on the previous one, but a loop of unknown length waits for each piece in turn -- 25 round trips
-// for a row of the hybrid decomposition's remainder (k_fin_atx_dot took 18 us at M = 200k where its neighbours take 6).
-template <int P>
+// for a row of the hybrid decomposition's remainder.  (DEEP = false: the plain loop -- k_fin_atx_dot, whose many one-piece rows lost
+// more to the registers of the prefetch than its few long rows gained: 17 -> 20 us at M = 200k; it starts its long rows first instead.)
+template <int P, bool DEEP = true>
 __device__ __forceinline__ void gather_pieces(const int32_t* __restrict__ partial, int np, int ppk, int p0, int64_t rows_p, int64_t row,
                                               long long (&s)[P][7]) {
 #pragma unroll
@@ -1155,7 +1182,7 @@ __device__ __forceinline__ void gather_pieces(const int32_t* __restrict__ partia
     const int64_t pstride = (int64_t)ppk * rows_p * 8;                       // int32 from one piece to the next
     const int32_t* base = partial + ((int64_t)p0 * rows_p + row) * 8;
     int ks = 0;
-    for (; ks + 4 <= np; ks += 4) {
+    for (; DEEP && ks + 4 <= np; ks += 4) {
         int4 a[4][P], b[4][P];
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -1263,9 +1290,13 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
     const double* __restrict__ addx = a.addx[v];
     const double scale = scal[3], P = scal[1];
     double s = 0.0;
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    // Block b of the reduction is run by the workgroup dispatched (gridDim.x - 1 - b)-th: the rows of the hybrid decomposition's
+    // remainder -- the LAST rows, up to 25 pieces each where the others have one -- start first instead of last (the partial sums
+    // keep their slots, so nothing changes for whoever adds them up)
+    const int64_t bx = (int64_t)gridDim.x - 1 - blockIdx.x;
+    for (int64_t m = bx * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
         long long sxy[2][7];
-        gather_pieces<2>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), ppk, p0, rows_p, m, sxy);
+        gather_pieces<2, false>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), ppk, p0, rows_p, m, sxy);
         long long xh, xl, yh, yl;
         combine(sxy[0], xh, xl);
         combine(sxy[1], yh, yl);
@@ -1284,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0 && a.part[v]) a.part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0 && a.part[v]) a.part[v][bx] = sh[0] + sh[1] + sh[2] + sh[3];
     // (the block partials are added up by gvk::finalize, launched behind this kernel: a last-block ticket would serialise
     // ~1000 atomics on one address, 50 ns each -- measured 74 us for this kernel at M = 500k against 16 us without)
 }

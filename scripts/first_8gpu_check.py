@@ -33,6 +33,27 @@ def main(out):
             bad.append("bench --gpus %d: multi_gpu.rccl_nranks = %r" % (n, d.get("multi_gpu", {}).get("rccl_nranks")))
         if n == 1 and ref and abs(d["value"] / ref - 1) > 0.03:
             bad.append("1-GPU value %.0f GB/s is more than 3 %% from the committed line %.0f (%s)" % (d["value"], ref, last[-1]))
+        # every leg: the shards cover the marker range exactly once, in rank order (divide_work, utilities.cpp:259-291)
+        pr = d.get("multi_gpu", {}).get("per_rank") if n > 1 else None
+        if n > 1:
+            if not pr or len(pr) != n:
+                bad.append("bench --gpus %d: multi_gpu.per_rank has %s entries" % (n, len(pr) if pr else None))
+            else:
+                pr = sorted(pr, key=lambda r: r["rank"])
+                at = 0
+                for r in pr:
+                    if r["first_marker"] != at:
+                        bad.append("bench --gpus %d: rank %d starts at marker %d, expected %d" % (n, r["rank"], r["first_marker"], at))
+                    at += r["markers"]
+                if 1 in rows and "config" in rows[1] and at != rows[1]["config"].get("Mt", at):
+                    bad.append("bench --gpus %d: the shards hold %d markers in all" % (n, at))
+        # the VAMP leg of every leg agrees with its own reference sequence (x_hat 1e-7; north star 1e-5) and -- the recursion being the
+        # same arithmetic whatever the sharding, up to the order of the cross-rank sums -- takes the CG steps of the 1-GPU run
+        v = d.get("vamp", {})
+        if v and v.get("x_hat_rel_l2") is not None and not v["x_hat_rel_l2"] < 1e-7:
+            bad.append("bench --gpus %d: vamp.x_hat_rel_l2 = %r" % (n, v["x_hat_rel_l2"]))
+        if n > 1 and 1 in rows and v.get("cg_iters") and rows[1].get("vamp", {}).get("cg_iters") and v["cg_iters"] != rows[1]["vamp"]["cg_iters"]:
+            bad.append("bench --gpus %d: CG steps per iteration %s differ from the 1-GPU run's %s" % (n, v["cg_iters"], rows[1]["vamp"]["cg_iters"]))
     if 1 in rows:
         print("%-6s %12s %10s %12s %14s" % ("GPUs", "GB/s", "x 1 GPU", "efficiency", "VAMP it/s"))
         for n, d in sorted(rows.items()):
