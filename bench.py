@@ -399,7 +399,7 @@ def main():
         out["vamp"]["config"] = (
             "sim.cpp phenotype (h2 0.5, CV %d, seed 1), default 23-component prior, rho 0.5, CG-max-iter %d, %d iterations; "
             "iters/s over iterations 2.., file output off; n_ax / n_atx = explicit vector products, n_*_pass = passes over "
-            "the genotype shard.  fuse_solves %d (DESIGN.md section 5); `reference_sequence` = the same run issuing the "
+            "the genotype shard.  fuse_solves %d (docs/history/rounds1-3.md section 5); `reference_sequence` = the same run issuing the "
             "reference's own sequence of products (fuse_solves 0), x_hat agreement between the two in `x_hat_rel_l2`"
             % (CV, a.CG_max_iter, len(r.trace), a.fuse_solves))
         if a.fuse_solves != 0:
@@ -414,7 +414,7 @@ def main():
                 num, den = float(tt[0]), float(tt[1])
             out["vamp"]["x_hat_rel_l2"] = float(np.sqrt(num / den)) if den > 0 else None
             if a.fuse_solves >= 4:
-                # level 4 (the default of the drivers and of this bench) is the only level that touches alpha2 (DESIGN.md section
+                # level 4 (the default of the drivers and of this bench) is the only level that touches alpha2 (docs/history/rounds1-3.md section
                 # 5): the level below it is measured beside it, with its own distance from the reference sequence
                 r3, v3 = vamp_leg(3)
                 num3 = float(np.linalg.norm(r3.x_est - r0.x_est)) ** 2
@@ -544,7 +544,7 @@ def main():
             m_ax = c2["ms_ax_kernel"] / max(c2["n_ax_kernel"], 1)
             m_atx = c2["ms_atx_kernel"] / max(c2["n_atx_kernel"], 1)
             out["tile_layout"] = {
-                "what": "the same step on ONE resident re-encoding that serves Ax and ATx (DESIGN.md section 3): resident genotype "
+                "what": "the same step on ONE resident re-encoding that serves Ax and ATx (docs/history/rounds1-3.md section 3): resident genotype "
                         "bytes per GPU %.1f GB instead of %.1f GB" % (M * ((N + 3) // 4) / 1e9, 2 * M * ((N + 3) // 4) / 1e9),
                 "value_GBps": round(job_bytes * nst / dt2 / 1e9, 2), "ms_per_step": round(dt2 / nst * 1e3, 4), "steps": nst,
                 "ax": {"avg_ms": round(m_ax, 4), "GBps": round(shard_bytes / (m_ax * 1e-3) / 1e9, 1) if m_ax > 0 else None},

@@ -635,7 +635,7 @@ int autotune_ks(gv_ctx* c) {
                 gvm::Decomp t = best; t.prio = 1;
                 if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
             }
-            if (best.ks > 1 && best.taper == 0.f) {
+            if (best.ks > 1 && best.taper == 0.f && best.geo == 0.f) {      // (a geometric split has its own segment lengths)
                 const gvm::Decomp base = best;
                 for (float tp : {0.5f, 0.9f}) {
                     gvm::Decomp t = base; t.taper = tp;
@@ -659,7 +659,7 @@ int autotune_ks(gv_ctx* c) {
 // its slice of the N-vector is all-reduced and scaled on a side stream while chunk t + 1 decodes; the context's stream joins
 // the side stream at the end.  Every chunk is the same exact integer arithmetic as the undivided pass and the all-reduce
 // of a slice adds the same numbers in the same rank order: results are bit-identical to the one-message form.  What it
-// buys is (T - 1)/T of the exchange time at the price of T - 1 more kernel tails: a knob to measure
+// buys is (T - 1)/T of the exchange time at the price of T - 1 more kernel tails (docs/history/rounds1-3.md section 6): a knob to measure
 // on an 8-GPU node, off by default.
 int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double* outa, double* outb,
                   const gvm::CgHook* cg) {
@@ -1311,7 +1311,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
                 if (!A(hipMalloc(&pl.tiles, (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096), "hipMalloc(tile layout)")) return;
             } else {
                 // ONE allocation for the two stripe sets, stripes_n (the Ax side) first.  Where the driver places a 100 GB allocation
-                // moves the kernel that streams it by 1.5-3.5 % (nine ingests on one box, Ax 14.9-15.6 ms and
+                // moves the kernel that streams it by 1.5-3.5 % (docs/history/rounds1-3.md section 4.2: nine ingests on one box, Ax 14.9-15.6 ms and
                 // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
                 // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
                 // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.

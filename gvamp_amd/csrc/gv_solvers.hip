@@ -198,7 +198,7 @@ static int lmmse2_device(gv_ctx* c, const double* xa, const double* xb, double t
 // ---- the steady state of cg_run with every scalar on the device (kernel mode 1) ------------------------------------------
 // A CG step of the host-driven loop above costs three scalar round trips (alpha, the Onsager rule, beta / the residual
 // rule): the host waits for a reduction, computes one division and launches the next small kernel -- ~15 us of idle GPU each
-// through the mailbox on one GPU (1-2 % of a step at 12.5-100 GB shards: DESIGN.md section 5 has the A/B, which is a tie
+// through the mailbox on one GPU (1-2 % of a step at 12.5-100 GB shards: docs/history/rounds1-3.md section 5 has the A/B, which is a tie
 // there), plus a small-message all-reduce latency each on a sharded job, which is what this loop is for.  Here the
 // state of each system (gvm::ST_*) lives in HBM; the step is
 //   Ax pass   [k_prep_ax: p <- z + beta p on the way in | k_quant | stream | k_fin_ax | all-reduce]

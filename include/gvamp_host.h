@@ -31,7 +31,7 @@ typedef struct {                 /* the knobs vamp reads from Options (options.h
     int use_XXT_denoiser;         /* --use-XXT-denoiser (options.cpp:208-216) */
     int bin_class;                /* 1: --model bin_class (vamp_probit.cpp), y in {0,1}; x_est is then the UNSCALED x1_hat */
     double probit_var;            /* --probit-var (options.hpp:124) */
-    int fuse_solves;              /* 0 ... 4: see --fuse-solves */
+    int fuse_solves;              /* 0 ... 4: see --fuse-solves (docs/history/rounds1-3.md section 5) */
     int C;                        /* probit covariates (--C); 0 = none */
     const double* covs;           /* N x C row-major (the rows of --cov-file), or NULL */
     double* cov_eff_out;          /* C fitted covariate effects (vamp::get_cov_eff), or NULL */

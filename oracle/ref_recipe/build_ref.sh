@@ -3,7 +3,7 @@
 # and only when, everything it includes is present.  No stand-ins: the reference's translation units include Boost
 # (data.cpp:17, utilities.cpp:8, vamp.cpp:19: <boost/math/distributions/students_t.hpp>; options.cpp:9:
 # <boost/algorithm/string/trim.hpp>; vamp_probit.cpp:14-17: <boost/numeric/ublas/...>) and <mpi.h>.  Without real Boost
-# headers this script says so and builds nothing: the oracle then stays "parity unpinned" (DESIGN.md section 2).
+# headers this script says so and builds nothing: the oracle then stays "parity unpinned" (docs/history/rounds1-3.md section 2).
 #
 #   REF=/root/reference BOOST_ROOT=/path/to/boost oracle/ref_recipe/build_ref.sh
 #

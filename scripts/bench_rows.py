@@ -1,4 +1,4 @@
-"""Measurement of the widened rows (SURVEY 8f / DESIGN.md section 8) at the sizes BASELINE.json names for them.
+"""Measurement of the widened rows (SURVEY 8f / docs/history/rounds1-3.md section 8) at the sizes BASELINE.json names for them.
 
 One JSON object per row on stdout (development tool: bench.py stays the contract for the headline metric).
   python scripts/bench_rows.py > gpurun_out/rows.json

@@ -1,5 +1,5 @@
 """Do the fuse levels drift?  The by-products of levels 3 and 4 chain from iteration to iteration (A x2_hat and A^T A x2_hat are never
-re-anchored on an explicit product).  Long runs on independent and on block-correlated genotypes at every level
+re-anchored on an explicit product, docs/history/rounds1-3.md section 5).  Long runs on independent and on block-correlated genotypes at every level
 against the same run issuing the reference's own sequence of products (level 0): x1_hat per iteration, gamw and step counts.
   python scripts/drift_check.py [N] [M] [iterations]        (development; run on a GPU box)"""
 import json

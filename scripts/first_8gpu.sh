@@ -5,7 +5,7 @@
 #   1. bench.py --gpus 1 / 2 / 4 / 8        the strong-scaling line of BASELINE.json; every line must carry
 #                                            multi_gpu.rccl_nranks == N, and the N = 1 value must sit within 3 % of the last
 #                                            committed 1-GPU bench line (profiles/r*_bench_n1.json)
-#   2. GV_OVERLAP = 0 / 2 / 4 at 8 ranks     the exchange of data::Ax overlapped with the decode: measured, not assumed
+#   2. GV_OVERLAP = 0 / 2 / 4 at 8 ranks     the exchange of data::Ax overlapped with the decode (docs/history/rounds1-3.md section 6): measured, not assumed
 #   3. GV_CG_DEVICE = 0 / 1 at 8 ranks       device-resident CG scalars against the host-driven loop (its case is the sharded job)
 #   4. gvamp_sim as 8 RCCL ranks             the reference's command line under `mpirun -np 8`, against the files the real
 #                                            reference wrote (tests/golden/survey_probe/sim_np8_*)

@@ -122,7 +122,7 @@ def one_case(rng, idx, tol=1e-5, verbose=False):
                 sh.set_kernel_mode(mode)
             assert r.niter == ref.niter, "niter"
             assert [t["cg_iters"] for t in r.trace] == [int(t["cg_iters"]) for t in ref.trace], "cg counts"
-            # pure-noise phenotypes are the worst case for the cancellations of iteration 1: with gam1 = 1e-8
+            # pure-noise phenotypes are the worst case for the cancellations of iteration 1 (docs/history/rounds1-3.md section 2): with gam1 = 1e-8
             # and no signal, alpha2 = 1 - O(1e-8), so gam1_next = gam2 (1 / alpha2 - 1) carries 1e8 x the rounding difference of
             # alpha2 (replayed case 89 of seed 777005, probit, N = 255 < M = 1025: every scalar of iteration 1 within 6e-14 of the
             # oracle's, gam1_next 4.6e-6 off, x_est 1.9e-6; the two kernel families of the product, whose reductions run in the

@@ -20,7 +20,7 @@ BIG = False
 NT = min(32, os.cpu_count() or 1)     # oracle threads
 EDGE_N = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097]
 EDGE_M = [1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2049]
-ENVK = ("GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_HY_M", "GV_HY_N", "GV_TAPER", "GV_PRIO", "GV_TUNE_CACHE")
+ENVK = ("GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_HY_M", "GV_HY_N", "GV_TAPER", "GV_GEO", "GV_PRIO", "GV_TUNE_CACHE")
 
 
 def rel(a, b):
@@ -87,7 +87,8 @@ def run_case(k):
                "GV_HY_N": "%d:%d" % (rng.integers(1, 6), rng.choice([1, 7, 97, 768])), "GV_PRIO": str(int(rng.integers(2)))}
     elif mode == 1:
         env = {"GV_KS_M": str(int(rng.integers(1, 6))), "GV_KS_N": str(int(rng.integers(1, 6))),
-               "GV_TAPER": str(float(rng.choice([0.0, 0.5, 0.9]))), "GV_PRIO": str(int(rng.integers(2)))}
+               "GV_TAPER": str(float(rng.choice([0.0, 0.5, 0.9]))), "GV_GEO": str(float(rng.choice([0.0, 0.0, 0.5, 0.8]))),
+               "GV_PRIO": str(int(rng.integers(2)))}
     elif mode == 2:
         env = {"GV_SK_M": str(int(rng.choice([1, 7, 97, 768, 1536]))), "GV_SK_N": str(int(rng.choice([1, 7, 97, 768, 1536])))}
     for kk in ENVK:

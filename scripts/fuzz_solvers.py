@@ -238,7 +238,9 @@ def run_case(seed0, k):
         # stopping rule, and agree with the exact solution no better than that)
         tolx = loose * (1e-13 * kappa ** 2 + 1e-9)
         if loose > 1.0:
-            tolx = max(tolx, 2e-4)
+            # (seed 402, case 572, reproduced bit for bit on the round-3 tree: N = 2958, M = 3, 40 steps on a rank-3 system with
+            # kappa = 2.9e3 -- A^T mu of the two loops 1.2e-3 apart: the 1e-4 stopping rule times sqrt(kappa) is the scale there)
+            tolx = max(tolx, 2e-4, 1e-4 * np.sqrt(kappa))
         for key, ok in (("mn", okx[0]), ("mn2", okx[1]), ("atm", okx[1]), ("mb2", okx[1]), ("aat", okx[1]), ("ata2", okx[1])):
             if ok:
                 assert close(d[key], h[key], tolx), (key, info, rel(d[key], h[key]), kappa)
@@ -274,7 +276,10 @@ def run_case(seed0, k):
     for key in ("rr", "ra", "rb"):
         assert trace_close(plain[0][key], d[key], tol_sh), ("sharded " + key, info, plain[0][key][:5], d[key][:5])
     if P["ride"]:
-        assert rel(plain[0]["ro"], d["ro"]) < 1e-12, ("sharded rider", info)
+        # every rank quantises its own slice of the rider with its own exponent and the slices' products are added in another order:
+        # equal at the scale of the operand, not of a result that may cancel (seed 402, case 312, also on the round-3 tree: N = 4, M = 3)
+        e_ro = np.linalg.norm(plain[0]["ro"] - d["ro"])
+        assert e_ro < 1e-12 * max(np.linalg.norm(d["ro"]), np.linalg.norm(P["rx"])), ("sharded rider", info, e_ro)
     if P["xxt"]:
         for key in ("xr1", "xr2", "xr3"):
             assert trace_close(plain[0][key], d[key], tol_sh), ("sharded " + key, info, plain[0][key][:5], d[key][:5])

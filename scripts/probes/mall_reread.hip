@@ -1,7 +1,7 @@
 // mall_reread.hip -- development probe (not part of the product): can a second read of a block that has just been streamed
 // from HBM be served by the 256 MiB Infinity Cache at a rate that ADDS to the HBM stream?
 //
-// Motivation: A^T (A p) = sum over blocks b of individuals of A_b^T (A_b p).  On the tile layout the
+// Motivation (docs/history/rounds1-3.md section 10): A^T (A p) = sum over blocks b of individuals of A_b^T (A_b p).  On the tile layout the
 // two products read the SAME bytes, so a blocked operator would stream the matrix from HBM once per lmmse_mult and take the
 // second read of every block from the last-level cache -- if that cache delivers.
 //

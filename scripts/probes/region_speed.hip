@@ -1,5 +1,5 @@
 // Development probe: how fast does a plain read stream run over different 8 GiB regions of ONE large allocation, and of several
-// smaller ones?  (the placement of a 100 GB allocation moves the kernel that streams it by 1.5-3.5 %.)
+// smaller ones?  (docs/history/rounds1-3.md section 4.2: the placement of a 100 GB allocation moves the kernel that streams it by 1.5-3.5 %.)
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/region_speed scripts/probes/region_speed.hip && scripts/probes/region_speed [GiB]
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,5 +1,5 @@
 // Development probe: does memory mapped through the HIP virtual-memory API (physical chunks of a chosen size behind an aligned
-// virtual range) stream faster / more predictably than hipMalloc?  
+// virtual range) stream faster / more predictably than hipMalloc?  (docs/history/rounds1-3.md section 4.2.)
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/vmm_speed scripts/probes/vmm_speed.hip && scripts/probes/vmm_speed [chunk GiB]
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -45,7 +45,7 @@ for N, M in SHAPES:
         print(N, M, layout, picks, [dict(v) for v in votes], flush=True)
         rows.append((N, M, layout - 1, picks))
 h = build.kernel_src_hash()[:16]
-src = open(a.out).read()
+src = open(os.path.join(build.CSRC, "gv_tune_builtin.h")).read()      # (the head of the shipped file; --out may not exist yet)
 head = src[:src.index("static const char* const GV_BUILTIN_FOR_HASH")]
 body = 'static const char* const GV_BUILTIN_FOR_HASH = "%s";\nstatic const BuiltinPick GV_BUILTIN_PICKS[] = {\n' % h
 for N, M, lay, picks in rows:

@@ -72,7 +72,7 @@ def test_single_solve_device_loop_equals_host_loop(oracle, N, M, warm, denoiser,
 
 @pytest.mark.parametrize("N,M,warm,ride,max_iter", [(2000, 3000, True, True, 40), (1200, 6000, False, True, 40), (2000, 3000, True, False, 2)])
 def test_dual_solve_with_by_products_device_loop_equals_host_loop(N, M, warm, ride, max_iter):
-    """gv_cg_solve2x: LMMSE + Onsager solves in lock-step, the rider and the recurrence by-products."""
+    """gv_cg_solve2x: LMMSE + Onsager solves in lock-step, the rider and the recurrence by-products (docs/history/rounds1-3.md section 5)."""
     sh, _ = _shard(N, M, seed=11)
     with sh:
         rng = np.random.default_rng(N + M)

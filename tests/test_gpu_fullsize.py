@@ -141,7 +141,7 @@ def test_ragged_multi_chunk_shard_with_na_phenotypes(oracle):
 
 def test_kernel_families_agree_on_a_vamp_run_at_scale():
     """A whole VAMP run (N=100k x M=200k, 5 GB shard) on the fp64 VALU family and on the i8 MFMA fixed-point family:
-    same CG / EM counts, estimates equal to the ~1e-9 that iteration 1's cancellation leaves."""
+    same CG / EM counts, estimates equal to the ~1e-9 that iteration 1's cancellation leaves (docs/history/rounds1-3.md section 2)."""
     N, M = 100000, 200000
     with capi.Shard(N, M, anchor=True) as sh:
         sh.synth_bed(77, 5000)

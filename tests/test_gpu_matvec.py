@@ -347,7 +347,7 @@ def test_bandwidth_probes_report_plausible_rates():
 @pytest.mark.parametrize("N,M", [(3000, 5000), (1003, 20011), (70001, 777)])
 def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
     """The streaming kernel's work decomposition (uniform K-split, balanced ranges that cross quad boundaries, with or without
-    progress-based wave priority) only changes who adds which int32 partial sums: every product must
+    progress-based wave priority; docs/history/rounds1-3.md section 4.2) only changes who adds which int32 partial sums: every product must
     come out bit for bit the same.  The decomposition is fixed per context through the development overrides."""
     import os
     rng = np.random.default_rng(N + M)
@@ -361,6 +361,7 @@ def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
         {"GV_KS_M": "1", "GV_KS_N": "1"},
         {"GV_KS_M": "3", "GV_KS_N": "5", "GV_PRIO": "1"},
         {"GV_KS_M": "4", "GV_KS_N": "3", "GV_TAPER": "0.9"},      # tapered K-segments (long first, short last)
+        {"GV_KS_M": "4", "GV_KS_N": "6", "GV_GEO": "0.6", "GV_PRIO": "1"},   # geometric K-segments (big first, round 4)
         {"GV_SK_M": "37", "GV_SK_N": "53"},                       # balanced, ranges of >= 8 cells across quad boundaries
         {"GV_SK_M": "768", "GV_SK_N": "1536", "GV_PRIO": "0"},
         {"GV_HY_M": "2:5", "GV_HY_N": "3:7"},                     # hybrid: 2 / 3 quads whole, the rest in 5 / 7 balanced ranges
@@ -369,7 +370,7 @@ def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
     ]
     results = []
     for env in settings:
-        for k in ("GV_AUTOTUNE", "GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_HY_M", "GV_HY_N", "GV_PRIO", "GV_TAPER"):
+        for k in ("GV_AUTOTUNE", "GV_KS_M", "GV_KS_N", "GV_SK_M", "GV_SK_N", "GV_HY_M", "GV_HY_N", "GV_PRIO", "GV_TAPER", "GV_GEO"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -389,3 +390,34 @@ def test_work_decompositions_are_bit_identical(monkeypatch, N, M):
         for a, b in zip(r, results[0]):
             assert np.array_equal(a, b)
     assert np.array_equal(results[0][0], results[0][2]) and np.array_equal(results[0][1], results[0][4])   # one- vs two-vector pass
+
+
+def test_pinned_decompositions_keep_every_bit_and_inadmissible_ones_are_refused():
+    """gv_set_decomp: a decomposition pinned after the ingest (uniform with a geometric or linear taper, balanced, hybrid) is what
+    gv_get_decomp reports afterwards and changes no bit of any product; one that needs more partial-sum pieces than the context
+    holds room for, or with parameters out of range, is refused with a message and leaves the previous one in place."""
+    N, M = 5000, 9000
+    rng = np.random.default_rng(3)
+    bed = synth.synth_bed(N, M, seed=17, miss_ppm=10000)
+    x, x2 = rng.standard_normal(M), rng.standard_normal(M)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        dx, dx2, p, p2, w, w2 = sh.vecM(x), sh.vecM(x2), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM()
+        sh.ax2_dev(dx, dx2, p, p2); sh.atx2_dev(p, p2, w, w2)
+        ref = [v.download() for v in (p, p2, w, w2)]
+        for spec in (dict(ks=3, geo=0.5, prio=1), dict(ks=4, taper=0.5), dict(balanced_cells=16, prio=1),
+                     dict(balanced_cells=9, whole_quads=2, prio=1), dict(ks=1)):
+            for cls in ("atx2", "ax2"):
+                sh.set_decomp(cls, **spec)
+                got = sh.decomp()[cls]
+                for k, v in spec.items():
+                    assert abs(float(got.get(k, 0)) - float(v)) < 1e-6, (cls, spec, got)
+            sh.ax2_dev(dx, dx2, p, p2); sh.atx2_dev(p, p2, w, w2)
+            for a, b in zip(ref, [v.download() for v in (p, p2, w, w2)]):
+                assert np.array_equal(a, b), spec
+        keep = sh.decomp()["atx2"]
+        for bad in (dict(ks=60), dict(ks=3, geo=1.5), dict(ks=0), dict(balanced_cells=4)):
+            with pytest.raises(capi.GvError, match="not admissible"):
+                sh.set_decomp("atx2", **bad)
+        assert sh.decomp()["atx2"] == keep
