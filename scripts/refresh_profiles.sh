@@ -1,10 +1,10 @@
 # Regenerates profiles/<R>_* on a GPU box (development).  Two calls (each fits a 20-minute gpurun call):
-#   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r3 a     bench line, kernel statistics, PMC traffic
-#   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r3 b     rows, ingest, kernel timelines, mid-size counter passes
-#   gpurun --timeout 600  -- bash scripts/refresh_profiles.sh r3 c     the kernel timelines only
+#   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r4 a     bench line, kernel statistics, PMC traffic
+#   gpurun --timeout 1200 -- bash scripts/refresh_profiles.sh r4 b     rows, ingest, kernel timelines, mid-size counter passes
+#   gpurun --timeout 600  -- bash scripts/refresh_profiles.sh r4 c     the kernel timelines only
 # Outputs go to gpurun_out/prof_refresh_<part>/ ; copy them into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r3}; PART=${2:-a}
+R=${1:-r4}; PART=${2:-a}
 O=gpurun_out/prof_refresh_$PART; rm -rf $O; mkdir -p $O
 export GV_TUNE_CACHE_DIR=$PWD/$O/tune_cache        # shapes outside the shipped table: the first run measures, later ones read back
 if [ "$PART" = a ]; then
