@@ -306,7 +306,10 @@ public:
         jobs.assign(n, Job{nullptr, nullptr, 0});
         taken.reset(new std::atomic<int>[n > 0 ? n : 1]);
         for (int i = 0; i < n; i++) taken[i].store(1);
-        for (int i = 0; i < n; i++) th.emplace_back(&CopyPool::work, this, i);
+        try {
+            for (int i = 0; i < n; i++) th.emplace_back(&CopyPool::work, this, i);
+        } catch (...) {      // (no more threads to be had: the pool works with the helpers it got, copy() reads th.size())
+        }
     }
     // dst <- src, n bytes, shared among the caller and the helpers (below 256 KiB, or in a forked child whose helpers did not
     // survive the fork, the caller copies alone).  Calls are serialised by copy_mu: contexts of several threads share the pool.
@@ -320,13 +323,16 @@ public:
         const size_t parts = (size_t)nh + 1, per = ((n / parts) + 63) & ~(size_t)63;
         {
             std::lock_guard<std::mutex> lk(mu);
+            // Order matters: a helper still finishing its loop iteration of the PREVIOUS call may claim a job of this one the moment
+            // its `taken` flag reads 0 -- so the count it will decrement is set first, and the flag is released only after the job
+            // it guards has been written (the helper's claim acquires it).
+            pending.store(nh, std::memory_order_relaxed);
             for (int i = 0; i < nh; i++) {
                 const size_t off = per * (size_t)(i + 1);
                 const size_t len = off >= n ? 0 : (i == nh - 1 ? n - off : (off + per > n ? n - off : per));
                 jobs[i] = Job{(char*)dst + off, (const char*)src + off, len};
-                taken[i].store(0, std::memory_order_relaxed);
+                taken[i].store(0, std::memory_order_release);
             }
-            pending.store(nh, std::memory_order_release);
             gen.fetch_add(1, std::memory_order_release);
         }
         cv.notify_all();
@@ -1353,7 +1359,12 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         }
         alloc_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
     };
-    std::thread alloc_thr(alloc_layout);
+    std::thread alloc_thr;
+    try {
+        alloc_thr = std::thread(alloc_layout);
+    } catch (...) {      // (no thread to be had: allocate here, nothing overlaps)
+        alloc_layout();
+    }
     const auto t_prep0 = std::chrono::steady_clock::now();
     const int64_t CH = file ? 8192 : 32768;   // file source: each pinned staging buffer is CH * mbytes bytes
     uint8_t* tmp = nullptr;
@@ -1379,7 +1390,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         pre_read = b + 1;
     }
     const double prep_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count();
-    alloc_thr.join();
+    if (alloc_thr.joinable()) alloc_thr.join();
     if (!alloc_err.empty() && !rc) rc = fail(c, "ingest: allocating the resident layout failed: %s", alloc_err.c_str());
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "ingest: hipDeviceSynchronize failed");
     const auto t_in1 = std::chrono::steady_clock::now();      // the layouts are allocated (the driver maps / wipes 100+ GB)
