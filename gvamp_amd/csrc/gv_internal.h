@@ -171,14 +171,14 @@ void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const*
 // launch stay block partials too (k_cgx_decide adds them up: cgx_decide's part / part_nb); returns the number of blocks
 int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-           double* const* red, double diag, int64_t n, const double* const* dp_part = nullptr, int dp_nb = 0);
+           double* const* red, double diag, int64_t n, const double* const* dp_part = nullptr, int dp_nb = 0,
+           double* const* az = nullptr, const double* const* aw = nullptr, int64_t npad = 0);   // az: A mu += alpha A p rides along
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);   // ordered sum of block partials
 void state_init(hipStream_t s, double* dst, const double* q);   // q: gvm::ST_SIZE doubles, by value in the launch
 void set_ints(hipStream_t s, int* dst, int a, int b);
 // the state block of a system at its start from the block partials of its two opening reductions over n entries (one rank)
 void state_from_partials(hipStream_t s, double* dst, const double* q, const double* part_rz, int K_rz, int k_rz, const double* part_vv,
                          int64_t n, bool sqrt_norm);
-void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
                 int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
                 const double* other_st = nullptr, const int* ride_report = nullptr, const double* const* part = nullptr,

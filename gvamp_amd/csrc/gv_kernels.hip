@@ -604,6 +604,7 @@ struct CgxAB {
     double* st[2]; double* mu[2]; const double* p[2]; const double* v[2]; double* r[2]; const double* d[2]; double* z[2];
     const double* dp[2]; double* part[2]; double* red[2];
     const double* dpp[2]; int dp_nb;      // dpp[v] != NULL: <d,p> still in dp_nb block partials (one rank: no all-reduce, no k_finalize)
+    double* az[2]; const double* aw[2]; long long npad;   // az[v] != NULL: A mu += alpha A p over npad entries (gv_cg_extras.a_mu_a)
 };
 __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n) {
     __shared__ double sh[4];
@@ -620,6 +621,11 @@ __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n)
     const double* __restrict__ d = a.d[v];
     double* __restrict__ z = a.z[v];
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (a.az[v]) {      // A mu accumulated from the A p_k (what k_axpy_st did in a launch of its own: the same expression, the same bits)
+        double* __restrict__ y = a.az[v];
+        const double* __restrict__ x = a.aw[v];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.npad; i += stride) y[i] += alpha * x[i];
+    }
     double s_vmu = 0, s_rz = 0, s_rr = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         double m = fma(alpha, p[i], mu[i]);
@@ -638,16 +644,9 @@ __global__ __launch_bounds__(256) void k_cgx_ab(CgxAB a, double diag, int64_t n)
     if (threadIdx.x == 0) {
         double* o = a.part[v] + (int64_t)blockIdx.x * 3;
         o[0] = s_vmu; o[1] = s_rz; o[2] = s_rr;
-        if (blockIdx.x == 0) st[gvm::ST_ALPHA] = alpha;                   // for A mu += alpha A p (k_axpy_st)
+        if (blockIdx.x == 0) st[gvm::ST_ALPHA] = alpha;
     }
     // (block partials -> gvk::finalize behind this kernel; see k_fin_atx_dot for why not a last-block ticket)
-}
-// y += st[ST_ALPHA] * x while the system is active (A mu accumulated from the A p_k, gv_cg_extras.a_mu_a)
-__global__ void k_axpy_st(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ st, int64_t n) {
-    if (st[gvm::ST_ACTIVE] == 0.0) return;
-    const double alpha = st[gvm::ST_ALPHA];
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += alpha * x[i];
 }
 // ---- vamp::CG_solverAAT (denoiserXXT.cpp:52-130), the N-space CG of --use-XXT-denoiser 1, with its scalars on the device ----
 // d = tau d + gam2 p (the rest of lmmse_multAAT, denoiserXXT.cpp:30-33) and the block partials of <d, p> (:88)
@@ -1242,13 +1241,17 @@ void dots_ex(hipStream_t s, int K, const double* const* xa, const double* const*
 
 int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const double* const* p, const double* const* v,
            double* const* r, const double* const* d, double* const* z, const double* const* dp, double* const* part,
-           double* const* red, double diag, int64_t n, const double* const* dp_part, int dp_nb) {
+           double* const* red, double diag, int64_t n, const double* const* dp_part, int dp_nb, double* const* az,
+           const double* const* aw, int64_t npad) {
     CgxAB a{};
     for (int k = 0; k < nsys; k++) {
         a.st[k] = st[k]; a.mu[k] = mu[k]; a.p[k] = p[k]; a.v[k] = v[k]; a.r[k] = r[k]; a.d[k] = d[k]; a.z[k] = z[k];
         a.dp[k] = dp[k]; a.part[k] = part[k]; a.red[k] = red[k];
         a.dpp[k] = dp_part ? dp_part[k] : nullptr;
+        a.az[k] = az ? az[k] : nullptr;
+        a.aw[k] = aw ? aw[k] : nullptr;
     }
+    a.npad = npad;
     a.dp_nb = dp_nb;
     const int nb = red_blocks(n, 256);
     hipLaunchKernelGGL(k_cgx_ab, dim3(nb, nsys), dim3(256), 0, s, a, diag, n);
@@ -1260,10 +1263,6 @@ int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const 
 }
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out) {
     hipLaunchKernelGGL(k_finalize, dim3(K), dim3(256), 0, s, partial, nb, K, out);
-}
-void axpy_st(hipStream_t s, double* y, const double* x, const double* st, int64_t n) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_axpy_st, dim3(nblk(n, 256)), dim3(256), 0, s, y, x, st, n);
 }
 // one CG_solverAAT step after d = A (A^T p) has arrived: everything but the read-back
 // Three launches (two when the Ax epilogue has taken k_aat_dq along, one more with the search-direction update): every reduction is added up by the kernel that consumes it

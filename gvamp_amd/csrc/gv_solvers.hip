@@ -309,7 +309,10 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         const int ns = two ? 2 : 1;
         gvm::CgHook hk;
         hk.go = c->cgx_go;
-        if (ride_pending) { hk.ride = d_ride; hk.alt_x = ride_x; }
+        // one rank: the epilogue of the Ax pass delivers the rider's product itself (no k_ride_copy); sharded or overlapped: it is
+        // copied out of the slot behind the cross-rank sum and the scaling of that slot's output
+        const bool ride_direct = ride_pending && !multi && !ovl;
+        if (ride_pending) { hk.ride = d_ride; hk.alt_x = ride_x; if (ride_direct) hk.ride_out = ride_out; }
         for (int j = 0; j < ns; j++) {
             CgSys& s = sys[act[j]];
             hk.state[j] = dst[act[j]];
@@ -335,7 +338,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
                 if (comm_allreduce(c, wn[0], 2 * npad)) return 1;      // w_n | w_n2: one message
                 gvk::scale_vec(st, wn[0], 2 * npad, scale);
             }
-            if (ride_pending) gvk::ride_copy(st, ride_out, wn[0], wn[1], dst[0], dst[1], d_ride, npad);
+            if (ride_pending && !ride_direct) gvk::ride_copy(st, ride_out, wn[0], wn[1], dst[0], dst[1], d_ride, npad);
         } else {
             if (ovl) {
                 if (ax_overlapped(c, 1, sys[act[0]].p, nullptr, wn[0], nullptr, &hk)) return 1;
@@ -371,10 +374,11 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
                 a_part[j] = c->red_partial + (size_t)act[j] * RED_BLOCKS * 8 + 4 * RED_BLOCKS;   // (clear of the <d,p> partials)
                 a_red[j] = c->red_out + 8 * act[j];
             }
+            double* a_az[2] = {nullptr, nullptr};
+            const double* a_aw[2] = {nullptr, nullptr};
+            for (int j = 0; j < ns; j++) { a_az[j] = sys[act[j]].az; a_aw[j] = wn[j]; }       // A mu += alpha A p rides in the same launch
             const int nb_ab = gvk::cgx_ab(st, ns, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M,
-                                          self ? a_dpp : nullptr, self ? gvm::atx_dot_blocks(c->plan) : 0);
-            for (int j = 0; j < ns; j++)
-                if (sys[act[j]].az) gvk::axpy_st(st, sys[act[j]].az, wn[j], dst[act[j]], npad);   // A mu += alpha A p
+                                          self ? a_dpp : nullptr, self ? gvm::atx_dot_blocks(c->plan) : 0, a_az, a_aw, npad);
             KCHK(c);
             if (multi && comm_allreduce(c, c->red_out, K)) return 1;           // <v,mu>, <r,z>, <r,r>
             const double* c_red[2] = {c->red_out, c->red_out + 8};
