@@ -2076,7 +2076,10 @@ int gv_bind_host_numa(int device, int* numa_node_out) {
     }
     if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
     CPU_AND(&both, &want, &have);
-    if (CPU_COUNT(&both) == 0) return 0;          // the launcher pinned this rank elsewhere on purpose: leave it
+    // fewer than 8 CPUs in common (a launcher that pinned this rank elsewhere, a cgroup that grants a sliver of the node): leave the
+    // affinity alone -- the rank's main thread spins on the scalar mailbox, and the staging helpers, the file readers and RCCL's
+    // proxy threads need cores of their own beside it
+    if (CPU_COUNT(&both) < 8) return 0;
     if (sched_setaffinity(0, sizeof(both), &both) != 0) return 0;
     if (numa_node_out) *numa_node_out = node;
     return 0;

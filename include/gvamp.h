@@ -329,7 +329,7 @@ int gv_comm_rank(const gv_ctx* ctx);
 /* One process per GPU on a multi-socket node: restricts the calling thread -- and every thread it starts afterwards -- to the
  * CPUs of the NUMA node `device` hangs off (sysfs: the PCI device's numa_node, the node's cpulist), intersected with the CPUs it
  * may already use.  *numa_node_out (may be NULL) = that node, or -1 when nothing was changed (single-node host, topology hidden,
- * no CPU in common, GVAMP_NUMA_BIND=0).  Call it before the first gv_create of the process; the drivers and bench.py do. */
+ * fewer than 8 CPUs in common, GVAMP_NUMA_BIND=0).  Call it before the first gv_create of the process; the drivers and bench.py do. */
 int gv_bind_host_numa(int device, int* numa_node_out);
 int gv_comm_size(const gv_ctx* ctx);
 
