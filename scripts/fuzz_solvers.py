@@ -248,7 +248,8 @@ def run_case(seed0, k):
         tol_atm = min(0.5, tolx * max(1.0, kappa))
         for key, ok in (("mn", okx[0]), ("mn2", okx[1]), ("atm", okx[1]), ("mb2", okx[1]), ("aat", okx[1]), ("ata2", okx[1])):
             if ok:
-                assert close(d[key], h[key], tol_atm if key == "atm" else tolx), (key, info, rel(d[key], h[key]), kappa)
+                # (A A^T mu_a = (v - r - gam2 mu_a) / tau is the same range component, obtained as a difference of terms kappa times larger)
+                assert close(d[key], h[key], tol_atm if key in ("atm", "aat") else tolx), (key, info, rel(d[key], h[key]), kappa)
     # ---- B: marker shards in one process
     nr = int(rng.integers(2, 5))
     cuts = sorted(int(c) for c in rng.integers(0, M + 1, size=nr - 1))
@@ -295,8 +296,9 @@ def run_case(seed0, k):
             for key in ("atm", "mb2", "ata2"):       # (A^T mu_a: at kappa times the tolerance of mu_a, as above; seed 512, case 896)
                 assert close(cat(key), d[key], min(0.5, tol_shx * max(1.0, kappa)) if key == "atm" else tol_shx), \
                     ("sharded " + key, info, rel(cat(key), d[key]), kappa)
-            for key in ("mn", "mn2", "aat"):
-                assert close(plain[0][key], d[key], tol_shx), ("sharded " + key, info, rel(plain[0][key], d[key]), kappa)
+            for key in ("mn", "mn2", "aat"):      # (aat: the range component again -- seed 721, case 1289: M = 2, kappa = 601, 3.6e-3)
+                assert close(plain[0][key], d[key], min(0.5, tol_shx * max(1.0, kappa)) if key == "aat" else tol_shx), \
+                    ("sharded " + key, info, rel(plain[0][key], d[key]), kappa)
     return info
 
 
