@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libgvamp.so")
 _LIB = None
 
 SPACE_M, SPACE_N = 0, 1
-ABI_VERSION = 2          # GV_ABI_VERSION of include/gvamp.h this module's ctypes structs were written against
+ABI_VERSION = 3          # GV_ABI_VERSION of include/gvamp.h this module's ctypes structs were written against
 
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_synchronize", "gv_set_dims", "gv_mbytes",
@@ -22,7 +22,7 @@ EXPORTS = [
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots", "gv_vec_dots_ex",
     "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep",
-    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_comm_rank", "gv_comm_size", "gv_bind_host_numa", "gv_set_timing",
+    "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_debug_force_multi", "gv_comm_rank", "gv_comm_size", "gv_bind_host_numa", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_set_decomp", "gv_tune_info", "gv_ingest_info", "gv_ingest_info2", "gv_set_expected_passes", "gv_copy_bandwidth", "gv_read_bandwidth",
 ]
 
@@ -177,6 +177,7 @@ def load():
     L.gv_ingest_info.argtypes = [vp, dp, dp]
     L.gv_ingest_info2.argtypes = [vp, C.POINTER(IngestStats)]
     L.gv_set_expected_passes.argtypes = [vp, C.c_int64]
+    L.gv_debug_force_multi.argtypes = [vp, C.c_int, C.c_int]
     L.gv_bind_host_numa.argtypes = [C.c_int, C.POINTER(C.c_int)]
     L.gv_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
     L.gv_read_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
@@ -534,6 +535,11 @@ class Shard:
 
     def set_overlap(self, tiles):
         self._ck(self.L.gv_set_overlap(self.h, tiles))
+
+    def force_multi(self, transport=1, delay_us=0):
+        """gv_debug_force_multi (test hook): this one-rank shard takes the sharded branches over an in-stream exchange
+        (1 loop-back with poisoning, 2 the 1-rank RCCL communicator, 3 both; 0 = off)."""
+        self._ck(self.L.gv_debug_force_multi(self.h, transport, delay_us))
 
     def set_timing(self, on):
         self._ck(self.L.gv_set_timing(self.h, int(on)))

@@ -204,12 +204,38 @@ struct LocalGroup {
 std::mutex g_groups_mu;
 std::map<int, std::shared_ptr<LocalGroup>> g_groups;
 
-bool is_multi(const gv_ctx* c) { return c->nranks > 1 && (c->comm || c->local || c->cb); }
+// (force_multi: a one-rank context made to take the sharded branches -- gv_debug_force_multi)
+bool is_multi(const gv_ctx* c) { return c->force_multi != 0 || (c->nranks > 1 && (c->comm || c->local || c->cb)); }
+
+// The exchange of a forced one-rank job: asynchronous and in-stream like RCCL's, with nothing for the host to wait on.  The
+// loop-back moves the message through scratch and poisons it in between, so a consumer that is not ordered behind the exchange
+// (a missing event edge between the side stream and the context's stream, a kernel enqueued ahead of its all-reduce) reads NaNs.
+static int forced_allreduce(gv_ctx* c, double* dev, size_t n, hipStream_t stream) {
+    if ((c->force_multi & 2) && c->comm)
+        NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, stream));
+    if (c->force_multi & 1) {
+        const int q = (stream == c->stream) ? 0 : 1;
+        if (c->loop_cap[q] < n) {
+            // (grown once per stream to the largest message of a job, w_n | w_n2; the wait is the test hook's, not the product's)
+            HIPCHK(c, hipStreamSynchronize(stream));
+            if (c->loop_buf[q]) (void)hipFree(c->loop_buf[q]);
+            c->loop_buf[q] = nullptr;
+            c->loop_cap[q] = 0;
+            const size_t cap = n > (size_t)(2 * c->npad + 64) ? n : (size_t)(2 * c->npad + 64);
+            HIPCHK(c, hipMalloc(&c->loop_buf[q], sizeof(double) * cap));
+            c->loop_cap[q] = cap;
+        }
+        gvk::loopback(stream, dev, c->loop_buf[q], (int64_t)n, c->loop_delay_us);
+        KCHK(c);
+    }
+    return 0;
+}
 
 // SUM all-reduce of n doubles living on the device, on the context's stream
 int comm_allreduce(gv_ctx* c, double* dev, size_t n) { return comm_allreduce_on(c, dev, n, c->stream); }
 int comm_allreduce_on(gv_ctx* c, double* dev, size_t n, hipStream_t stream) {
     if (!is_multi(c)) return 0;
+    if (c->force_multi) return forced_allreduce(c, dev, n, stream);
     if (c->comm) {
         NCCLCHK(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, stream));
         return 0;
@@ -710,7 +736,8 @@ int ax_overlapped(gv_ctx* c, int nv, const double* xa, const double* xb, double*
         KCHK(c);
     }
     HIPCHK(c, hipEventRecord(c->ev_comm, c->comm_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    if (!(c->force_multi & 4))     // (bit 4 of gv_debug_force_multi: fault injection for tests/test_gpu_forced_multi.py -- the join is dropped)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm, 0));
     return 0;
 }
 bool use_overlap(const gv_ctx* c) {   // nothing rank-local in here (have_stripes: every rank holds SOME re-encoded layout, whichever)
@@ -1104,6 +1131,7 @@ int gv_abi_version(void) { return GV_ABI_VERSION; }
 // lock: stream / event creation and destruction racing across threads is where a runtime is least exercised, and neither
 // call is on any hot path.
 static std::mutex g_lifecycle_mu;
+static void gv_destroy_locked(gv_ctx* c);      // the caller holds g_lifecycle_mu and has drained the streams
 
 int gv_create(int device, gv_ctx** out) {
     if (!out) return fail(nullptr, "gv_create: out is NULL");
@@ -1152,6 +1180,17 @@ int gv_create(int device, gv_ctx** out) {
     }
     if (const char* ov = getenv("GV_OVERLAP")) c->overlap_tiles = atoi(ov) > 64 ? 64 : (atoi(ov) < 0 ? 0 : atoi(ov));
     *out = c;
+    // GVAMP_FORCE_MULTI=<transport>[:<delay_us>] -- gv_debug_force_multi for every context of the process (drivers, bench.py)
+    if (const char* fm = getenv("GVAMP_FORCE_MULTI")) {
+        const int tr = atoi(fm);
+        const char* colon = strchr(fm, ':');
+        if (tr > 0 && gv_debug_force_multi(c, tr, colon ? atoi(colon + 1) : 0)) {
+            g_create_err = "gv_create: GVAMP_FORCE_MULTI: " + c->err;
+            *out = nullptr;
+            gv_destroy_locked(c);
+            return 1;
+        }
+    }
     return 0;
 }
 
@@ -1161,6 +1200,9 @@ void gv_destroy(gv_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     std::lock_guard<std::mutex> life(g_lifecycle_mu);
+    gv_destroy_locked(c);
+}
+static void gv_destroy_locked(gv_ctx* c) {
     c->comm = nullptr;
     c->comm_keep.reset();          // ncclCommDestroy if this was the last context sharing the communicator
     free_dataset(c);
@@ -1170,6 +1212,7 @@ void gv_destroy(gv_ctx* c) {
     if (c->host_pin) (void)hipHostFree(c->host_pin);
     if (c->mbox) (void)hipHostFree(c->mbox);
     if (c->pub_counter) (void)hipFree(c->pub_counter);
+    for (double* q : c->loop_buf) if (q) (void)hipFree(q);
     if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
     for (hipEvent_t e : c->xfer_ev) if (e) (void)hipEventDestroy(e);
     for (auto& r : c->ev_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1925,6 +1968,7 @@ static void comm_drop(gv_ctx* c) {
     c->cb_user = nullptr;
     c->rank = 0;
     c->nranks = 1;
+    c->force_multi = 0;
 }
 int gv_comm_share(gv_ctx* c, const gv_ctx* owner) {
     NEED(c, owner != nullptr && owner != c, "gv_comm_share: owner is NULL or the context itself");
@@ -2007,6 +2051,23 @@ int gv_comm_init_callback(gv_ctx* c, int nranks, int rank, gv_allreduce_fn fn, v
             if (back[i] != probe[i] * nranks)
                 return fail(c, "gv_comm_init_callback: all-reduce self-test failed (%g != %g)", back[i], probe[i] * nranks);
     }
+    return 0;
+}
+// Test hook (include/gvamp.h): transport 0 = off, 1 = loop-back through scratch, 2 = the 1-rank RCCL communicator (created here when
+// the context holds none), 3 = RCCL then the loop-back.  Only a context of a one-rank job may be forced.
+int gv_debug_force_multi(gv_ctx* c, int transport, int delay_us) {
+    NEED(c, transport >= 0 && transport <= 7 && (transport == 0 || (transport & 3)) && delay_us >= 0,
+         "gv_debug_force_multi: transport 0..3 (+ 4: fault injection), delay_us >= 0");
+    NEED(c, c->nranks == 1 && !c->local && !c->cb, "gv_debug_force_multi: only a one-rank context can be forced");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((transport & 2) && !c->comm) {
+        ncclUniqueId id;
+        NCCLCHK(c, ncclGetUniqueId(&id));
+        if (gv_comm_init(c, 1, 0, &id)) return 1;
+    }
+    c->force_multi = transport;
+    c->loop_delay_us = delay_us;
     return 0;
 }
 int gv_set_overlap(gv_ctx* c, int tiles) {

@@ -105,6 +105,12 @@ struct gv_ctx {
     hipEvent_t ev_chunk = nullptr, ev_comm = nullptr;
     gv_allreduce_fn cb = nullptr;          // host-callback communicator (gv_comm_init_callback)
     void* cb_user = nullptr;
+    // gv_debug_force_multi: a ONE-rank context takes every multi-rank branch; the exchange is an in-stream loop-back through
+    // scratch (1), the 1-rank RCCL communicator (2) or both (3) -- never a host synchronisation
+    int force_multi = 0;
+    int loop_delay_us = 0;
+    double* loop_buf[2] = {nullptr, nullptr};     // [0] the context's stream, [1] the side stream of the overlapped exchange
+    size_t loop_cap[2] = {0, 0};
 
     // instrumentation ------------------------------------------------------------------------------
     int timing = 0;
@@ -161,6 +167,8 @@ void axpby(hipStream_t s, double* out, double a, const double* x, double b, cons
 void mask_copy(hipStream_t s, double* out, const double* in, const uint32_t* mask2, int64_t npad);
 void copy(hipStream_t s, double* dst, const double* src, int64_t n);                  // dst = src (kernel, not hipMemcpyAsync)
 void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n);     // p = fma(beta, p, z)
+// one-rank all-reduce that moves the message through scratch and poisons it meanwhile (gv_debug_force_multi)
+void loopback(hipStream_t s, double* buf, double* scratch, int64_t n, int delay_us);
 // K dot products <x[k], y[k]> over n elements -> red_out[0..K)
 void dots(hipStream_t s, int K, const double* const* x, const double* const* y, int64_t n, double* partial,
           double* out);

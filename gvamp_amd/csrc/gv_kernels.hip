@@ -406,6 +406,26 @@ __global__ void k_mask_copy(double* out, const double* in, const uint32_t* mask2
     uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
     out[n] = present ? in[n] : 0.0;
 }
+// ---- loop-back transport (gv_debug_force_multi): a one-rank all-reduce that really moves the message.  k_loop_out takes the
+// buffer to scratch and POISONS it (a quiet NaN with a recognisable payload), k_loop_wait holds the stream for a bounded number
+// of microseconds, k_loop_in brings it back.  Whoever reads the buffer without being ordered behind the exchange reads NaNs.
+__global__ void k_loop_out(double* __restrict__ buf, double* __restrict__ scratch, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    scratch[i] = buf[i];
+    buf[i] = __longlong_as_double(0x7ff8000000c0ffeeLL);
+}
+__global__ void k_loop_wait(int us) {
+    // wall_clock64 ticks at 100 MHz on gfx950; bounded by the iteration count as well (a stuck clock must not hang the stream)
+    const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)us * 100ull;
+    for (int it = 0; it < (1 << 22) && wall_clock64() - t0 < ticks; it++) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_loop_in(double* __restrict__ buf, double* __restrict__ scratch, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    buf[i] = scratch[i];
+    scratch[i] = __longlong_as_double(0x7ff8000000c0ffeeLL);
+}
 __global__ void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, int64_t n2) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1203,6 +1223,12 @@ void axpby(hipStream_t s, double* out, double a, const double* x, double b, cons
 void copy(hipStream_t s, double* dst, const double* src, int64_t n) {
     if (n <= 0 || dst == src) return;
     hipLaunchKernelGGL(k_vcopy, dim3(nblk(n, 256)), dim3(256), 0, s, dst, src, n);
+}
+void loopback(hipStream_t s, double* buf, double* scratch, int64_t n, int delay_us) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_loop_out, dim3(nblk(n, 256)), dim3(256), 0, s, buf, scratch, n);
+    if (delay_us > 0) hipLaunchKernelGGL(k_loop_wait, dim3(1), dim3(1), 0, s, delay_us > 5000 ? 5000 : delay_us);
+    hipLaunchKernelGGL(k_loop_in, dim3(nblk(n, 256)), dim3(256), 0, s, buf, scratch, n);
 }
 void p_update(hipStream_t s, double* p, const double* z, double beta, int64_t n) {
     if (n <= 0) return;            // an empty shard (M == 0) steps through the solver with empty vectors

@@ -875,15 +875,16 @@ struct HalfOp {
 int gv_cg_solve_aat2(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                      int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
                      double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b) {
-    return gv_cg_solve_aat2w(c, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, st_a, st_b, relres_a, relres_b,
-                             aat_mu_a, ata_mu_b, nullptr);
+    // (without gv_aat_warm::pre_x nothing writes v_a)
+    return gv_cg_solve_aat2w(c, const_cast<gv_vec*>(v_a), mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, st_a, st_b, relres_a,
+                             relres_b, aat_mu_a, ata_mu_b, nullptr);
 }
 
 // gv_aat_warm (gvamp.h).  aat_mu_start_a: A A^T mu_start_a, as the previous call left it in aat_mu_a -- the initial residual of
 // the warm-started N-space solve (denoiserXXT.cpp:76-78) is then formed without its ATx + Ax pair.  accumulate_at_mu_a: A^T mu_a
 // is built from the A^T p_k every application starts with (A^T mu_a = A^T mu_start_a + sum_k alpha_k A^T p_k) instead of by a
 // closing ATx pass; A^T mu_start_a comes from at_mu_start_a, or from the explicit opening application, or is 0 for a zero start.
-int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* st_a, gv_cg_stats* st_b,
                       double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_aat_warm* wm) {
     gv_aat_warm nowarm{};
@@ -1280,7 +1281,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, const gv_vec* v_a, const gv_vec* mu_start_a, co
                 h->pending = false;
                 if (h == &hz) continue;                                            // the rider's product is in place
                 if (h == &hr) {                                                    // v_a = y - A r2 is complete: solve a can start
-                    gvk::axpby(s, const_cast<double*>(v_a->d), 1.0, v_a->d, -1.0, hr.dst, n);
+                    gvk::axpby(s, v_a->d, 1.0, v_a->d, -1.0, hr.dst, n);
                     MIX_TRY(a_start());
                     continue;
                 }

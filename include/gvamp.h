@@ -28,9 +28,11 @@ typedef struct gv_vec gv_vec;
 
 /* Bumped whenever a struct of this header grows or a default changes, so that a binding compiled against an older header fails
  * its version check instead of overrunning a buffer.  History: 1 rounds 1-2; 2 round 3 (gv_decomp_info grew by whole_quads,
- * the context defaults became kernel mode 1 / no raw rows / layout auto) and round 4 (gv_ingest_info2, gv_set_expected_passes).
+ * the context defaults became kernel mode 1 / no raw rows / layout auto) and round 4 (gv_ingest_info2, gv_set_expected_passes);
+ * 3 round 5 (gv_cg_solve_aat2w takes v_a as the in/out vector it is; layout auto takes ONE resident layout unless the caller
+ * announces a long run -- gv_set_expected_passes; gv_debug_force_multi).
  * A binding checks  gv_abi_version() == GV_ABI_VERSION  once, before anything else (INTEGRATION.md section B does). */
-#define GV_ABI_VERSION 2
+#define GV_ABI_VERSION 3
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int gv_abi_version(void);
@@ -266,7 +268,7 @@ typedef struct gv_aat_warm {
     gv_vec* ata_v_b;            /* as in gv_cg_warm: A^T A v_b of the zero-started M-space solve b, captured or handed in */
     int have_ata_v_b;
     /* pre_x / pre_out: the right-hand side of solve a is completed inside the call -- pre_out = A pre_x, then v_a <- v_a - pre_out
-     * (v_a is UPDATED IN PLACE although the prototype says const): v = y - A r2 of denoiserXXT.cpp:40-42 with v_a = y, pre_x = r2.
+     * (v_a is an in/out argument of gv_cg_solve_aat2w for this reason): v = y - A r2 of denoiserXXT.cpp:40-42 with v_a = y, pre_x = r2.
      * That Ax shares its pass with the first half-application of solve b, which puts the two solves in phase from the start
      * (one pass fewer than forming v_a outside).  ride_x / ride_out: ride_out = A ride_x for an M-vector unrelated to the solves
      * (z1 = A x1_hat, vamp.cpp:429), taken in an Ax pass that has a slot free, else by a pass of its own at the end. */
@@ -275,7 +277,8 @@ typedef struct gv_aat_warm {
     const gv_vec* ride_x;
     gv_vec* ride_out;
 } gv_aat_warm;
-int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
+/* v_a: read only, unless warm->pre_x is set -- then it is updated in place (see pre_x above). */
+int gv_cg_solve_aat2w(gv_ctx* ctx, gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,
                       int max_iter, gv_vec* mu_a, gv_vec* at_mu_a, gv_vec* mu_b, gv_cg_stats* stats_a, gv_cg_stats* stats_b,
                       double* relres_a, double* relres_b, gv_vec* aat_mu_a, gv_vec* ata_mu_b, const gv_aat_warm* warm);
 
@@ -283,7 +286,8 @@ int gv_cg_solve_aat2w(gv_ctx* ctx, const gv_vec* v_a, const gv_vec* mu_start_a, 
  * data::pvals_calc (data.cpp:1108-1226, one estimator): leave-one-out t-test p-value of every local marker,
  * pvals[M].  z1 = A x1_hat and y (filtered phenotype) are N-space handles, x1_hat the M-space estimate (the
  * sqrt(N)-scaled x1_hat of vamp.cpp, as passed at :765).  One pass over the genotype shard (two digit vectors, y_mod
- * and y_mod^2, share the 16 MFMA columns) + exact per-marker genotype counts; Student-t tail evaluated on the host. */
+ * and y_mod^2, share the 16 MFMA columns) + exact per-marker genotype counts; the regression test and its Student-t tail run in
+ * the epilogue of that pass (k_fin_pvals, gv_pval_dev.h), only the p-values cross PCIe. */
 int gv_pvals_loo(gv_ctx* ctx, const gv_vec* z1, const gv_vec* y, const gv_vec* x1_hat, double* pvals);
 /* data::pvals_calc_LOCO (data.cpp:1235-1353): chrom[M] in 1..23 (read_chromosome_info, data.cpp:346-380); per
  * chromosome one Ax (with its cross-rank all-reduce) + one marker pass.  Markers of other chromosomes get 0. */
@@ -325,6 +329,18 @@ int gv_comm_share(gv_ctx* ctx, const gv_ctx* owner);
  * that many chunks of individuals and all-reduces each slice on a side HIP stream while the next chunk decodes; 0 / 1 = one
  * message after the whole pass (default; also set by the environment variable GV_OVERLAP).  Bit-identical results. */
 int gv_set_overlap(gv_ctx* ctx, int tiles);
+/* TEST HOOK, never part of a production job.  A context of a ONE-rank job takes every branch a sharded job takes -- the N-vector
+ * exchange inside data::Ax (data.cpp:928/:995), the packed scalar all-reduces (utilities.cpp:203), k_finalize + all-reduce instead of
+ * the one-rank shortcuts of the device-resident CG, the side-stream exchange of gv_set_overlap -- with an exchange that is
+ * asynchronous and in-stream like RCCL's (no host synchronisation, unlike the gv_comm_init_local / _callback transports):
+ *   transport 1: loop-back kernels -- the message moves to scratch, the buffer is filled with NaNs, (delay_us later) it moves back;
+ *                a consumer that is not stream-ordered behind its exchange reads NaNs;
+ *   transport 2: ncclAllReduce on a 1-rank RCCL communicator (created here if the context holds none);   3: both, RCCL first;
+ *   transport 0: back to the plain one-rank paths;   + 4: fault injection -- the overlapped exchange drops its closing event edge
+ *                (the harness must then SEE wrong results: tests/test_gpu_forced_multi.py checks that it has teeth).
+ * Sums over one rank are the identity, so every result must equal the plain one-rank run BIT FOR BIT (tests/test_gpu_forced_multi.py).
+ * Also: environment variable GVAMP_FORCE_MULTI=<transport>[:<delay_us>] at gv_create (drivers, bench.py). */
+int gv_debug_force_multi(gv_ctx* ctx, int transport, int delay_us);
 int gv_comm_rank(const gv_ctx* ctx);
 /* One process per GPU on a multi-socket node: restricts the calling thread -- and every thread it starts afterwards -- to the
  * CPUs of the NUMA node `device` hangs off (sysfs: the PCI device's numa_node, the node's cpulist), intersected with the CPUs it

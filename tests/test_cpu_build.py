@@ -32,7 +32,7 @@ def test_libgvamp_exports_every_declared_symbol(built):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert set(names) == set(capi.EXPORTS), set(names) ^ set(capi.EXPORTS)
-    assert L.gv_abi_version() == capi.ABI_VERSION == 2
+    assert L.gv_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_libgvamp_host_exports(built):
