@@ -38,9 +38,14 @@ def parse():
     ap.add_argument("--CG-max-iter", type=int, default=50)
     ap.add_argument("--ld-block", type=int, default=64, help="second VAMP setting: markers per LD block (0 = skip that leg)")
     ap.add_argument("--ld-ppm", type=int, default=900000, help="second VAMP setting: within-block copy probability, 1e-6")
-    ap.add_argument("--no-tile-leg", action="store_true", help="skip the closing measurement of the one-layout (tile) kernels")
+    ap.add_argument("--no-side-leg", "--no-tile-leg", dest="no_side_leg", action="store_true",
+                    help="skip the closing measurement of the same step on the OTHER resident layout")
+    ap.add_argument("--no-rows", action="store_true", help="skip the mid-size rows (config 2 / one 8-GPU shard / config 4 / config 5)")
+    ap.add_argument("--rows-only", action="store_true", help="only the mid-size rows: prints {\"rows\": [...]} (profiles/r*_rows.json)")
+    ap.add_argument("--rows-layout", type=int, default=0, help="resident layout of the rows: 0 = what the drivers get for a run of that "
+                    "length (gv_set_expected_passes(iterations x 12) -> one tile layout), 1 / 2 = fixed")
     ap.add_argument("--layout", type=int, default=0, help="resident re-encoding of kernel mode 1: 0 = leave the library's default "
-                    "(auto: two stripe sets when they fit the free HBM, else the tile layout), 1 = two stripe sets "
+                    "(auto: one tile layout unless the run is announced as long and two stripe sets fit), 1 = two stripe sets "
                     "(2 x M*N/4 bytes), 2 = one tile layout (M*N/4 bytes)")
     ap.add_argument("--fuse-solves", type=int, default=4,
                     help="0 = the reference's sequence of matvecs, 1 = LMMSE and Onsager CG share passes (bit-identical), "
@@ -63,12 +68,18 @@ def alg_bytes(N, M):
 
 
 def cpu_baseline(N, seed, want_markers, device):
-    """Oracle (CPU restatement, OpenMP) timed on a bounded sample: the first `m` markers of the same synthetic matrix, one
-    Ax + one ATx per repetition, at several thread counts (all hardware threads, one per physical core, a quarter): the best is
-    `value`, every setting is listed.  A port, not the reference (unbuildable here): no credit either way is claimed from the
-    GPU / CPU ratio -- the roofline fraction is what measures the kernels."""
+    """Oracle (CPU restatement, OpenMP) timed on the GPU box's host cores, per SURVEY 8(d): a timing-only build of the port
+    (-O3 -march=native -fopenmp, compiled on this host: oracle/Makefile `timing`; the parity library keeps its own flags), on a
+    bounded sample -- the first `m` markers of the same synthetic matrix:
+      * one Ax + one ATx per repetition at several thread counts (all hardware threads, half, a quarter): the best is `value`;
+      * REAL VAMP iterations of the port: config 1 whole (N=2000 x M=10000) and the m-marker slice at full N -- the measured
+        second iteration beside what the matvec model (n_ax * t_ax + n_atx * t_atx) says for that same iteration, so that the
+        extrapolation to the headline size rests on a checked model.
+    A port, not the reference (unbuildable here): no credit either way is claimed from the GPU / CPU ratio -- the roofline
+    fraction is what measures the kernels."""
     from gvamp_amd import capi
     from oracle import gvoracle as go
+    flags = go.use_timing_build()
     hw = os.cpu_count() or 1
     mb = (N + 3) // 4
     m = want_markers or max(256, min(20000, int(2.0e9 // mb)))
@@ -82,7 +93,7 @@ def cpu_baseline(N, seed, want_markers, device):
     tried = []
     for nt in sorted({hw, max(1, hw // 2), max(1, hw // 4)}, reverse=True):
         reps, t_ax, t_atx = 0, 0.0, 0.0
-        while reps < 1 or (t_ax + t_atx < 5.0 and reps < 30):
+        while reps < 1 or (t_ax + t_atx < 3.0 and reps < 30):
             t1 = time.time()
             z = go.ax(bed, N, m, mave, msig, x, nthreads=nt)
             t2 = time.time()
@@ -94,13 +105,37 @@ def cpu_baseline(N, seed, want_markers, device):
         tried.append({"threads": nt, "GBps": round(2 * alg_bytes(N, m) * reps / (t_ax + t_atx) / 1e9, 3),
                       "ax_s": t_ax / reps, "atx_s": t_atx / reps, "reps": reps})
     best = max(tried, key=lambda t: t["GBps"])
-    return {"value": best["GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "port", "sample_markers": m,
-            "ax_s": best["ax_s"], "atx_s": best["atx_s"], "hardware_threads": hw,
-            "thread_sweep": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()} for t in tried],
-            "sample": "oracle/ (OpenMP) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix; best of %s threads: "
-                      "%d threads, Ax %.3f s, ATx %.3f s per call (untuned scalar port; the reference itself cannot be built "
-                      "here)" % (m, N, "/".join(str(t["threads"]) for t in tried), best["threads"], best["ax_s"], best["atx_s"]),
-            "cpu_model": _cpu_model()}
+    out = {"value": best["GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "port", "flags": flags, "sample_markers": m,
+           "ax_s": best["ax_s"], "atx_s": best["atx_s"], "hardware_threads": hw,
+           "thread_sweep": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in t.items()} for t in tried],
+           "sample": "oracle/ (OpenMP, %s) Ax+ATx on the first %d markers x N=%d of the same synthetic matrix; best of %s threads: "
+                     "%d threads, Ax %.3f s, ATx %.3f s per call (scalar port; the reference itself cannot be built here)"
+                     % (flags.split(" (")[0], m, N, "/".join(str(t["threads"]) for t in tried), best["threads"], best["ax_s"], best["atx_s"]),
+           "cpu_model": _cpu_model()}
+    # ---- real VAMP iterations of the port, and the matvec model checked against them
+    nt = best["threads"]
+    measured = {}
+    try:
+        kw = dict(iterations=2, CG_max_iter=50, rho=0.5, seed=1, gam1=1e-8, gamw=2.0, nthreads=nt)
+        beta, y = go.sim_phen(bed, N, m, 0.5, max(1, m // 100), 1, nthreads=nt)
+        r = go.infere(bed, N, m, y, None, None, true_signal=beta, **kw)
+        t2 = r.trace[-1]
+        model = t2["n_ax"] * best["ax_s"] + t2["n_atx"] * best["atx_s"]
+        measured["slice_N%d_M%d" % (N, m)] = {"seconds": round(t2["seconds"], 3), "n_ax": int(t2["n_ax"]), "n_atx": int(t2["n_atx"]),
+                                              "matvec_model_s": round(model, 3), "measured_over_model": round(t2["seconds"] / model, 3)}
+        out["measured_over_model"] = round(t2["seconds"] / model, 3)
+        with capi.Shard(2000, 10000, device=device) as s1:          # config 1 whole (sim.cpp N=2000 M=10000, 3 mixture components)
+            s1.set_layout(True, False)
+            s1.synth_bed(seed, 5000)
+            bed1 = s1.download_bed()
+        b1, y1 = go.sim_phen(bed1, 2000, 10000, 0.5, 100, 1, nthreads=nt)
+        r1 = go.infere(bed1, 2000, 10000, y1, [0.90, 0.07, 0.03], [0, 0.001, 0.01], true_signal=b1, **dict(kw, iterations=3))
+        measured["config1_N2000_M10000"] = {"seconds": round(float(np.mean([t["seconds"] for t in r1.trace[1:]])), 4),
+                                            "n_ax": int(r1.trace[-1]["n_ax"]), "n_atx": int(r1.trace[-1]["n_atx"])}
+    except Exception as e:      # noqa: BLE001  (a baseline leg must never take the bench line down)
+        measured["error"] = repr(e)
+    out["vamp_iter_s_measured"] = measured
+    return out
 
 
 def kernel_sources_sha256():
@@ -121,6 +156,60 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+ROWS = [
+    # (key, what, N, M, iterations, extra arguments of infere)
+    ("config2", "config 2: linear N=100k x M=500k, CG-max-iter 50", 100000, 500000, 5, {}),
+    ("shard_8gpu", "one shard of the 8-GPU headline job on its own: N=400k x M=125k (no exchange)", 400000, 125000, 6, {}),
+    ("config4", "config 4: probit (--model bin_class) N=100k x M=500k", 100000, 500000, 5, dict(model="bin_class", gam1=1e-8, gamw=1.0)),
+    ("config5", "config 5: --use-XXT-denoiser 1 (matrix-free N-space CG) N=50k x M=200k", 50000, 200000, 4, dict(use_XXT_denoiser=1)),
+]
+
+
+def run_rows(a, device):
+    """The mid-size rows of SURVEY 8(d) / BASELINE configs 2, 4, 5 and the per-GPU shard of config 3: whole VAMP iterations of the
+    host loop on a fresh shard each, --fuse-solves 4 (the drivers' default) and 0 (the reference's own sequence of products) side
+    by side on the SAME resident shard.  it/s over iterations 2..; pass_GBps = passes over the shard x algorithmic bytes / time;
+    frac = that over the 8 TB/s peak.  The layout is what a driver run of that length gets (gv_set_expected_passes(iterations x 12))
+    unless --rows-layout fixes it."""
+    from gvamp_amd import capi, hostapi
+    rows = []
+    for key, what, N, M, iterations, kw in ROWS:
+        with capi.Shard(N, M, device=device) as sh:
+            if a.rows_layout:
+                sh.set_layout(False, a.rows_layout)
+            else:
+                sh.set_expected_passes(iterations * 12)
+            t = time.perf_counter()
+            sh.synth_bed(4242, 5000)
+            sh.compute_markers_statistics()
+            sh.synchronize()
+            ingest = time.perf_counter() - t
+            beta, y = hostapi.sim_phen(sh, 0.5, max(1, M // 100), 1)
+            if kw.get("model") == "bin_class":
+                y = (y > 0).astype(float)                      # case / control labels from the simulated liability
+            row = {"row": key, "what": what, "N": N, "M": M, "layout": sh.get_layout(), "ingest_s": round(ingest, 3),
+                   "alg_GB_per_pass": round(alg_bytes(N, M) / 1e9, 3)}
+            xs = {}
+            for fuse in (4, 0):
+                r = hostapi.infere_linear(sh, y, None, None, iterations=iterations, CG_max_iter=a.CG_max_iter, rho=0.5, seed=1,
+                                          true_signal=beta, history=False, fuse_solves=fuse, **kw)
+                its = r.trace
+                tail = its[1:] if len(its) > 1 else its
+                secs = sum(t["seconds"] for t in tail)
+                npass = sum(t["n_ax_pass"] + t["n_atx_pass"] for t in tail)
+                gbps = npass * alg_bytes(N, M) / secs / 1e9
+                xs[fuse] = r.x_est
+                row["fuse_%d" % fuse] = {
+                    "iters_per_s": round(len(tail) / secs, 2), "passes": npass, "pass_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4),
+                    "seconds_per_iter": [round(t["seconds"], 5) for t in its], "cg_iters": [t["cg_iters"] for t in its],
+                    "n_ax_pass": [t["n_ax_pass"] for t in its], "n_atx_pass": [t["n_atx_pass"] for t in its]}
+            den = float(np.linalg.norm(xs[0]))
+            row["x_hat_rel_l2_fuse4_vs_0"] = float(np.linalg.norm(xs[4] - xs[0]) / den) if den > 0 else None
+            row["corr_with_truth"] = round(float(np.corrcoef(xs[4], beta)[0, 1]), 4)
+        rows.append(row)
+    return rows
 
 
 def spawn_ranks(a):
@@ -203,6 +292,10 @@ def main():
         if world > 1 or force_dist:
             dist.barrier()
 
+    if a.rows_only:
+        if rank == 0:
+            print(json.dumps({"rows": run_rows(a, local_rank), "rows_layout": a.rows_layout or "as the drivers (expected passes)"}), flush=True)
+        return
     N, Mt = a.N, a.Mt
     M, S = divide_work(Mt, world, rank)
     sh = capi.Shard(N, M, Mt=Mt, S=S, device=local_rank)
@@ -215,6 +308,10 @@ def main():
         sh.set_layout(True, False)
         sh.set_kernel_mode(0)
     assert sh.get_kernel_mode() == a.mode
+    # what this run is about to do with the shard (gv_set_expected_passes, as the drivers announce iterations x 12): the timed steps
+    # and the VAMP legs (levels 4 / 0 / 3, then the LD genotypes at 4 / 0), ~12 ATx passes per iteration
+    planned_passes = a.warmup + a.steps + a.vamp_iterations * 12 * (3 + (2 if a.ld_block > 0 else 0))
+    sh.set_expected_passes(planned_passes)
     t0 = time.time()
     sh.synth_bed(a.seed, 5000)
     sh.compute_markers_statistics()
@@ -322,8 +419,8 @@ def main():
                    "markers_per_gpu": M, "kernel_mode": a.mode, "parallelism": "marker-sharded x%d" % world,
                    "resident_layout": ("fp64 raw rows" if a.mode == 0 else "two stripe sets, 2 x M*N/4 bytes" if layout == 1
                                        else "one tile layout, M*N/4 bytes"),
-                   "engine": ("library defaults (no gv_set_kernel_mode / gv_set_layout call)" if engine_defaults
-                              else "--mode %d --layout %d" % (a.mode, a.layout)),
+                   "engine": ("library defaults (no gv_set_kernel_mode / gv_set_layout call; gv_set_expected_passes(%d) = what this "
+                              "run makes)" % planned_passes if engine_defaults else "--mode %d --layout %d" % (a.mode, a.layout)),
                    "ingest_s": round(t_ingest, 2), "ingest_alloc_s": round(t_alloc, 2), "ingest_fill_s": round(t_fill, 2),
                    "tune_s": round(tune_s, 3), "tune_source": tune_src},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
@@ -490,14 +587,28 @@ def main():
             v = out["vamp"].get("reference_sequence", out["vamp"])             # the reference's own matvec counts
             est = [(v["n_ax"][i] * cb["ax_s"] + v["n_atx"][i] * cb["atx_s"]) * f for i in range(1, len(v["n_ax"]))]
             cb["vamp_iter_s_extrapolated"] = round(sum(est) / len(est), 1)
+            if cb.get("measured_over_model"):
+                cb["vamp_iter_s_extrapolated_x_measured_over_model"] = round(sum(est) / len(est) * cb["measured_over_model"], 1)
             cb["vamp_note"] = ("seconds per VAMP iteration the CPU port would need for the matvec counts of the reference "
-                               "sequence (vamp.reference_sequence): "
-                               "(n_ax*t_ax + n_atx*t_atx) measured on the sample, scaled linearly by Mt/sample_markers")
+                               "sequence (vamp.reference_sequence): (n_ax*t_ax + n_atx*t_atx) measured on the sample, scaled "
+                               "linearly by Mt/sample_markers; `vamp_iter_s_measured` holds REAL iterations of the port in this run "
+                               "(config 1 whole; the sample slice at full N) and `measured_over_model` what that model missed on "
+                               "the slice (denoiser, EM, vector updates)")
         out["cpu_baseline"] = cb
     sh.close()
-    # ---- the same operator on ONE resident layout (gv_set_layout(.., 2): M*N/4 bytes instead of 2 x M*N/4), measured in the same
-    # process on the same box, and checked bit for bit against the two-layout result above --------------------------------
-    if a.mode == 1 and layout_everywhere == 1 and not a.no_tile_leg:
+    # ---- the same operator on the OTHER resident layout (main leg on the one tile layout: two stripe sets, 2 x M*N/4 bytes, announced
+    # as a long run would announce itself; main leg on two stripe sets: the tile layout), measured in the same process on the same box,
+    # and checked bit for bit against the main leg's result --------------------------------------------------------------------
+    other = 1 if layout_everywhere == 2 else (2 if layout_everywhere == 1 else 0)
+    if other == 1:
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+        if 2.0 * M * ((N + 3) // 4) + 4e9 > 0.92 * free_b:
+            other = 0                       # two stripe sets do not fit this GPU: no side leg
+        if world > 1:
+            t = torch.tensor([float(other)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            other = int(t.item())
+    if a.mode == 1 and other != 0 and not a.no_side_leg:
         barrier()
         # this leg always MEASURES its decompositions (no cache, no shipped table): its tune_s is what a cold first contact with a
         # shape costs on this box, whatever the main leg found in the cache or in gv_tune_builtin.h
@@ -505,13 +616,13 @@ def main():
         os.environ["GV_TUNE_CACHE"] = "0"
         os.environ["GV_TUNE_BUILTIN"] = "0"
         with capi.Shard(N, M, Mt=Mt, S=S, device=local_rank) as st:
-            st.set_layout(False, 2)
+            st.set_layout(False, other)
             st.set_kernel_mode(1)
             t1 = time.time()
             st.synth_bed(a.seed, 5000)
             st.compute_markers_statistics()
             t_in = time.time() - t1
-            tile_ingest = st.ingest_stats()
+            side_ingest = st.ingest_stats()
             if world > 1 or force_dist:
                 uid = [capi.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
@@ -543,16 +654,18 @@ def main():
                 same = bool(t.item() == 1.0)
             m_ax = c2["ms_ax_kernel"] / max(c2["n_ax_kernel"], 1)
             m_atx = c2["ms_atx_kernel"] / max(c2["n_atx_kernel"], 1)
-            out["tile_layout"] = {
-                "what": "the same step on ONE resident re-encoding that serves Ax and ATx (docs/history/rounds1-3.md section 3): resident genotype "
-                        "bytes per GPU %.1f GB instead of %.1f GB" % (M * ((N + 3) // 4) / 1e9, 2 * M * ((N + 3) // 4) / 1e9),
+            one_gb, two_gb = M * ((N + 3) // 4) / 1e9, 2 * M * ((N + 3) // 4) / 1e9
+            out["two_stripe_sets" if other == 1 else "tile_layout"] = {
+                "what": ("the same step on TWO resident re-encodings, one per product (gv_set_layout(.., 1); what auto builds for a run "
+                         "announced as >= 1000 ATx passes): resident genotype bytes per GPU %.1f GB instead of %.1f GB" % (two_gb, one_gb))
+                        if other == 1 else
+                        ("the same step on ONE resident re-encoding that serves Ax and ATx (docs/history/rounds1-3.md section 3): resident "
+                         "genotype bytes per GPU %.1f GB instead of %.1f GB" % (one_gb, two_gb)),
                 "value_GBps": round(job_bytes * nst / dt2 / 1e9, 2), "ms_per_step": round(dt2 / nst * 1e3, 4), "steps": nst,
                 "ax": {"avg_ms": round(m_ax, 4), "GBps": round(shard_bytes / (m_ax * 1e-3) / 1e9, 1) if m_ax > 0 else None},
                 "atx": {"avg_ms": round(m_atx, 4), "GBps": round(shard_bytes / (m_atx * 1e-3) / 1e9, 1) if m_atx > 0 else None},
-                "bit_identical_to_two_layouts": same, "ingest_s": round(t_in, 2), "ingest_alloc_s": round(tile_ingest["alloc_s"], 2),
-                "ingest_fill_s": round(tile_ingest["fill_s"], 2), "resident_GB": round(tile_ingest["resident_GB"], 1),
-                "note": "what gv_set_layout(.., 3) picks when gv_set_expected_passes says the run is short (< 1000 ATx passes): half the "
-                        "bytes to allocate and fill",
+                "bit_identical_to_main_leg": same, "ingest_s": round(t_in, 2), "ingest_alloc_s": round(side_ingest["alloc_s"], 2),
+                "ingest_fill_s": round(side_ingest["fill_s"], 2), "resident_GB": round(side_ingest["resident_GB"], 1),
                 "tune_s": round(tt_s, 3), "tune_source": tt_src,
                 "decomposition": st.decomp()}
         for k, v in cold_env.items():
@@ -560,6 +673,8 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    if rank == 0 and world == 1 and not a.no_rows:
+        out["rows"] = run_rows(a, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

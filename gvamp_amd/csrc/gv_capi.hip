@@ -1291,8 +1291,14 @@ static int read_slab(int fd, int64_t off, uint8_t* dst, size_t nbytes) {
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    th.reserve((size_t)nt);
+    int started = 1;                            // ranges [1, started) have a thread; the rest are read by this one
+    try {
+        for (; started < nt; started++) th.emplace_back(work, started);
+    } catch (...) {
+    }
     work(0);
+    for (int t = started; t < nt; t++) work(t);
     for (std::thread& x : th) x.join();
     for (int v : st) if (v > 0) return v;      // a real I/O error wins over a short file
     for (int v : st) if (v) return v;
@@ -1315,18 +1321,19 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         // stripe sets again would fail at exactly the sizes auto exists for
         c->want_tile = pl.layout == 1;
     } else if (c->want_auto && c->want_stripes) {
-        // gv_set_layout(.., 3): two stripe sets (the faster ATx, by 2-5 %) when they fit the free HBM with room for the
-        // vectors and scratch AND the run is long enough to earn the second set back, else the one tile layout (half the bytes)
+        // gv_set_layout(.., 3), the default: ONE tile layout -- half the bytes to allocate and fill -- unless the caller has announced a
+        // long run (gv_set_expected_passes >= 1000) AND two stripe sets (the faster ATx, by 2-5 %) fit the free HBM with room for the
+        // vectors and scratch.  The second set costs its bytes once more at ingest -- allocated at 25-400 GB/s depending on whether
+        // the driver is still wiping freed memory, filled at ~400 GB/s: 0.5-4.3 s per 100 GB measured -- and returns ~3 % of one ATx
+        // pass (bytes / 6.5 TB/s) per pass: break-even between 500 and 9 000 passes whatever the shard size (both sides scale with the
+        // bytes).  A run that says nothing about its length (a bare binding, bench.py's five iterations: 5.3 of 6.4 s to solution were
+        // that allocation in round 4) is not assumed to be long.
         size_t free_b = 0, total_b = 0;
         HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
         const double one = (double)((M + 63) / 64) * (double)((c->N + 255) / 256) * 4096.0;
         const double other = (c->want_raw ? (double)M * (double)P : 32768.0 * (double)P) + 64.0 * (double)(M + c->npad) + 2.0e9;
-        c->want_tile = 2.0 * one + other > 0.92 * (double)free_b;
-        // Time-aware part (gv_set_expected_passes; 0 = unknown: memory decides alone).  The second stripe set costs its bytes once
-        // more at ingest -- allocated at 25-400 GB/s depending on whether the driver is still wiping freed memory, filled at
-        // ~400 GB/s: 0.5-4.3 s per 100 GB measured -- and returns ~3 % of one ATx pass (bytes / 6.5 TB/s) per pass: break-even
-        // between 500 and 9 000 passes.  Below 1 000 expected passes the one-layout ingest wins the run.
-        if (!c->want_tile && c->expected_passes > 0 && c->expected_passes < 1000) c->want_tile = true;
+        const bool two_fit = 2.0 * one + other <= 0.92 * (double)free_b;
+        c->want_tile = !(two_fit && c->expected_passes >= 1000);
     }
     const int want_layout = c->want_tile ? 1 : 0;
     const bool rebuild = c->want_stripes && (pl.layout != want_layout || !(want_layout ? pl.tiles : pl.stripes_m));
@@ -1363,13 +1370,10 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
                 // moves the kernel that streams it by 1.5-3.5 % (docs/history/rounds1-3.md section 4.2: nine ingests on one box, Ax 14.9-15.6 ms and
                 // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
                 // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
-                // came first.  GV_STRIPE_SLAB=0 (or an allocation that large failing) falls back to one allocation per set.
-                const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
-                             sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
-                const char* se = getenv("GV_STRIPE_SLAB");
+                // came first.  An allocation that large failing falls back to one allocation per set.
                 void* slab = nullptr;
                 const size_t al = (size_t)1 << 30, off_m = (sz_n + al - 1) / al * al;
-                if (!(se && atoi(se) == 0) && hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
+                if (hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
                     c->stripes_slab = slab;
                     pl.stripes_n = slab;
                     pl.stripes_m = (char*)slab + off_m;
@@ -1427,14 +1431,27 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
     }
     // chunks 0 and 1 of a file come off the file system while the layout is still being allocated
     int pre_read = 0, pre_io[2] = {0, 0};
-    for (int b = 0; b < 2 && file && !rc && (int64_t)b * CH < M; b++) {
-        const int64_t m0 = (int64_t)b * CH, mc = M - m0 < CH ? M - m0 : CH;
-        pre_io[b] = read_slab(fileno(file), file_off + m0 * c->mbytes, stage[b], (size_t)mc * c->mbytes);
-        pre_read = b + 1;
+    try {
+        for (int b = 0; b < 2 && file && !rc && (int64_t)b * CH < M; b++) {
+            const int64_t m0 = (int64_t)b * CH, mc = M - m0 < CH ? M - m0 : CH;
+            pre_io[b] = read_slab(fileno(file), file_off + m0 * c->mbytes, stage[b], (size_t)mc * c->mbytes);
+            pre_read = b + 1;
+        }
+    } catch (const std::exception& e) {      // (no reader thread to be had: the allocation thread is still joined below)
+        rc = fail(c, "ingest: reading the .bed file failed: %s", e.what());
     }
     const double prep_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count();
     if (alloc_thr.joinable()) alloc_thr.join();
-    if (!alloc_err.empty() && !rc) rc = fail(c, "ingest: allocating the resident layout failed: %s", alloc_err.c_str());
+    if (!alloc_err.empty()) {
+        // nothing half-built stays behind: a retry on this context must allocate everything again (rebuild is decided from these
+        // pointers), and the streaming kernels must never meet a layout whose digit / partial-sum buffers are missing
+        if (c->stripes_slab) { (void)hipFree(c->stripes_slab); c->stripes_slab = nullptr; pl.stripes_m = pl.stripes_n = nullptr; }
+        for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
+                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+        (void)hipGetLastError();
+        if (!rc) rc = fail(c, "ingest: allocating the resident layout failed: %s", alloc_err.c_str());
+    }
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, "ingest: hipDeviceSynchronize failed");
     const auto t_in1 = std::chrono::steady_clock::now();      // the layouts are allocated (the driver maps / wipes 100+ GB)
     c->ingest_overlap_s = alloc_secs < prep_secs ? alloc_secs : prep_secs;

@@ -52,8 +52,8 @@ void data::open_device(int device, int kernel_mode) {
     if (gv_env_nranks() > 1) (void)gv_bind_host_numa(device, nullptr);   // one process per GPU: stay on the CPUs next to it
     if (gv_create(device, &ctx)) die(std::string("FATAL: ") + gv_last_error(nullptr));
     ck(ctx, gv_set_dims(ctx, N, M, Mt, S), "gv_set_dims");
-    // kernel mode 1: two stripe sets (1), the single tile layout (2: half the HBM, same bits), or -- the default, 3 -- two stripe
-    // sets when they fit the free HBM and the tile layout when they do not (--resident-layout)
+    // kernel mode 1: two stripe sets (1), the single tile layout (2: half the HBM, same bits), or -- the default, 3 -- the tile
+    // layout unless the run is long (>= 1000 expected ATx passes) and two stripe sets fit the free HBM (--resident-layout)
     const char* lay = getenv("GVAMP_RESIDENT_LAYOUT");
     const int stripes = kernel_mode != 0 ? ((lay && atoi(lay) >= 1 && atoi(lay) <= 3) ? atoi(lay) : 3) : 0;
     ck(ctx, gv_set_layout(ctx, kernel_mode == 0, stripes), "gv_set_layout");
@@ -221,9 +221,16 @@ void data::read_genotype_data() {
     printf("INFO   : rank %d streams %zu bytes (%.3f GB) of raw data to the device.\n", rank, size_bytes, double(size_bytes) / 1.0E9);
     const auto t0 = std::chrono::steady_clock::now();
     ck(ctx, gv_upload_bed_file(ctx, bedfp.c_str(), (int64_t)(3 + size_t(S) * mbytes)), "gv_upload_bed_file");
-    if (rank == 0)                                                                   // data.cpp:227-232
+    if (rank == 0) {                                                                 // data.cpp:227-232
         std::cout << "reading genotype data took "
                   << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " seconds." << std::endl;
+        gv_ingest_stats st{};
+        if (gv_ingest_info2(ctx, &st) == 0 && st.layout != 0)      // [ext] what --resident-layout 3 decided, and from what
+            std::cout << "resident layout: " << (st.layout == 1 ? "two stripe sets" : "one tile layout") << ", " << st.resident_bytes / 1e9
+                      << " GB (expected ATx passes " << (long long)st.expected_passes
+                      << (st.expected_passes >= 1000 ? ": a long run -- two sets when they fit" : ": not announced as a long run -- one layout")
+                      << "; --resident-layout / GVAMP_EXPECTED_PASSES override)" << std::endl;
+    }
 }
 
 std::vector<int> data::read_chromosome_info(std::string bim_file) {

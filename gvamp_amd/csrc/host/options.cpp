@@ -139,7 +139,8 @@ void Options::read_command_line_options(int argc, char** argv) {
     if (rank_for_printing() == 0) std::cout << ss.str() << std::endl;
     // [ext] what --resident-layout 3 (auto) may assume about the length of the run: every data object of the process tells the
     // library to expect about 12 ATx passes per VAMP iteration (4-40 in the runs measured), gv_set_expected_passes -- below 1 000 passes a
-    // second stripe set does not earn its allocation back and auto takes the one tile layout.  $GVAMP_EXPECTED_PASSES overrides.
+    // second stripe set does not earn its allocation back and auto takes the one tile layout (as it does for a caller that says
+    // nothing: bench.py and a bare binding get the same layout as a driver run of fewer than 84 iterations).  $GVAMP_EXPECTED_PASSES overrides.
     if (!getenv("GVAMP_EXPECTED_PASSES")) setenv("GVAMP_EXPECTED_PASSES", std::to_string((long long)iterations * 12).c_str(), 1);
 }
 

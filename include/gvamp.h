@@ -81,10 +81,11 @@ int gv_atx(gv_ctx* ctx, const double* p, double* out);
  * needed by kernel mode 0 and gv_download_bed); stripes selects the re-encoded 2-bit layout of kernel mode 1:
  *   0 none, 1 two stripe sets (marker-major for ATx, individual-major for Ax: 2 x M*N/4 bytes resident),
  *   2 ONE tile layout that serves both products (M*N/4 bytes resident; bit-identical results),
- *   3 auto: two stripe sets when they fit the free HBM at ingest (their ATx is 2-5 % faster), else the tile layout.
+ *   3 auto: the tile layout, unless the caller announced a long run (gv_set_expected_passes >= 1000) and two stripe sets (their
+ *     ATx is 2-5 % faster) fit the free HBM at ingest.
  * Default: raw_rows = 0, stripes = 3 -- what bench.py measures and what a binding that never calls this gets (INTEGRATION.md
  * section B): the rows stream through a chunk buffer at ingest and only the re-encoded layout stays resident, so a 100 GB
- * shard occupies 200 GB (or 100 GB) of HBM, not 300.  raw_rows = 1 is needed by kernel mode 0 and gv_download_bed only. */
+ * shard occupies 100 GB (or 200 GB) of HBM, not 300.  raw_rows = 1 is needed by kernel mode 0 and gv_download_bed only. */
 int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
 int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0 none, 1 two stripe sets, 2 tile layout */
 /* kernel family for Ax/ATx: 1 (default) = i8 MFMA fixed-point kernels on the re-encoded layout (0.8 of the HBM roofline,
@@ -394,8 +395,9 @@ int gv_ingest_info2(gv_ctx* ctx, gv_ingest_stats* out);
 /* Hint for gv_set_layout(.., 3) (auto), to be given before the ingest: how many ATx passes over the shard the caller expects to
  * make (a VAMP run: iterations x CG steps; 0 = unknown).  The second stripe set of layout 1 costs its bytes once more at ingest
  * (0.5-4.3 s per 100 GB, depending on whether the driver is still wiping freed memory) and makes every ATx pass ~3 % faster: it
- * pays for itself after 500-9 000 passes.  With a hint below 1 000, auto takes the one tile layout even when two sets would fit;
- * with 0 or >= 1 000 memory decides alone, as before.  The drivers pass iterations x 12. */
+ * pays for itself after 500-9 000 passes, whatever the shard size.  Auto builds the two sets only with a hint >= 1 000 (and room in
+ * HBM); below that, and with no hint at all (ABI 3: a run that says nothing about its length is not assumed to be long), it takes
+ * the one tile layout.  The drivers pass iterations x 12, bench.py the passes it is about to make. */
 int gv_set_expected_passes(gv_ctx* ctx, int64_t passes);
 int gv_get_decomp(gv_ctx* ctx, gv_decomp_info* out4);
 /* Pins the decomposition of class cls (0 ATx, 1 two-vector ATx, 2 Ax, 3 two-vector Ax), e.g. one a deployment measured itself:

@@ -34,11 +34,31 @@ class Params(C.Structure):
                 ("freeze_ind", C.POINTER(C.c_double))]
 
 
+_SO = "libgvoracle.so"
+TIMING_FLAGS = None      # set by use_timing_build(): the compiler flags of the library in use, None = the parity build
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "libgvoracle.so")
+    so = os.path.join(_HERE, _SO)
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _HERE, "libgvoracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, _SO])
     return so
+
+
+def use_timing_build():
+    """bench.py's cpu_baseline leg only: the same sources compiled -O3 -march=native ON THIS HOST into
+    libgvoracle_timing.so, kept apart from the parity library (whose -O2 -mavx2 -mfma flags are chosen for bit-reproducibility
+    and portability, oracle/Makefile).  Returns the flags in use; falls back to the parity build when there is no compiler."""
+    global _SO, _LIB, TIMING_FLAGS
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgvoracle_timing.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _SO, _LIB = "libgvoracle_timing.so", None
+        TIMING_FLAGS = "-O3 -march=native -fopenmp (oracle/Makefile: timing; built on this host)"
+    except (OSError, subprocess.CalledProcessError):
+        _SO, _LIB = "libgvoracle.so", None
+        TIMING_FLAGS = "-O2 -mavx2 -mfma -fopenmp (parity build: the timing build did not compile on this host)"
+    lib()
+    return TIMING_FLAGS
 
 
 def lib():

@@ -418,9 +418,9 @@ def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
 
 
 def test_auto_layout_weighs_the_length_of_the_run_and_ingest_reports_its_parts(tmp_path):
-    """gv_set_expected_passes: with the automatic layout a short run (< 1000 ATx passes) takes the one tile layout -- half the bytes
-    to allocate and fill -- although two stripe sets would fit; an unknown or long run keeps the two sets; an explicit layout is
-    never overruled; results are the same bits either way.  gv_ingest_info2: the allocation of the resident layout runs beside the
+    """gv_set_expected_passes: with the automatic layout a short run (< 1000 ATx passes) or one that says nothing about its length
+    takes the one tile layout -- half the bytes to allocate and fill -- although two stripe sets would fit; an announced long run
+    takes the two sets; an explicit layout is never overruled; results are the same bits either way.  gv_ingest_info2: the allocation of the resident layout runs beside the
     preparation of the source (a file: the pinned staging buffers and the first two chunks), and what that hid is reported."""
     N, M = 4101, 20000
     bed = synth.synth_bed(N, M, seed=9, miss_ppm=5000)
@@ -436,14 +436,15 @@ def test_auto_layout_weighs_the_length_of_the_run_and_ingest_reports_its_parts(t
             st = sh.ingest_stats()
             sh.compute_markers_statistics()
             got[name] = (sh.get_layout(), sh.Ax(x), st)
-    assert [got[k][0] for k in ("unknown", "short", "long", "explicit")] == [1, 2, 1, 1]
+    assert [got[k][0] for k in ("unknown", "short", "long", "explicit")] == [2, 2, 1, 1]
     for k in ("short", "long", "explicit"):
         assert np.array_equal(got[k][1], got["unknown"][1])
     mb = (N + 3) // 4
     for k, (lay, _, st) in got.items():
         assert st["layout"] == lay and st["alloc_s"] >= st["overlap_s"] >= 0.0 and st["fill_s"] > 0.0
         assert st["resident_GB"] * 1e9 >= (1 if lay == 2 else 2) * M * mb        # (padded to whole 4 KiB blocks)
-    assert got["short"][2]["resident_GB"] < 0.6 * got["unknown"][2]["resident_GB"]
+    assert got["short"][2]["resident_GB"] < 0.6 * got["long"][2]["resident_GB"]
+    assert got["unknown"][2]["resident_GB"] == got["short"][2]["resident_GB"]
     assert got["short"][2]["expected_passes"] == 60
     with capi.Shard(N, M) as sh:
         with pytest.raises(capi.GvError, match="passes >= 0"):
