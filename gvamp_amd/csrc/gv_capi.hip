@@ -1371,6 +1371,8 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
                 // ATx 14.8-16.0 ms from one ingest to the next); of two sets carved out of one allocation the first was in its fast
                 // mode in nearly every ingest measured (Ax 14.80-14.99 ms in 13 of 14) and the second near it (ATx 14.95-15.4), whichever set
                 // came first.  An allocation that large failing falls back to one allocation per set.
+                const size_t sz_m = (size_t)(pl.nrg_m > 0 ? pl.nrg_m : 1) * pl.nkb_m * 4096,
+                             sz_n = (size_t)pl.nrg_n * (pl.nkb_n > 0 ? pl.nkb_n : 1) * 4096;
                 void* slab = nullptr;
                 const size_t al = (size_t)1 << 30, off_m = (sz_n + al - 1) / al * al;
                 if (hipMalloc(&slab, off_m + sz_m) == hipSuccess) {
