@@ -118,7 +118,8 @@ def cpu_baseline(N, seed, want_markers, device):
     try:
         kw = dict(iterations=2, CG_max_iter=50, rho=0.5, seed=1, gam1=1e-8, gamw=2.0, nthreads=nt)
         beta, y = go.sim_phen(bed, N, m, 0.5, max(1, m // 100), 1, nthreads=nt)
-        r = go.infere(bed, N, m, y, None, None, true_signal=beta, **kw)
+        # (the default 23-component prior needs Mt >= 50 000 -- utilities.cpp:91-140 -- so the slice takes config 1's three components)
+        r = go.infere(bed, N, m, y, [0.90, 0.07, 0.03], [0, 0.001, 0.01], true_signal=beta, **kw)
         t2 = r.trace[-1]
         model = t2["n_ax"] * best["ax_s"] + t2["n_atx"] * best["atx_s"]
         measured["slice_N%d_M%d" % (N, m)] = {"seconds": round(t2["seconds"], 3), "n_ax": int(t2["n_ax"]), "n_atx": int(t2["n_atx"]),
