@@ -452,6 +452,11 @@ def main():
                             "ms_allreduce_per_ax": max(r["ms_allreduce_per_ax"] for r in per_rank), "per_rank": per_rank}
     else:
         out["decomposition"] = mine["decomposition"]
+    if os.environ.get("GVAMP_FORCE_MULTI"):
+        # gv_debug_force_multi (test hook): this one-rank run took the sharded branches over an in-stream exchange -- NOT a benchmark
+        # configuration; what it shows is the cost of those branches at one rank (the exchange itself moves nothing between GPUs)
+        out["forced_multi"] = {"GVAMP_FORCE_MULTI": os.environ["GVAMP_FORCE_MULTI"], "GV_OVERLAP": os.environ.get("GV_OVERLAP", "0"),
+                               "ms_allreduce_per_ax": mine["ms_allreduce_per_ax"], "n_allreduce": cnt["n_allreduce"]}
     # ---- second half of the metric: VAMP iterations/s (vamp::infere of the host C++ mirror on the same shard) ----
     if a.vamp_iterations > 0:
         from gvamp_amd import hostapi
