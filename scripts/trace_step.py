@@ -1,6 +1,6 @@
 """The launch list of ONE steady-state CG step out of a rocprofv3 kernel trace: every kernel between the last two k_cgx_decide
 launches whose step streamed (development tool; profiles/r5_forced_multi_gaps.txt).
-  python scripts/trace_step.py <kernel_trace.csv> [which]        which: -1 = the last complete step (default), -2 the one before ..."""
+  python scripts/trace_step.py <kernel_trace.csv> [which]        which: default = the step with the fewest launches (a pure CG step), -1 = the last complete step, -2 the one before ..."""
 import csv
 import re
 import sys
@@ -22,7 +22,10 @@ for a, b in zip(dec[:-1], dec[1:]):
     seg = ev[a + 1:b + 1]
     if any(("k_mfma_matvec" in e[2] or "k_mfma_tile" in e[2]) and e[1] - e[0] > 20000 for e in seg):
         steps.append(seg)
-seg = steps[which]
+if len(sys.argv) <= 2:      # default: a pure CG step -- the one with the fewest launches (no denoiser / EM section inside)
+    seg = min(steps, key=len)
+else:
+    seg = steps[which]
 t0 = seg[0][0]
 span = seg[-1][1] - seg[0][0]
 print("one CG step: %d launches, span %.1f us" % (len(seg), span / 1e3))

@@ -304,3 +304,38 @@ def test_the_harness_has_teeth_a_dropped_event_edge_is_seen():
         sh.set_overlap(0)
         sh.ax_dev(x, z)
         assert np.array_equal(z.download(), good)
+
+
+@pytest.mark.parametrize("driver", ["gvamp_sim", "gvamp_main_real"])
+def test_drivers_under_GVAMP_FORCE_MULTI_write_the_same_files(tmp_path, driver):
+    """The reference-style executables (sim.cpp / main_real.cpp command lines) with every context of the process forced
+    (GVAMP_FORCE_MULTI=1:20 at gv_create; GV_OVERLAP=3): the .bin / .csv files must be the plain run's, byte for byte --
+    p-values with their per-chromosome Ax exchanges included."""
+    import filecmp
+    import lzma
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = os.path.join(root, "tests", "golden", "survey_probe")
+    bed = tmp_path / "toy.bed"
+    bed.write_bytes(lzma.open(os.path.join(G, "toy.bed.xz")).read())
+    with open(tmp_path / "toy.bim", "w") as f:
+        for i in range(10000):
+            f.write("%d\trs%d\t0\t%d\tA\tG\n" % (1 + i // 500, i, i + 1))
+    common = ["--bed-file", str(bed), "--bim-file", str(tmp_path / "toy.bim"), "--N", "2000", "--Mt", "10000", "--iterations", "3",
+              "--probs", "0.90,0.07,0.03", "--vars", "0,0.001,0.01", "--rho", "0.5", "--CG-max-iter", "20", "--model", "linear",
+              "--seed", "7", "--h2", "0.5", "--store-pvals", "1"]
+    if driver == "gvamp_sim":
+        common += ["--num-mix-comp", "3", "--CV", "500"]
+    else:
+        common += ["--run-mode", "infere", "--phen-files", os.path.join(G, "toy.phen")]
+    outs = {}
+    for name, extra in (("plain", {}), ("forced", {"GVAMP_FORCE_MULTI": "1:20", "GV_OVERLAP": "3"})):
+        out = str(tmp_path / name) + "/"
+        res = subprocess.run([os.path.join(root, "gvamp_amd", driver)] + common + ["--out-dir", out, "--out-name", "t"],
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        outs[name] = out
+    files = sorted(f for f in os.listdir(outs["plain"]) if f.endswith((".bin", ".csv")))
+    assert len(files) >= 8 and sorted(f for f in os.listdir(outs["forced"]) if f.endswith((".bin", ".csv"))) == files
+    for f in files:
+        assert filecmp.cmp(outs["plain"] + f, outs["forced"] + f, shallow=False), f
