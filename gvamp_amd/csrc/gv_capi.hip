@@ -1157,9 +1157,9 @@ int gv_create(int device, gv_ctx** out) {
     if ((e = hipMalloc(&c->red_partial, sizeof(double) * RED_BLOCKS * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc(&c->red_out, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc(&c->host_pin, sizeof(double) * RED_MAXK)) != hipSuccess) return bail("hipHostMalloc", e);
-    // scalar mailbox (read_scalars); GV_MAILBOX=0 keeps the copy + synchronise read-back
-    const char* mb = getenv("GV_MAILBOX");
-    if (!(mb && atoi(mb) == 0)) {
+    // scalar mailbox (read_scalars); a runtime that cannot map coherent host memory keeps the copy + synchronise read-back and the
+    // host-driven CG loop
+    {
         void* hp = nullptr;
         void* dp = nullptr;
         if (hipHostMalloc(&hp, sizeof(double) * RED_MAXK + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
@@ -2077,7 +2077,7 @@ int gv_comm_init_callback(gv_ctx* c, int nranks, int rank, gv_allreduce_fn fn, v
 int gv_debug_force_multi(gv_ctx* c, int transport, int delay_us) {
     NEED(c, transport >= 0 && transport <= 7 && (transport == 0 || (transport & 3)) && delay_us >= 0,
          "gv_debug_force_multi: transport 0..3 (+ 4: fault injection), delay_us >= 0");
-    NEED(c, c->nranks == 1 && !c->local && !c->cb, "gv_debug_force_multi: only a one-rank context can be forced");
+    NEED(c, transport == 0 || (c->nranks == 1 && !c->local && !c->cb), "gv_debug_force_multi: only a one-rank context can be forced");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((transport & 2) && !c->comm) {

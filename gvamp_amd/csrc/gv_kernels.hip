@@ -949,66 +949,12 @@ __global__ __launch_bounds__(256) void k_denoise(const double* __restrict__ r1, 
 }
 
 // vamp::updatePrior E-step (vamp.cpp:953-1013).  pr.probs[j] holds omegas[j] (j >= 1), pr.vars[j] the variances.
-// 64-thread blocks; per-thread accumulators and the num_j scratch live in LDS columns (no bank conflicts).  Everything
-// that depends on the component only (the exponent coefficient, the Gaussian prefactor, the posterior mean gain and
-// variance) is computed once per block, so an element costs one exp and a few FMAs per component instead of the nine
-// divisions / square roots of the formulas as written (same values up to the rounding of the re-association).
-__global__ __launch_bounds__(64) void k_prior_estep(const double* __restrict__ r1, int64_t n, double gam1,
-                                                    double lambda, gv_prior pr, double* __restrict__ partial) {
-    __shared__ double sh_num[GV_LMAX - 1][64];
-    __shared__ double sh_R[GV_LMAX - 1][64];
-    __shared__ double sh_G[GV_LMAX - 1][64];
-    __shared__ double c_exp[GV_LMAX - 1], c_pre[GV_LMAX - 1], c_gain[GV_LMAX - 1], c_var[GV_LMAX - 1];
-    const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
-    const double noise_var = 1 / gam1;
-    double max_sigma = pr.vars[0];
-    for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
-    if (t < Lm1) {
-        const double v = pr.vars[t + 1];
-        c_exp[t] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
-        c_pre[t] = lambda * pr.probs[t + 1] / sqrt(v + noise_var) / sqrt(2 * M_PI);
-        c_gain[t] = gam1 / (1 / v + gam1);
-        c_var[t] = 1.0 / (1.0 / v + gam1);
-    }
-    const double c0 = (1 - lambda) / sqrt(2 * M_PI * noise_var);
-    const double e0 = 0.5 * max_sigma / noise_var / (noise_var + max_sigma);
-    for (int j = 0; j < Lm1; j++) sh_R[j][t] = sh_G[j][t] = 0.0;
-    __syncthreads();
-    double acc_pin = 0.0;
-    int64_t stride = (int64_t)gridDim.x * 64;
-    for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
-        const double r = r1[i], r2 = r * r;
-        double sum_of_elems = 0.0;
-        for (int j = 0; j < Lm1; j++) {
-            double num = c_pre[j] * exp(-r2 * c_exp[j]);
-            sh_num[j][t] = num;
-            sum_of_elems += num;
-        }
-        const double inv = 1 / sum_of_elems;
-        const double pin = 1 / (1 + c0 * exp(-r2 * e0) * inv);
-        acc_pin += pin;
-        for (int j = 0; j < Lm1; j++) {
-            double beta = sh_num[j][t] * inv;
-            double gm = c_gain[j] * r;
-            sh_R[j][t] += beta * pin;
-            sh_G[j][t] += beta * (gm * gm + c_var[j]) * pin;
-        }
-    }
-    double* o = partial + (int64_t)blockIdx.x * K;
-    double s = wave_sum(acc_pin);
-    if (t == 0) o[0] = s;
-    for (int j = 0; j < Lm1; j++) {
-        double a = wave_sum(sh_R[j][t]), b = wave_sum(sh_G[j][t]);
-        if (t == 0) {
-            o[1 + 2 * j] = a;
-            o[2 + 2 * j] = b;
-        }
-    }
-}
-// The same E-step with the per-thread accumulators in registers, for priors of at most LC + 1 components.  The kernel above parks
-// 3 x (GV_LMAX - 1) x 64 doubles in LDS -- 47 KB per 64-thread block whatever L is, so three waves per CU: 32 us for 200k markers
-// and 53 us for 500k; here only the per-component constants (uniform over the block) stay in LDS.  Same operations in the same
-// order per thread, same block partials: same bits (tests/test_gpu_hardening.py holds the two against each other).
+// 64-thread blocks.  Everything that depends on the component only (the exponent coefficient, the Gaussian prefactor, the
+// posterior mean gain and variance) is computed once per block, so an element costs one exp and a few FMAs per component instead
+// of the nine divisions / square roots of the formulas as written (same values up to the rounding of the re-association).  The
+// per-thread accumulators live in registers, instantiated for priors of at most LC + 1 components; only the per-component
+// constants (uniform over the block) stay in LDS.  (An earlier form kept the accumulators in LDS columns: 47 KB per block, three
+// waves per CU, 32-53 us where this one takes 18-20; it produced the same bits and is gone.)
 template <int LC>
 __global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict__ r1, int64_t n, double gam1, double lambda,
                                                         gv_prior pr, double* __restrict__ partial) {
@@ -1375,11 +1321,9 @@ void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double
                  double* partial, double* out) {
     int nb = red_blocks(n, 64);
     int K = 1 + 2 * (pr.L - 1);
-    const char* force_lds = getenv("GV_ESTEP_LDS");      // (test switch: the LDS form for every prior)
     const int Lm1 = pr.L - 1;
 #define GV_ESTEP(LCV) hipLaunchKernelGGL(k_prior_estep_reg<LCV>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial)
-    if (force_lds && atoi(force_lds)) hipLaunchKernelGGL(k_prior_estep, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial);
-    else if (Lm1 <= 4) GV_ESTEP(4);
+    if (Lm1 <= 4) GV_ESTEP(4);
     else if (Lm1 <= 8) GV_ESTEP(8);
     else if (Lm1 <= 16) GV_ESTEP(16);
     else if (Lm1 <= 24) GV_ESTEP(24);

@@ -440,6 +440,9 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
 // host keeps scheduling pass by pass; but a CG step no longer costs two or three scalar round trips and a dozen
 // host-paced launches: the step's kernels (alpha, updates, beta, stopping rule) run back to back on the device and the host
 // reads ONE status word set per completed application.
+// GV_CG_DEVICE=0 selects the host-driven loops (scalars read back three times per step): the form kernel mode 0 and a runtime
+// without a mapped mailbox run anyway, kept switchable as the reference point of tests/test_gpu_cgdevice.py and for the
+// host-synchronising transports (gv_comm_init_callback / _local), whose collectives wait for the host whichever loop issues them.
 static bool cgx_usable(const gv_ctx* c) {
     const char* cgdev = getenv("GV_CG_DEVICE");
     // (nothing rank-local in here: an empty shard, M == 0, must take the same sequence of collectives as its peers)
@@ -542,9 +545,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
     }
     for (int k = 0; k < nsys; k++)
         if (cg_first_step_from_known_product(c, sys[k], tau, gam2, diag, max_iter, multi)) return 1;
-    const char* cgdev = getenv("GV_CG_DEVICE");
-    // (chosen by nothing rank-local: an empty shard, M == 0, must enter the same sequence of collectives as its peers)
-    const bool device_loop = c->kernel_mode == 1 && c->have_stripes && c->use_mbox && !(cgdev && atoi(cgdev) == 0);
+    const bool device_loop = cgx_usable(c);
     for (;;) {
         CgSys* act[2];
         int na = 0;
@@ -1073,13 +1074,9 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
         };
         b_post();
 
-        const char* pe = getenv("GV_AAT_PIPELINE");
-        const bool pipe_on = !(pe && atoi(pe) == 0);
-        const char* de = getenv("GV_AAT_DQ_FUSE");             // 0: k_aat_dq stays a launch of its own (A/B switch)
-        const bool dq_on = !(de && atoi(de) == 0);
         bool pipelined = false;
         for (;;) {
-            // ---- the steady state, enqueued ahead of its statuses (GV_AAT_PIPELINE=0: the host-paced loop below only) -------------
+            // ---- the steady state, enqueued ahead of its statuses ---------------------------------------------------------------
             // Once both systems are stepping and share their passes -- X: an ATx pass carrying the first half of Q_A (A^T p_a) and the
             // second half of Q_B; Y: an Ax pass carrying the second half of Q_A and the first half of Q_B -- nothing the host does
             // between two passes depends on a scalar except WHICH systems are still running.  So the host enqueues pass k + 1 and its
@@ -1098,7 +1095,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
             {
                 // (a pass or two of the host-paced loop come first: the right-hand side of solve a, and one pass that aligns the two
                 // systems when they start half an application apart)
-                if (!pipelined && dev && pipe_on && at_acc && max_iter > 0 && !hr.pending && a_phase == 1 && ha.pending && hb.pending &&
+                if (!pipelined && dev && at_acc && max_iter > 0 && !hr.pending && a_phase == 1 && ha.pending && hb.pending &&
                     sb.active && !ha.one_half && !hb.one_half && ha.kind() == hb.kind()) {
                     pipelined = true;
                     double* stA = c->cgx_state;
@@ -1171,7 +1168,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
                             if (slotA) hk.state[0] = stA;       // (for the rider's sake: no search direction to advance in this slot)
                             // one rank, a vector that fits RED_BLOCKS blocks: the epilogue of the pass leaves d_a = tau d_a + gam2 p_a
                             // and the block partials of <d_a, p_a> itself (k_aat_dq's work, bit for bit)
-                            const bool dq_fused = slotA && hostA && !multi && M > 0 && (n + 255) / 256 <= RED_BLOCKS && dq_on;
+                            const bool dq_fused = slotA && hostA && !multi && M > 0 && (n + 255) / 256 <= RED_BLOCKS;
                             if (dq_fused) { hk.dq_p[0] = p; hk.dq_part[0] = c->red_partial; hk.dq_tau = tau; hk.dq_gam2 = gam2; }
                             if (slotB) { hk.state[iB] = stB; hk.p[iB] = sb.p; hk.z[iB] = sb.z; }
                             const bool may_ride = ride_pending && slotA && slotB;

@@ -58,6 +58,25 @@ class host_loop:
         os.environ.pop("GV_CG_DEVICE", None)
 
 
+def range_close(a, b, mu, key, N, M, tol):
+    """A^T mu_a (key atm) / A A^T mu_a (key aat) of two runs whose mu_a agree to `tol`: the difference on the scale of the operands,
+    ||A||^k ||mu_a|| with ||A|| ~ 1 + sqrt(M / N), k = 1 / 2 -- and never further than 1e-2 apart on their own norm."""
+    a, b, mu = np.asarray(a), np.asarray(b), np.asarray(mu)
+    if a.shape != b.shape:
+        return False
+    if not (np.all(np.isfinite(b)) and np.all(np.isfinite(mu))):        # (degenerate people statistics: non-finite alike, see close)
+        return bool(np.array_equal(np.isfinite(a), np.isfinite(b)))
+    if not np.all(np.isfinite(a)):
+        return False
+    norm_a = 1.0 + np.sqrt(M / N)
+    scale = norm_a ** (2 if key == "aat" else 1) * float(np.linalg.norm(mu))
+    err = float(np.linalg.norm(a - b))
+    if scale == 0.0:
+        return err == 0.0
+    own = float(np.linalg.norm(b))
+    return err <= tol * scale and (own == 0.0 or err <= 1e-2 * own or err <= 1e-13 * scale)
+
+
 def solves(sh, M, S, P):
     """the two solver entry points on one shard (or one rank of a group); returns everything comparable"""
     va, vb = sh.vecM(P["va"][S:S + M]), sh.vecM(P["vb"][S:S + M])
@@ -117,11 +136,13 @@ def solves(sh, M, S, P):
                  mn=mn.download(), mn2=mn2.download(), atm=atm.download(), mb2=mb2.download(), aat=aat.download(),
                  ata2=ata2.download())
         # the form the VAMP loop uses at levels 3 / 4 (A^T mu_a accumulated inside the solve, a rider, the right-hand side completed
-        # inside): its steady state is enqueued ahead of its statuses (gv_cg_solve_aat2w) -- against the host-paced loop
-        # (GV_AAT_PIPELINE=0): every output and every counter bit for bit
+        # inside): its steady state is enqueued ahead of its statuses (gv_cg_solve_aat2w) -- against the same pipeline with every
+        # fused piece as a launch of its own and an in-stream exchange between them (gv_debug_force_multi: what a sharded job runs):
+        # every output and every counter bit for bit
         outs = []
-        for pipe in ("1", "0"):
-            os.environ["GV_AAT_PIPELINE"] = pipe
+        for forced in ((0, 1) if sh.L.gv_comm_size(sh.h) == 1 else (0, 0)):       # (a rank of a group is sharded already)
+            if forced:
+                sh.force_multi(forced)
             vq = sh.vecN(P["vn"])
             q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po = sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecN(), sh.vecN()
             sh.counters(reset=True)
@@ -133,10 +154,11 @@ def solves(sh, M, S, P):
                          [ra_, rb_] + [q.download() for q in (vq, q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po)]))
             for q in (vq, q_mn, q_at, q_mb, q_aat, q_ata, q_ro, q_po):
                 q.free()
-        os.environ.pop("GV_AAT_PIPELINE", None)
+        if sh.L.gv_comm_size(sh.h) == 1:
+            sh.force_multi(0)
         assert outs[0][0] == outs[1][0], ("pipelined XXT solver: counts", outs[0][0], outs[1][0])
         for a_, b_ in zip(outs[0][1], outs[1][1]):
-            assert np.array_equal(a_, b_, equal_nan=True), "pipelined XXT solver: outputs differ from the host-paced loop"
+            assert np.array_equal(a_, b_, equal_nan=True), "pipelined XXT solver: outputs differ from its unfused, exchanged form"
     return dict(**x, it=(st.iters, st.converged, st.n_relres, sa.iters, sa.converged, sa.n_relres, sb.iters, sb.converged, sb.n_relres),
                 cnt=tuple(c1[k] for k in keys) + tuple(c2[k] for k in keys), rr=rr, ra=ra, rb=rb, ons=sb.onsager,
                 mu=mu.download(), mu_a=mu_a.download(), mu_b=mu_b.download(), ro=ro.download(), amu=amu.download(),
@@ -245,11 +267,16 @@ def run_case(seed0, k):
         # the null space of A^T, divided by gam2 alone): two solutions that agree to tolx relative to ||mu_a|| agree to kappa * tolx
         # there (seed 512, case 111, reproduced bit for bit on the round-3 tree: N = 1025, M = 2, kappa = 1.8e4 -- mu_a within 3e-8, A^T
         # mu_a 3.5e-4 apart)
-        tol_atm = min(0.5, tolx * max(1.0, kappa))
+        # -- so these two are compared on the scale of what they are made from: ||A^T (mu_d - mu_h)|| <= ||A|| ||mu_d - mu_h||, i.e.
+        # the error of A^T mu_a against ||A|| ||mu_a|| (||A|| ~ 1 + sqrt(M / N) for these matrices) at the tolerance of mu_a itself,
+        # and A A^T mu_a against ||A||^2 ||mu_a||.  No factor kappa: where mu_a lies in the range of A this is kappa times tighter than
+        # a relative comparison widened by kappa (a dropped or doubled `A mu += alpha A p` shows), and where it does not it is the
+        # same bound.  On their own norm the two may still be off by kappa * tolx; that is capped at 1e-2 (worst case on record 3.6e-3).
         for key, ok in (("mn", okx[0]), ("mn2", okx[1]), ("atm", okx[1]), ("mb2", okx[1]), ("aat", okx[1]), ("ata2", okx[1])):
-            if ok:
-                # (A A^T mu_a = (v - r - gam2 mu_a) / tau is the same range component, obtained as a difference of terms kappa times larger)
-                assert close(d[key], h[key], tol_atm if key in ("atm", "aat") else tolx), (key, info, rel(d[key], h[key]), kappa)
+            if ok and key in ("atm", "aat"):
+                assert range_close(d[key], h[key], d["mn2"], key, N, M, tolx), (key, info, rel(d[key], h[key]), kappa)
+            elif ok:
+                assert close(d[key], h[key], tolx), (key, info, rel(d[key], h[key]), kappa)
     # ---- B: marker shards in one process
     nr = int(rng.integers(2, 5))
     cuts = sorted(int(c) for c in rng.integers(0, M + 1, size=nr - 1))
@@ -293,11 +320,11 @@ def run_case(seed0, k):
             # (as in A: 40 steps on a system of a handful of unknowns end at the stopping rule times sqrt(kappa), whoever adds the sums
             # in which order -- seed 613, case 194: N = 827, M = 5, A A^T mu_a of four ranks 1.3e-4 from the single shard's)
             tol_shx = max(tol_sh, 2e-4, 1e-4 * np.sqrt(kappa)) if loose > 1.0 else tol_sh
-            for key in ("atm", "mb2", "ata2"):       # (A^T mu_a: at kappa times the tolerance of mu_a, as above; seed 512, case 896)
-                assert close(cat(key), d[key], min(0.5, tol_shx * max(1.0, kappa)) if key == "atm" else tol_shx), \
+            for key in ("atm", "mb2", "ata2"):       # (A^T mu_a: on the scale ||A|| ||mu_a||, as above; seed 512, case 896)
+                assert (range_close(cat(key), d[key], d["mn2"], key, N, M, tol_shx) if key == "atm" else close(cat(key), d[key], tol_shx)), \
                     ("sharded " + key, info, rel(cat(key), d[key]), kappa)
             for key in ("mn", "mn2", "aat"):      # (aat: the range component again -- seed 721, case 1289: M = 2, kappa = 601, 3.6e-3)
-                assert close(plain[0][key], d[key], min(0.5, tol_shx * max(1.0, kappa)) if key == "aat" else tol_shx), \
+                assert (range_close(plain[0][key], d[key], d["mn2"], key, N, M, tol_shx) if key == "aat" else close(plain[0][key], d[key], tol_shx)), \
                     ("sharded " + key, info, rel(plain[0][key], d[key]), kappa)
     return info
 

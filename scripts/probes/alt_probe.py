@@ -1,4 +1,4 @@
-"""Development: is a streaming kernel as fast between other kernels as it is back to back?  python scripts/alt_probe.py N M"""
+"""Development: is a streaming kernel as fast between other kernels as it is back to back?  python scripts/probes/alt_probe.py N M"""
 import os
 import sys
 

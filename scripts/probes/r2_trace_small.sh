@@ -1,5 +1,5 @@
 # Kernel traces + gap summaries of whole VAMP iterations at the small-shard shapes (development; run under gpurun).
-#   gpurun -- bash scripts/r2_trace_small.sh <tag>
+#   gpurun -- bash scripts/probes/r2_trace_small.sh <tag>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r2}
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O

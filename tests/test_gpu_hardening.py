@@ -356,43 +356,32 @@ def test_gathered_dots_equal_their_own_launches_bit_for_bit(N, M):
             sh.dots_ex([(a, u, a, u, 0)])
 
 
-def test_stripe_sets_in_one_allocation_or_two_give_the_same_bits_and_survive_a_reingest():
-    """The two stripe sets are views into one allocation by default (gv_capi.hip: where the driver places a large allocation moves
-    the kernel that streams it); GV_STRIPE_SLAB=0 keeps one allocation per set.  Same products either way, a second ingest into
-    the same context (which releases and re-allocates) included."""
+def test_stripe_sets_survive_a_reingest():
+    """The two stripe sets are views into one allocation (gv_capi.hip: where the driver places a large allocation moves the kernel
+    that streams it).  A second ingest into the same context releases and re-allocates: same products for the same matrix."""
     N, M = 5003, 20011
     rng = np.random.default_rng(5)
     x = rng.standard_normal(M)
     p = np.zeros(4 * ((N + 3) // 4))
     p[:N] = rng.standard_normal(N)
-    out = []
-    for env in (None, "0"):
-        if env is not None:
-            os.environ["GV_STRIPE_SLAB"] = env
-        try:
-            with capi.Shard(N, M) as sh:
-                sh.synth_bed(3, 5000)
-                sh.compute_markers_statistics()
-                a1, t1 = sh.Ax(x), sh.ATx(p)
-                sh.synth_bed(4, 5000)                      # re-ingest: the resident layouts are rebuilt in place
-                sh.compute_markers_statistics()
-                a2, t2 = sh.Ax(x), sh.ATx(p)
-                sh.synth_bed(3, 5000)
-                sh.compute_markers_statistics()
-                a3, t3 = sh.Ax(x), sh.ATx(p)
-                assert np.array_equal(a1, a3) and np.array_equal(t1, t3) and not np.array_equal(a1, a2)
-                out.append((a1, t1, a2, t2))
-        finally:
-            os.environ.pop("GV_STRIPE_SLAB", None)
-    for u, v in zip(out[0], out[1]):
-        assert np.array_equal(u, v)
+    with capi.Shard(N, M) as sh:
+        sh.set_layout(False, 1)
+        sh.synth_bed(3, 5000)
+        sh.compute_markers_statistics()
+        a1, t1 = sh.Ax(x), sh.ATx(p)
+        sh.synth_bed(4, 5000)                      # re-ingest: the resident layouts are rebuilt in place
+        sh.compute_markers_statistics()
+        a2 = sh.Ax(x)
+        sh.synth_bed(3, 5000)
+        sh.compute_markers_statistics()
+        a3, t3 = sh.Ax(x), sh.ATx(p)
+        assert np.array_equal(a1, a3) and np.array_equal(t1, t3) and not np.array_equal(a1, a2)
 
 
 @pytest.mark.parametrize("L", [2, 3, 5, 6, 9, 12, 17, 18, 23, 26, 32])
-def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
-    """gv_prior_estep keeps its per-thread accumulators in registers (instantiations for up to 5, 9, 17, 25 and 32 components; the
-    LDS form parks 47 KB per 64-thread block, three waves per CU) -- same operations in the same order, same block partials: the same
-    bits (GV_ESTEP_LDS=1 forces the LDS form)."""
+def test_prior_estep_every_instantiation_vs_the_formulas(L):
+    """gv_prior_estep keeps its per-thread accumulators in registers, instantiated for up to 5, 9, 17, 25 and 32 components: each
+    against the E-step sums of vamp.cpp:953-1013 evaluated in numpy, and reproducible bit for bit."""
     M = 70001
     rng = np.random.default_rng(L)
     r1 = rng.standard_normal(M) * 0.3
@@ -401,19 +390,27 @@ def test_prior_estep_register_form_equals_the_lds_form_bit_for_bit(L):
     lam = 1 - probs[0]
     omegas = probs.copy()
     omegas[1:] /= lam
+    gam1 = 2.5
     out = []
     with capi.Shard(2000, M) as sh:
         sh.synth_bed(1)
         sh.compute_markers_statistics()
         dr = sh.vecM(r1)
-        for env in (None, "1"):
-            if env:
-                os.environ["GV_ESTEP_LDS"] = env
-            try:
-                out.append(np.array(sh.prior_estep(dr, 2.5, lam, omegas, vars_)))
-            finally:
-                os.environ.pop("GV_ESTEP_LDS", None)
+        for _ in range(2):
+            out.append(np.array(sh.prior_estep(dr, gam1, lam, omegas, vars_)))
+    nu, vmax = 1.0 / gam1, vars_.max()
+    v = vars_[1:][None, :]
+    num = lam * omegas[1:][None, :] * np.exp(-0.5 * r1[:, None] ** 2 * (vmax - v) / ((v + nu) * (vmax + nu))) / np.sqrt(v + nu) / np.sqrt(2 * np.pi)
+    S = num.sum(axis=1)
+    beta = num / S[:, None]
+    pin = 1.0 / (1.0 + (1 - lam) / np.sqrt(2 * np.pi * nu) * np.exp(-0.5 * r1 ** 2 * vmax / (nu * (nu + vmax))) / S)
+    mean, var = gam1 * r1[:, None] / (1.0 / v + gam1), 1.0 / (1.0 / v + gam1)
+    want = np.empty(1 + 2 * (L - 1))
+    want[0] = pin.sum()
+    want[1::2] = (beta * pin[:, None]).sum(axis=0)
+    want[2::2] = (beta * (mean ** 2 + var) * pin[:, None]).sum(axis=0)
     assert out[0].shape == (1 + 2 * (L - 1),) and np.all(np.isfinite(out[0]))
+    assert np.allclose(out[0], want, rtol=1e-11, atol=1e-13 * want[0])
     assert [float(v).hex() for v in out[0]] == [float(v).hex() for v in out[1]]
 
 

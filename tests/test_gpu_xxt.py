@@ -177,12 +177,14 @@ def test_xxt_sharded_run_vs_oracle(oracle, fuse):
 
 
 @pytest.mark.parametrize("N,M", [(300032, 6000), (3000, 9000)])
-def test_pipelined_joint_solver_equals_the_host_paced_loop_bit_for_bit(N, M):
+def test_pipelined_joint_solver_vs_its_unfused_launches_and_the_host_paced_loop(N, M):
     """gv_cg_solve_aat2w in the form the VAMP loop uses (A^T mu accumulated, right-hand side completed inside, a rider): its steady
     state is enqueued ahead of its statuses, a step's reductions are added up by their consumers and the Ax epilogue takes the
-    first update of the N-space step along -- against GV_AAT_PIPELINE=0 (host-paced) and GV_AAT_DQ_FUSE=0 (k_aat_dq a launch of its
-    own): every output and every counter bit for bit.  N = 300 032 is above the 262 144 entries a reduction covers with one entry per
-    thread: there the block partials run over 1024 blocks and the epilogue fusion is off by construction."""
+    first update of the N-space step along.  Against (a) the same pipeline with every fused piece as a launch of its own -- what a
+    sharded job runs: k_finalize + exchange between a reduction and its consumer, k_aat_dq behind the exchanged product, the
+    rider copied out of its slot (gv_debug_force_multi) -- every output and every counter BIT FOR BIT; (b) the host-paced loop with
+    host-side scalars (GV_CG_DEVICE=0): the same counts, outputs to rounding.  N = 300 032 is above the 262 144 entries a reduction
+    covers with one entry per thread: there the block partials run over 1024 blocks and the epilogue fusion is off by construction."""
     rng = np.random.default_rng(N + M)
     npad = 4 * ((N + 3) // 4)
     v = np.zeros(npad)
@@ -197,9 +199,12 @@ def test_pipelined_joint_solver_equals_the_host_paced_loop_bit_for_bit(N, M):
         sh.compute_markers_statistics()
         sh.compute_people_statistics()
         du, dx1, dr2 = sh.vecM(u), sh.vecM(x1), sh.vecM(r2)
-        for env in ({}, {"GV_AAT_PIPELINE": "0"}, {"GV_AAT_DQ_FUSE": "0"}):
+        for mode in ("pipelined", "unfused", "host"):
+            env = {"GV_CG_DEVICE": "0"} if mode == "host" else {}
             for k, val in env.items():
                 os.environ[k] = val
+            if mode == "unfused":
+                sh.force_multi(1)
             try:
                 dv = sh.vecN(v)
                 mu, at, mb, aat, ata, ro, po = sh.vecN(), sh.vecM(), sh.vecM(), sh.vecN(), sh.vecM(), sh.vecN(), sh.vecN()
@@ -212,11 +217,13 @@ def test_pipelined_joint_solver_equals_the_host_paced_loop_bit_for_bit(N, M):
             finally:
                 for k in env:
                     os.environ.pop(k, None)
+                sh.force_multi(0)
         assert outs[0][0][0] >= 2 and outs[0][0][2] >= 2, outs[0][0]
-        for other in outs[1:]:
-            assert other[0] == outs[0][0], (outs[0][0], other[0])
-            for a_, b_ in zip(outs[0][1], other[1]):
-                assert np.array_equal(a_, b_, equal_nan=True)
+        assert outs[1][0] == outs[0][0] and outs[2][0] == outs[0][0], [o[0] for o in outs]
+        for a_, b_ in zip(outs[0][1], outs[1][1]):
+            assert np.array_equal(a_, b_, equal_nan=True)
+        for a_, b_ in zip(outs[0][1], outs[2][1]):
+            assert rel(np.asarray(b_), np.asarray(a_)) < 1e-11
         # and the products themselves: the rider and the completed right-hand side against plain matvecs
         assert rel(outs[0][1][8], sh.Ax(x1)) < 1e-12
         assert rel(outs[0][1][9], sh.Ax(r2)) < 1e-12
