@@ -1,6 +1,6 @@
 """Read-only stream ceiling for the three lane -> piece patterns of the streaming kernels (development)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gvamp_amd import capi
 with capi.Shard(400000, 250000) as sh:
     sh.set_layout(False, 2)
