@@ -52,7 +52,7 @@ class CgWarm(C.Structure):
 class AatWarm(C.Structure):
     _fields_ = [("aat_mu_start_a", C.c_void_p), ("at_mu_start_a", C.c_void_p), ("accumulate_at_mu_a", C.c_int),
                 ("ata_v_b", C.c_void_p), ("have_ata_v_b", C.c_int), ("pre_x", C.c_void_p), ("pre_out", C.c_void_p),
-                ("ride_x", C.c_void_p), ("ride_out", C.c_void_p)]
+                ("ride_x", C.c_void_p), ("ride_out", C.c_void_p), ("pre_scale", C.c_double)]
 
 
 class Counters(C.Structure):
@@ -464,7 +464,7 @@ class Shard:
 
     def cg_solve_aat2(self, v_a, mu_start_a, v_b, tau, gam2, max_iter, mu_a, at_mu_a, mu_b, aat_mu_a=None, ata_mu_b=None,
                       aat_mu_start_a=None, at_mu_start_a=None, accumulate_at_mu_a=False, ata_v_b=None, have_ata_v_b=False,
-                      pre_x=None, pre_out=None, ride_x=None, ride_out=None):
+                      pre_x=None, pre_out=None, ride_x=None, ride_out=None, pre_scale=0.0):
         """gv_cg_solve_aat (system a, N-space) and the Onsager gv_cg_solve (system b, M-space) on shared passes; the last three
         arguments are gv_aat_warm (gv_cg_solve_aat2w): A A^T mu_start_a / A^T mu_start_a known from the previous call, and
         A^T mu_a accumulated inside the solve instead of by a closing pass."""
@@ -473,7 +473,7 @@ class Shard:
         wm = AatWarm(aat_mu_start_a.h if aat_mu_start_a is not None else None,
                      at_mu_start_a.h if at_mu_start_a is not None else None, int(bool(accumulate_at_mu_a)),
                      ata_v_b.h if ata_v_b is not None else None, int(bool(have_ata_v_b)),
-                     *[q.h if q is not None else None for q in (pre_x, pre_out, ride_x, ride_out)])
+                     *[q.h if q is not None else None for q in (pre_x, pre_out, ride_x, ride_out)], float(pre_scale))
         self._ck(self.L.gv_cg_solve_aat2w(self.h, v_a.h, mu_start_a.h if mu_start_a is not None else None, v_b.h, tau, gam2,
                                           max_iter, mu_a.h, at_mu_a.h, mu_b.h, C.byref(sa), C.byref(sb), _dp(ra), _dp(rb),
                                           aat_mu_a.h if aat_mu_a is not None else None,

@@ -937,7 +937,9 @@ void free_dataset(gv_ctx* c) {
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.tiles); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
     F(c->plan.cv2); F(c->plan.ev2);
     F(c->plan.scal); F(c->plan.partial);
-    F(c->cgx_state); F(c->cgx_go); F(c->cgx_rel);
+    F(c->cgx_state); F(c->cgx_go);
+    if (c->cgx_rel_h) (void)hipHostFree(c->cgx_rel_h);
+    c->cgx_rel = c->cgx_rel_h = nullptr;
     F(c->aat_slab);
     c->aat_slab_cap = 0;
     c->cgx_relcap = 0;

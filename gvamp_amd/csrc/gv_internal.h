@@ -82,8 +82,14 @@ struct gv_ctx {
     // (2 x cgx_relcap doubles), a pinned staging block for the initial states
     double* cgx_state = nullptr;
     int* cgx_go = nullptr;
-    double* cgx_rel = nullptr;
+    double* cgx_rel = nullptr;     // (device view of mapped, coherent HOST memory: the decide kernels write a trace entry per step straight
+    double* cgx_rel_h = nullptr;   //  into it and the host reads it behind the status it already waits for -- no copy, no event)
     int cgx_relcap = 0;
+    // How far the device-resident loops enqueue ahead of their statuses: the steps (cg_run_device) / passes (gv_cg_solve_aat2w) the
+    // previous solve of the same kind needed.  From that count on the host reads the status of the step it has just enqueued before
+    // it enqueues another -- consecutive VAMP iterations repeat their step counts, and a step enqueued after the last one costs a
+    // dozen dropped launches (~60 us) where a wrong guess the other way costs one host round trip (~15 us).  0 = no hint yet.
+    int spec_hint_steps = 0, spec_hint_passes = 0;
     void* stripes_slab = nullptr;  // owner of plan.stripes_n | plan.stripes_m when the two stripe sets share one allocation (ingest)
     double* aat_slab = nullptr;    // work vectors of the N-space solvers (gv_solvers.hip: aat_scratch), kept between calls
     size_t aat_slab_cap = 0;

@@ -218,9 +218,17 @@ static int cgx_alloc(gv_ctx* c, int max_iter) {
         HIPCHK(c, hipMalloc(&c->cgx_go, sizeof(int) * 4));
     }
     if (max_iter > c->cgx_relcap) {
-        if (c->cgx_rel) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->cgx_rel); c->cgx_rel = nullptr; }
+        // residual traces: mapped, coherent host memory like the mailbox.  A decide kernel stores its entry before it releases the
+        // status flag the host waits for anyway, so the trace is in host memory when the solve returns -- the two device-to-host
+        // copies a solve used to end with cost the host ~20 us each (profiles/r4_cfg5_gaps.txt: the gaps around copyBuffer)
+        if (c->cgx_rel_h) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->cgx_rel_h); c->cgx_rel = c->cgx_rel_h = nullptr; c->cgx_relcap = 0; }
         const int cap = max_iter < 64 ? 64 : max_iter;
-        HIPCHK(c, hipMalloc(&c->cgx_rel, sizeof(double) * 2 * cap));
+        void *hp = nullptr, *dp = nullptr;
+        HIPCHK(c, hipHostMalloc(&hp, sizeof(double) * 2 * cap, hipHostMallocMapped | hipHostMallocCoherent));
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return fail(c, "cgx_alloc: no device view of the trace buffer"); }
+        memset(hp, 0, sizeof(double) * 2 * cap);
+        c->cgx_rel_h = static_cast<double*>(hp);
+        c->cgx_rel = static_cast<double*>(dp);
         c->cgx_relcap = cap;
     }
     return 0;
@@ -390,10 +398,12 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             KCHK(c);
             steps.push_back(seq);
         }
-        // ---- the status of the step BEFORE the one just enqueued
-        if (steps.size() >= 2) {
+        // ---- the status of the step BEFORE the one just enqueued -- or, once the solve has made as many steps as the previous one
+        // needed (gv_ctx::spec_hint_steps), of the step just enqueued: it is probably the last
+        const bool likely_last = c->spec_hint_steps > 0 && (int)steps.size() >= c->spec_hint_steps;
+        if (likely_last || steps.size() >= 2) {
             CgxStatus s2[2];
-            if (cgx_wait(c, steps[steps.size() - 2], s2)) return 1;
+            if (cgx_wait(c, likely_last ? steps.back() : steps[steps.size() - 2], s2)) return 1;
             apply_status(s2);
         }
     }
@@ -416,6 +426,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         if (rode) c->cnt.n_ax += 1;
         c->cnt.n_ax_pass += executed;
         c->cnt.n_atx_pass += executed;
+        c->spec_hint_steps = executed;
         for (int k = 0; k < nsys; k++) {
             CgSys& s = sys[k];
             s.active = false;
@@ -426,9 +437,9 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             s.n_relres = (int)last[k].nrel;
             // the device trace is indexed by the iteration number of the solve; entries below done_iters[k] were written by
             // the host-driven rounds before the hand-over
-            if (s.relres && s.n_relres > done_iters[k])
-                if (to_host(c, s.relres + done_iters[k], drel[k] + done_iters[k], sizeof(double) * (size_t)(s.n_relres - done_iters[k])))
-                    return 1;
+            if (s.relres && s.n_relres > done_iters[k])      // (in host memory already: written ahead of the status just read)
+                memcpy(s.relres + done_iters[k], c->cgx_rel_h + (size_t)k * c->cgx_relcap + done_iters[k],
+                       sizeof(double) * (size_t)(s.n_relres - done_iters[k]));
         }
     }
     if (ride_done) *ride_done = rode;
@@ -803,7 +814,7 @@ int gv_cg_solve_aat(gv_ctx* c, const gv_vec* v, const gv_vec* mu_start, double t
                 n_relres = (int)stt.nrel;
                 if (stt.active == 0.0) { converged = (int)stt.conv; break; }
             }
-            if (relres && n_relres > 0) AAT_TRY(to_host(c, relres, c->cgx_rel, sizeof(double) * (size_t)n_relres));
+            if (relres && n_relres > 0) memcpy(relres, c->cgx_rel_h, sizeof(double) * (size_t)n_relres);
             AAT_HIP(hipGetLastError());
             goto done;
         }
@@ -999,7 +1010,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
             if (dev && sb.relres) sb.relres = &rel0;
             MIX_TRY(cg_first_step_from_known_product(c, sb, tau, gam2, diag_b, max_iter, multi));
             sb.relres = keep_rel;
-            if (dev && keep_rel && sb.n_relres > 0) gvk::fill(s, c->cgx_rel + c->cgx_relcap, 1, rel0);
+            if (dev && keep_rel && sb.n_relres > 0) c->cgx_rel_h[c->cgx_relcap] = rel0;      // (host memory: the device writes the later entries)
             if (dev) MIX_TRY(cgx_upload_sys(c, 1, sb));
         }
     }
@@ -1192,8 +1203,10 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
                             }
                         }
                         kind = 1 - kind;
-                        // the status of everything but the step just enqueued
-                        while (applied + 1 < steps.size()) {
+                        // the status of everything but the step just enqueued -- of that one too once the solve has made as many
+                        // passes as the previous one needed (gv_ctx::spec_hint_passes): it is probably the last
+                        const bool likely_last = c->spec_hint_passes > 0 && (int)passes.size() >= c->spec_hint_passes;
+                        while (applied + (likely_last ? 0 : 1) < steps.size()) {
                             CgxStatus s2[2];
                             MIX_TRY(cgx_wait(c, steps[applied].seq, s2));
                             apply(steps[applied], s2[0]);
@@ -1211,6 +1224,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
                     // (unless the rider took it: it rode in the first Ax pass in which exactly one system had finished).
                     {
                         const int last_useful = endA > endB ? endA : endB;
+                        c->spec_hint_passes = last_useful + 1;
                         int64_t d_ax = 0, d_atx = 0, d_axp = 0, d_atxp = 0;
                         bool rider_slot_found = false;
                         for (int i = 0; i < (int)passes.size(); i++) {
@@ -1278,7 +1292,7 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
                 h->pending = false;
                 if (h == &hz) continue;                                            // the rider's product is in place
                 if (h == &hr) {                                                    // v_a = y - A r2 is complete: solve a can start
-                    gvk::axpby(s, v_a->d, 1.0, v_a->d, -1.0, hr.dst, n);
+                    gvk::axpby(s, v_a->d, 1.0, v_a->d, wm->pre_scale != 0.0 ? -wm->pre_scale : -1.0, hr.dst, n);
                     MIX_TRY(a_start());
                     continue;
                 }
@@ -1339,9 +1353,9 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
             }
         }
         if (dev) {        // residual traces were written on the device
-            if (relres_a && a_nrel > 0) MIX_TRY(to_host(c, relres_a, c->cgx_rel, sizeof(double) * (size_t)a_nrel));
-            if (relres_b && sb.n_relres > 0)
-                MIX_TRY(to_host(c, relres_b, c->cgx_rel + c->cgx_relcap, sizeof(double) * (size_t)sb.n_relres));
+            // (every status has been read: the entries are in host memory)
+            if (relres_a && a_nrel > 0) memcpy(relres_a, c->cgx_rel_h, sizeof(double) * (size_t)a_nrel);
+            if (relres_b && sb.n_relres > 0) memcpy(relres_b, c->cgx_rel_h + c->cgx_relcap, sizeof(double) * (size_t)sb.n_relres);
         }
         if (aat_mu_a) {   // Q_A mu_a = v_a - r  =>  A A^T mu_a = (v_a - r - gam2 mu_a) / tau
             gvk::axpby(s, aat_mu_a->d, 1.0 / tau, v_a->d, -1.0 / tau, r, n);

@@ -73,7 +73,7 @@ vamp::vamp(int M, double gam1, double gamw, std::vector<double> true_signal, int
 vamp::~vamp() {
     if (!ctx) return;
     for (gv_vec* v : {x1_hat, x1_hat_prev, x2_hat, r1, r2, r2_prev, z1, y, mu_CG_last, bern_vec, invQ_bern_vec, vM, tM,
-                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, at_u, ata_u, unfrozen, frozen, dvec})
+                      tN, tN2, mu_CG_last_N, aty, ax2_der, ata_der, aat_der, ata_x2, at_u, ata_u, unfrozen, frozen, dvec, ar1, ar2})
         if (v) gv_vec_free(ctx, v);
 }
 
@@ -286,6 +286,9 @@ std::vector<double> vamp::infere_linear(data* dataset) {
     alpha1 = 0;
     alpha2 = 0;   // read at vamp.cpp:501 before its first assignment (:631); harmless there, 0 here
     have_ata_x2 = have_aat_prev = false;
+    // A r1 is known at the start of a fresh run: r1 = 0 (a restart / an initial estimate load r1: its product is not at hand)
+    have_ar1 = gam1_init == -1 && init_est != 1;
+    if (ar1) ck(gv_vec_fill(ctx, ar1, 0.0), "gv_vec_fill");       // (a second run on this object)
     warm_chain = true;      // the LMMSE solves of this loop warm-start one another (infere_bin_class starts every solve from zero)
     const double sqrtN = sqrt((double)N);
 
@@ -419,6 +422,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         if (verbose && rank == 0) std::cout << "eta1 = " << eta1 << std::endl << "gam2 = " << gam2 << std::endl;
         ck(gv_vec_copy(ctx, r2_prev, r2), "gv_vec_copy");                 // :483
         ck(gv_vec_axpby(ctx, r2, eta1 / gam2, x1_hat, -gam1 / gam2, r1), "gv_vec_axpby");   // :485-486
+        r2_c1 = eta1 / gam2;
+        r2_c2 = gam1 / gam2;
         if (use_lmmse_damp == 1 && it > 1) {                              // :488-498
             const double xi = std::min(2 * rho, 1.0);
             gam2 = 1.0 / pow(xi / sqrt(gam2) + (1 - xi) / sqrt(gam_before), 2);
@@ -503,13 +508,21 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             // level 4: A r2 and z1 are taken inside the joint solve (gv_aat_warm.pre_x / ride_x) -- A r2 in the pass that carries
             // the first half-application of the Onsager solve, so that the two solves run in phase, z1 in a free slot
             const bool inside = fuse_solves >= 4;
+            // ... and with A r1 at hand (carried from the previous iteration, 0 at the start) that pass carries z1 = A x1_hat, not A r2:
+            // A r2 = c1 z1 - c2 A r1 by linearity.  One pass fewer per iteration whenever the two solves finish in the same step
+            // (z1 then found no free slot and took a pass of its own).  Every reanchor_every-th iteration takes the explicit products.
+            for (gv_vec** v : {&ar1, &ar2})
+                if (inside && !*v) ck(gv_vec_alloc(ctx, GV_SPACE_N, v), "gv_vec_alloc");       // (zero-filled: A r1 of r1 = 0)
+            const bool by_linearity = inside && have_ar1 && !reanchor_now();
             auto z1_outputs = [&]() {
                 double tz = now_s();
                 z1_outputs_a();
                 t_io += now_s() - tz;
                 z1_outputs_b();
             };
-            if (inside)
+            if (by_linearity)
+                ck(gv_vec_axpby(ctx, tN, 1.0, y, r2_c2, ar1), "gv_vec_axpby");   // the solver turns y + c2 A r1 into y - A r2 (- c1 z1)
+            else if (inside)
                 ck(gv_vec_copy(ctx, tN, y), "gv_vec_copy");                // the solver turns it into y - A r2
             else {
                 ck(gv_ax2_dev(ctx, x1_hat, r2, z1, ax2_der), "gv_ax2_dev");   // z1 = A x1_hat (:429) and A r2, one pass
@@ -536,7 +549,8 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 at_out = at_u;
                 wm.accumulate_at_mu_a = 1;
                 if (known_start) { wm.aat_mu_start_a = aat_der; wm.at_mu_start_a = at_u; }
-                if (inside) { wm.pre_x = r2; wm.pre_out = ax2_der; wm.ride_x = x1_hat; wm.ride_out = z1; }
+                if (by_linearity) { wm.pre_x = x1_hat; wm.pre_out = z1; wm.pre_scale = r2_c1; }
+                else if (inside) { wm.pre_x = r2; wm.pre_out = ax2_der; wm.ride_x = x1_hat; wm.ride_out = z1; }
                 if (fuse_solves >= 4 && CG_max_iter > 0) {      // A^T A u of the probe, as in fused_solves
                     if (!ata_u) ck(gv_vec_alloc(ctx, GV_SPACE_M, &ata_u), "gv_vec_alloc");
                     if (reanchor_now()) have_ata_u = false;
@@ -553,7 +567,11 @@ std::vector<double> vamp::infere_linear(data* dataset) {
                 have_ata_u = probe_product_is_usable(gamw, gam2);
                 probe_product_state = have_ata_u ? 1 : 2;
             }
-            if (inside) z1_outputs();
+            if (by_linearity) ck(gv_vec_axpby(ctx, ax2_der, r2_c1, z1, -r2_c2, ar1), "gv_vec_axpby");   // A r2
+            if (inside) {
+                ck(gv_vec_copy(ctx, ar2, ax2_der), "gv_vec_copy");         // (kept: ax2_der becomes A x2_hat below)
+                z1_outputs();
+            }
             st.cg_iters = sa.iters;
             st.onsager_iters = sb.iters;
             if (verbose && rank == 0) {
@@ -646,6 +664,10 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         st.eta2 = eta2; st.gam2_reest = gam2;
         gam1 = std::min(std::max(eta2 - gam2, gamma_min), gamma_max);     // :702
         ck(gv_vec_axpby(ctx, r1, eta2 / gam1, x2_hat, -gam2 / gam1, r2), "gv_vec_axpby");   // :706-707
+        if (reverse == 1 && fuse_solves >= 4 && ar1 && have_derived) {   // A r1 of the next iteration, from A x2_hat and A r2
+            ck(gv_vec_axpby(ctx, ar1, eta2 / gam1, ax2_der, -gam2 / gam1, ar2), "gv_vec_axpby");
+            have_ar1 = true;
+        }
         st.gam1_next = gam1;
         if (verbose && rank == 0) std::cout << "gam2 re-est = " << gam2 << std::endl << "gam1 = " << gam1 << std::endl;
 

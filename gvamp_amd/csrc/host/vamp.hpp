@@ -98,6 +98,12 @@ public:
     gv_vec* ata_u = nullptr;        // level 3: A^T A u of the Onsager probe (the same u every iteration): its solve starts one step in
     bool have_ata_u = false;
     gv_vec* at_u = nullptr;         // --use-XXT-denoiser 1 at level 3: A^T u, accumulated inside the N-space solve
+    // --use-XXT-denoiser 1 at level 4: A r1 and A r2 carried from iteration to iteration -- r2 = (eta1 x1_hat - gam1 r1) / gam2
+    // (vamp.cpp:485-486) and r1 = (eta2 x2_hat - gam2 r2) / gam1 (:706-707) are linear in vectors whose products are at hand, so
+    // A r2 costs no pass: the first pass of the joint solve carries z1 = A x1_hat instead, and z1 needs no pass of its own
+    gv_vec *ar1 = nullptr, *ar2 = nullptr;
+    bool have_ar1 = false;
+    double r2_c1 = 0, r2_c2 = 0;    // r2 = r2_c1 x1_hat - r2_c2 r1 of the current iteration
     bool have_ata_x2 = false, warm_chain = false, have_aat_prev = false;
     // --use-freeze 1 (vamp.cpp:205-209,:308,:353): markers whose g1d does not enter alpha1 and that are not damped
     int use_freeze = 0;

@@ -277,6 +277,10 @@ typedef struct gv_aat_warm {
     gv_vec* pre_out;
     const gv_vec* ride_x;
     gv_vec* ride_out;
+    /* v_a <- v_a - pre_scale * pre_out (0 = 1).  With pre_x = x1_hat, pre_out = z1 and the caller's v_a = y + (gam1/gam2) A r1 the solve
+     * gets its right-hand side y - A r2 from A r2 = (eta1/gam2) A x1_hat - (gam1/gam2) A r1 (r2 is that combination, vamp.cpp:485-486)
+     * and the iteration's z1 = A x1_hat (vamp.cpp:429) for free: no pass for A r2 (host/vamp.cpp keeps A r1 up to date from A x2_hat). */
+    double pre_scale;
 } gv_aat_warm;
 /* v_a: read only, unless warm->pre_x is set -- then it is updated in place (see pre_x above). */
 int gv_cg_solve_aat2w(gv_ctx* ctx, gv_vec* v_a, const gv_vec* mu_start_a, const gv_vec* v_b, double tau, double gam2,

@@ -168,7 +168,9 @@ def test_vamp_runs_at_fuse_3_and_4_follow_fuse_2_and_the_oracle(oracle, xxt, lev
         passes2, passes3 = a["n_ax_pass"] + a["n_atx_pass"], b["n_ax_pass"] + b["n_atx_pass"]
         # (XXT: the closing A^T u of denoiserXXT.cpp:46 is accumulated inside the solve as well -- one more product, every iteration;
         # and from the second iteration on the Onsager solve takes its first application from A^T A u of the probe: two more)
-        fewer = (2 if i > 0 else 0) + (1 if xxt else 0) + (2 if level >= 4 and i > 0 else 0)
+        # (XXT at level 4: A r2 = c1 A x1_hat - c2 A r1 by linearity -- the first pass of the joint solve carries z1 = A x1_hat and the
+        # product A r2 is never formed: one more, every iteration)
+        fewer = (2 if i > 0 else 0) + (1 if xxt else 0) + (2 if level >= 4 and i > 0 else 0) + (1 if xxt and level >= 4 else 0)
         assert passes2 - fewer <= passes3 <= passes2, (i, passes2, passes3)
         # (level 4 keeps A^T A u from the first iteration whose gam2 / tau lets it be captured without cancellation: the first or
         # the second -- so the second iteration may still apply the operator for the Onsager solve's first step)
@@ -309,3 +311,41 @@ def test_level_4_on_the_other_code_paths(oracle, monkeypatch, variant, xxt):
         assert b["cg_iters"] == int(o["cg_iters"])
     assert sum(t["n_ax"] + t["n_atx"] for t in r4.trace) < sum(t["n_ax"] + t["n_atx"] for t in r0.trace)
     assert rel(r4.x_est, r0.x_est) < 1e-8 and rel(r4.x_est, ref.x_est) < 1e-7
+
+
+@pytest.mark.parametrize("reanchor", [0, 2, 3])
+def test_xxt_level_4_takes_A_r2_by_linearity_and_reanchors(oracle, reanchor):
+    """--use-XXT-denoiser 1 at level 4: r2 = (eta1 x1_hat - gam1 r1) / gam2 and r1 = (eta2 x2_hat - gam2 r2) / gam1 are linear in
+    vectors whose products are at hand, so the joint solve's first pass carries z1 = A x1_hat and A r2 is never multiplied out
+    (host/vamp.cpp: ar1 / ar2).  Follows level 0 and the oracle; one product fewer than the explicit form in every iteration but the
+    re-anchored ones (--reanchor-every K: explicit A r2 and z1 there, so that rounding never chains over more than K iterations)."""
+    N, M = 1500, 2200
+    bed = synth.synth_bed(N, M, seed=61, miss_ppm=5000)
+    beta, y = oracle.sim_phen(bed, N, M, 0.5, 110, 9)
+    probs, vars_ = [0.9, 0.07, 0.03], [0, 1e-3, 1e-2]
+    kw = dict(iterations=7, CG_max_iter=40, rho=0.5, seed=9, true_signal=beta, history=True, use_XXT_denoiser=1)
+    ref = oracle.infere(bed, N, M, y, probs, vars_, **{k: v for k, v in kw.items() if k != "history"})
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        r0 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=0, **kw)
+        r3 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=3, reanchor_every=reanchor, **kw)
+        r4 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=4, reanchor_every=reanchor, **kw)
+        r4b = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=4, reanchor_every=reanchor, **kw)      # a second run on the shard
+    assert r4.niter == r0.niter == ref.niter == 7
+    for i, (a, b, o) in enumerate(zip(r0.trace, r4.trace, ref.trace)):
+        assert (b["cg_iters"], b["onsager_iters"], b["L_after"]) == (a["cg_iters"], a["onsager_iters"], a["L_after"]), i
+        assert b["cg_iters"] == int(o["cg_iters"])
+        for k in ("gam1_denoise", "alpha1", "gam2", "alpha2", "gamw", "gam1_next", "R2_denoise", "R2_lmmse"):
+            assert abs(a[k] - b[k]) <= 1e-9 * abs(a[k]), (i, k, a[k], b[k])
+    assert rel(r4.x_est, r0.x_est) < 1e-9 and rel(r4.x_est, ref.x_est) < 1e-7
+    for i in range(7):
+        assert rel(r4.x1[i], r0.x1[i]) < 1e-9 and rel(r4.x2[i], r0.x2[i]) < 1e-9
+    assert np.array_equal(r4b.x_est, r4.x_est)
+    # products: level 4 against level 3 on the same schedule of re-anchored iterations (iteration numbers it = i + 1 > 1 with
+    # it % reanchor == 0) -- A r2 is gone wherever the iteration is not re-anchored; the probe's A^T A u (level 4) saves two more
+    for i, (a, b) in enumerate(zip(r3.trace, r4.trace)):
+        anchored = reanchor > 0 and i > 0 and (i + 1) % reanchor == 0
+        d = a["n_ax"] + a["n_atx"] - (b["n_ax"] + b["n_atx"])
+        assert d in ({0, 2} if anchored else {1, 3}), (i, anchored, d)
+        assert b["n_ax_pass"] + b["n_atx_pass"] <= a["n_ax_pass"] + a["n_atx_pass"], i

@@ -137,7 +137,7 @@ def test_joint_nspace_and_onsager_solves_equal_the_separate_ones(warm):
         assert rel(ata.download(), sh.ATx(sh.Ax(mu_b))) < 1e-10
 
 
-@pytest.mark.parametrize("fuse", [0, 2])
+@pytest.mark.parametrize("fuse", [0, 2, 4])
 def test_xxt_sharded_run_vs_oracle(oracle, fuse):
     """--use-XXT-denoiser 1 on two marker shards (in-process communicator): people statistics all-reduced over the
     shards (data.cpp:604-606), N-space vectors replicated, M-space Onsager solve sharded."""
