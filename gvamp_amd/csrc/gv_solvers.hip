@@ -262,8 +262,10 @@ static int cgx_wait(gv_ctx* c, unsigned long long seq, CgxStatus* out2) {
 // device: while the rider is pending every step is enqueued two-vector shaped (slot v = system v); k_prep_ax feeds ride_x
 // into the slot of a system that has finished (if the other one is still running), k_ride_copy moves the product out and
 // k_cgx_decide marks the rider done (status word 7) -- the same step in which the host-driven loop would have placed it.
+// state_on_device: the state blocks were built on the device by the opening (cg_open_device): nothing to upload, and the residual
+// traces start at entry 0 on the device.
 static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x,
-                         double* ride_out, bool* ride_done) {
+                         double* ride_out, bool* ride_done, bool state_on_device = false) {
     const int64_t M = c->M, npad = c->npad;
     hipStream_t st = c->stream;
     const bool multi = is_multi(c);
@@ -287,7 +289,8 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             q[gvm::ST_CONV] = s.converged; q[gvm::ST_NRELRES] = s.n_relres; q[gvm::ST_DENOISER] = s.denoiser;
             go0 |= s.active ? 1 : 0;
         }
-        gvk::state_init(st, c->cgx_state + k * gvm::ST_SIZE, q);        // (by value in the launch: no pinned staging to protect)
+        if (!state_on_device || k >= nsys)
+            gvk::state_init(st, c->cgx_state + k * gvm::ST_SIZE, q);    // (by value in the launch: no pinned staging to protect)
     }
     gvk::set_ints(st, c->cgx_go, go0, riding ? 1 : 0);                    // rider word: 1 pending, 2 rode
     KCHK(c);
@@ -437,9 +440,9 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
             s.n_relres = (int)last[k].nrel;
             // the device trace is indexed by the iteration number of the solve; entries below done_iters[k] were written by
             // the host-driven rounds before the hand-over
-            if (s.relres && s.n_relres > done_iters[k])      // (in host memory already: written ahead of the status just read)
-                memcpy(s.relres + done_iters[k], c->cgx_rel_h + (size_t)k * c->cgx_relcap + done_iters[k],
-                       sizeof(double) * (size_t)(s.n_relres - done_iters[k]));
+            const int from = state_on_device ? 0 : done_iters[k];
+            if (s.relres && s.n_relres > from)      // (in host memory already: written ahead of the status just read)
+                memcpy(s.relres + from, c->cgx_rel_h + (size_t)k * c->cgx_relcap + from, sizeof(double) * (size_t)(s.n_relres - from));
         }
     }
     if (ride_done) *ride_done = rode;
@@ -522,6 +525,50 @@ static int mspace_step_device(gv_ctx* c, CgSys& sb, double gam2, double diag, in
     return 0;
 }
 
+// ---- the opening of a solve on the device (one rank, device-resident loop): z = r / diag with <r,z> and ||v||^2 stay block partials,
+// the state block of the system is built from them on the device (k_state_from_partials) -- and with A^T A v at hand the first
+// step of a zero-started solve (d = (tau / diag) A^T A v + gam2 p: no pass) is a device step like every later one.  The
+// host-driven opening (cg_finish_init, cg_first_step_from_known_product) reads scalars back five times for the two solves of a VAMP
+// iteration, ~280 us of a 13 ms iteration at N = 400k x M = 125k (profiles/r5_forced_multi_gaps.txt, plain leg); this one never.
+// Same kernels, same sums in the same order, same IEEE divisions and square roots: the same bits.
+static int cg_open_device(gv_ctx* c, CgSys& s, int blk, double tau, double gam2, double diag, int max_iter) {
+    const int64_t M = c->M;
+    hipStream_t st = c->stream;
+    double* part = c->red_partial + (size_t)blk * RED_BLOCKS * 8;       // the system's own region, as in cg_run_device
+    double* stb = c->cgx_state + blk * gvm::ST_SIZE;
+    gvk::cg_step_b(st, s.r, s.d, 0.0, diag, s.z, s.mu, M, part, nullptr);              // z = r / diag (:1152); partials of <r,z> ...
+    const double* vv[1] = {s.v};
+    gvk::dots(st, 1, vv, vv, M, part + 4 * RED_BLOCKS, nullptr);                        // ... and of ||v||^2
+    gvk::copy(st, s.p, s.z, M);                                                         // p = z (:1154)
+    double q[gvm::ST_SIZE];
+    for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+    q[gvm::ST_ACTIVE] = 1.0;
+    q[gvm::ST_DENOISER] = s.denoiser;
+    gvk::state_from_partials(st, stb, q, part, 4, 0, part + 4 * RED_BLOCKS, M, true);
+    s.phase = 1;
+    s.req = s.p;
+    s.res = s.d;
+    if (s.ata_v && s.ata_v_known && !s.mu0) {       // the first step from the known product (cg_first_step_from_known_product)
+        gvk::axpby(st, s.d, tau / diag, s.ata_v, gam2, s.p, M);
+        const double *xs[1] = {s.d}, *ys[1] = {s.p};
+        gvk::dots(st, 1, xs, ys, M, part, nullptr);
+        double *a_st[1] = {stb}, *a_mu[1] = {s.mu}, *a_r[1] = {s.r}, *a_z[1] = {s.z}, *a_part[1] = {part + 4 * RED_BLOCKS},
+               *a_red[1] = {c->red_out + 8 * blk};
+        const double *a_p[1] = {s.p}, *a_v[1] = {s.v}, *a_d[1] = {s.d}, *a_dp[1] = {c->red_out + 8 * blk}, *a_dpp[1] = {part};
+        const int nb_ab = gvk::cgx_ab(st, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M, a_dpp,
+                                      gvm::atx_dot_blocks(c->plan));
+        const double* c_red[1] = {c->red_out + 8 * blk};
+        const double* c_part[1] = {a_part[0]};
+        double* c_rel[1] = {s.relres ? c->cgx_rel + (size_t)blk * c->cgx_relcap : nullptr};
+        // (nobody waits for this status: the loop's first step publishes the state of both systems)
+        gvk::cgx_decide(st, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
+                        reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), ++c->mbox_seq, nullptr, nullptr, nullptr, c_part, nb_ab);
+        s.iters = 1;                                // (the host's count of steps that cost no product: cg_run_device starts from it)
+    }
+    KCHK(c);
+    return 0;
+}
+
 // ride_x / ride_out (may be NULL): out = data::Ax(ride_x), taken along in the free slot of the first round in which only
 // one system is still active (a two-vector pass costs what a one-vector pass costs), else by a pass of its own.
 static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int max_iter, const double* ride_x = nullptr,
@@ -529,6 +576,12 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
     const int64_t M = c->M;
     const bool multi = is_multi(c);
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
+    const bool device_loop = cgx_usable(c);
+    // one rank, every system opening without an operator application of its own (zero start, or a warm start whose products are
+    // known): the opening runs on the device too (cg_open_device) -- chosen by nothing rank-local
+    bool dev_open = device_loop && !multi && M > 0 && max_iter > 0;
+    for (int k = 0; k < nsys; k++) dev_open = dev_open && !(sys[k].mu0 && !sys[k].ata0);
+    if (dev_open && cgx_alloc(c, max_iter)) return 1;
     for (int k = 0; k < nsys; k++) {
         CgSys& s = sys[k];
         if (s.mu0 && s.ata0) {
@@ -540,7 +593,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             if (s.az && s.amu0 != s.az)
                 gvk::copy(c->stream, s.az, s.amu0, c->npad);   // A mu0
             KCHK(c);
-            if (cg_finish_init(c, s, diag, multi)) return 1;
+            if (dev_open ? cg_open_device(c, s, k, tau, gam2, diag, max_iter) : cg_finish_init(c, s, diag, multi)) return 1;
         } else if (s.mu0) {
             gvk::copy(c->stream, s.mu, s.mu0, M);
             s.phase = 0;
@@ -550,13 +603,12 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             gvk::fill(c->stream, s.mu, M, 0.0);
             if (s.az) gvk::fill(c->stream, s.az, c->npad, 0.0);
             gvk::copy(c->stream, s.r, s.v, M);
-            if (cg_finish_init(c, s, diag, multi)) return 1;
+            if (dev_open ? cg_open_device(c, s, k, tau, gam2, diag, max_iter) : cg_finish_init(c, s, diag, multi)) return 1;
         }
         if (max_iter <= 0 && s.phase == 1) s.active = false;
     }
-    for (int k = 0; k < nsys; k++)
+    for (int k = 0; k < nsys && !dev_open; k++)
         if (cg_first_step_from_known_product(c, sys[k], tau, gam2, diag, max_iter, multi)) return 1;
-    const bool device_loop = cgx_usable(c);
     for (;;) {
         CgSys* act[2];
         int na = 0;
@@ -570,7 +622,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
         if (device_loop && all_stepping) {
             // every active system is past its initial residual: hand the steady state to the device-resident loop
             bool rode = false;
-            if (cg_run_device(c, sys, nsys, tau, gam2, max_iter, ride_x, ride_out, &rode)) return 1;
+            if (cg_run_device(c, sys, nsys, tau, gam2, max_iter, ride_x, ride_out, &rode, dev_open)) return 1;
             if (rode) ride_x = nullptr;
             break;
         }

@@ -5,3 +5,4 @@ f=$(find $O/cfg5 -name "*kernel_trace.csv" | head -1); cp $f $O/cfg5_kernel_trac
 python3 scripts/trace_gaps.py $f -27 > $O/cfg5_gaps.txt 2>&1; head -14 $O/cfg5_gaps.txt; cat $O/cfg5.out
 python3 scripts/trace_tail.py $f 130 > $O/cfg5_tail.txt
 rm -rf $O/cfg5
+python3 scripts/trace_phases.py $O/cfg5_kernel_trace.csv 4 > $O/cfg5_phases.txt; cat $O/cfg5_phases.txt
