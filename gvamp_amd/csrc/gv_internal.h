@@ -193,6 +193,7 @@ void set_ints(hipStream_t s, int* dst, int a, int b);
 // the state block of a system at its start from the block partials of its two opening reductions over n entries (one rank)
 void state_from_partials(hipStream_t s, double* dst, const double* q, const double* part_rz, int K_rz, int k_rz, const double* part_vv,
                          int64_t n, bool sqrt_norm);
+void state_from_scalars(hipStream_t s, double* dst, const double* q, const double* rz, const double* vv, bool sqrt_norm);
 void cgx_decide(hipStream_t s, int nsys, double* const* st, const double* const* red, double* const* relres, double gam2,
                 int max_iter, int* go, double* mailbox, unsigned long long* flag, unsigned long long seq, int* ride,
                 const double* other_st = nullptr, const int* ride_report = nullptr, const double* const* part = nullptr,

@@ -789,6 +789,16 @@ __global__ __launch_bounds__(256) void k_state_from_partials(double* __restrict_
         dst[threadIdx.x] = q;
     }
 }
+// ... or from scalars that have been summed over the ranks already (sharded jobs: finalize + in-stream all-reduce, no host)
+__global__ void k_state_from_scalars(double* __restrict__ dst, StateInit a, const double* __restrict__ rz, const double* __restrict__ vv,
+                                     int sqrt_norm) {
+    if (threadIdx.x < gvm::ST_SIZE) {
+        double q = a.q[threadIdx.x];
+        if (threadIdx.x == gvm::ST_RZ) q = rz[0];
+        if (threadIdx.x == gvm::ST_NORMV) q = sqrt_norm ? sqrt(vv[0]) : vv[0];
+        dst[threadIdx.x] = q;
+    }
+}
 __global__ void k_set_ints(int* __restrict__ dst, int a, int b) {
     if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
 }
@@ -1275,6 +1285,11 @@ void state_from_partials(hipStream_t s, double* dst, const double* q, const doub
     for (int i = 0; i < gvm::ST_SIZE; i++) a.q[i] = q[i];
     const int nb = red_blocks(n, 256);        // both reductions ran over n entries
     hipLaunchKernelGGL(k_state_from_partials, dim3(1), dim3(256), 0, s, dst, a, part_rz, nb, K_rz, k_rz, part_vv, nb, sqrt_norm ? 1 : 0);
+}
+void state_from_scalars(hipStream_t s, double* dst, const double* q, const double* rz, const double* vv, bool sqrt_norm) {
+    StateInit a;
+    for (int i = 0; i < gvm::ST_SIZE; i++) a.q[i] = q[i];
+    hipLaunchKernelGGL(k_state_from_scalars, dim3(1), dim3(64), 0, s, dst, a, rz, vv, sqrt_norm ? 1 : 0);
 }
 void set_ints(hipStream_t s, int* dst, int a, int b) { hipLaunchKernelGGL(k_set_ints, dim3(1), dim3(64), 0, s, dst, a, b); }
 void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride) {

@@ -525,47 +525,75 @@ static int mspace_step_device(gv_ctx* c, CgSys& sb, double gam2, double diag, in
     return 0;
 }
 
-// ---- the opening of a solve on the device (one rank, device-resident loop): z = r / diag with <r,z> and ||v||^2 stay block partials,
-// the state block of the system is built from them on the device (k_state_from_partials) -- and with A^T A v at hand the first
-// step of a zero-started solve (d = (tau / diag) A^T A v + gam2 p: no pass) is a device step like every later one.  The
-// host-driven opening (cg_finish_init, cg_first_step_from_known_product) reads scalars back five times for the two solves of a VAMP
-// iteration, ~280 us of a 13 ms iteration at N = 400k x M = 125k (profiles/r5_forced_multi_gaps.txt, plain leg); this one never.
-// Same kernels, same sums in the same order, same IEEE divisions and square roots: the same bits.
-static int cg_open_device(gv_ctx* c, CgSys& s, int blk, double tau, double gam2, double diag, int max_iter) {
+// ---- the opening of a solve on the device (device-resident loop): z = r / diag with <r,z> and ||v||^2, the state block of each
+// system built on the device from those sums -- one rank: from the block partials (k_state_from_partials); sharded: finalised,
+// all-reduced IN STREAM (one message for every system of the call) and picked up by k_state_from_scalars -- and with A^T A v at
+// hand the first step of a zero-started solve (d = (tau / diag) A^T A v + gam2 p: no pass) is a device step like every later one.
+// The host-driven opening (cg_finish_init, cg_first_step_from_known_product) reads scalars back five times for the two solves of a
+// VAMP iteration -- ~280 us of a 13 ms iteration at N = 400k x M = 125k (profiles/r5_forced_multi_gaps.txt), and on a sharded job
+// each of them with a host-side all-reduce round trip behind it; this one never touches the host.  Same kernels, same sums in the
+// same order, same IEEE divisions and square roots: the same bits.  An empty shard (M == 0) enters the same collectives with zeros.
+static int cg_open_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, double diag, int max_iter, bool multi) {
     const int64_t M = c->M;
     hipStream_t st = c->stream;
-    double* part = c->red_partial + (size_t)blk * RED_BLOCKS * 8;       // the system's own region, as in cg_run_device
-    double* stb = c->cgx_state + blk * gvm::ST_SIZE;
-    gvk::cg_step_b(st, s.r, s.d, 0.0, diag, s.z, s.mu, M, part, nullptr);              // z = r / diag (:1152); partials of <r,z> ...
-    const double* vv[1] = {s.v};
-    gvk::dots(st, 1, vv, vv, M, part + 4 * RED_BLOCKS, nullptr);                        // ... and of ||v||^2
-    gvk::copy(st, s.p, s.z, M);                                                         // p = z (:1154)
-    double q[gvm::ST_SIZE];
-    for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
-    q[gvm::ST_ACTIVE] = 1.0;
-    q[gvm::ST_DENOISER] = s.denoiser;
-    gvk::state_from_partials(st, stb, q, part, 4, 0, part + 4 * RED_BLOCKS, M, true);
-    s.phase = 1;
-    s.req = s.p;
-    s.res = s.d;
-    if (s.ata_v && s.ata_v_known && !s.mu0) {       // the first step from the known product (cg_first_step_from_known_product)
-        gvk::axpby(st, s.d, tau / diag, s.ata_v, gam2, s.p, M);
-        const double *xs[1] = {s.d}, *ys[1] = {s.p};
-        gvk::dots(st, 1, xs, ys, M, part, nullptr);
-        double *a_st[1] = {stb}, *a_mu[1] = {s.mu}, *a_r[1] = {s.r}, *a_z[1] = {s.z}, *a_part[1] = {part + 4 * RED_BLOCKS},
-               *a_red[1] = {c->red_out + 8 * blk};
-        const double *a_p[1] = {s.p}, *a_v[1] = {s.v}, *a_d[1] = {s.d}, *a_dp[1] = {c->red_out + 8 * blk}, *a_dpp[1] = {part};
-        const int nb_ab = gvk::cgx_ab(st, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M, a_dpp,
-                                      gvm::atx_dot_blocks(c->plan));
-        const double* c_red[1] = {c->red_out + 8 * blk};
-        const double* c_part[1] = {a_part[0]};
-        double* c_rel[1] = {s.relres ? c->cgx_rel + (size_t)blk * c->cgx_relcap : nullptr};
-        // (nobody waits for this status: the loop's first step publishes the state of both systems)
-        gvk::cgx_decide(st, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
-                        reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), ++c->mbox_seq, nullptr, nullptr, nullptr, c_part, nb_ab);
-        s.iters = 1;                                // (the host's count of steps that cost no product: cg_run_device starts from it)
+    auto part_of = [&](int k) { return c->red_partial + (size_t)k * RED_BLOCKS * 8; };   // the system's own region, as in cg_run_device
+    auto red_of = [&](int k) { return c->red_out + 8 * k; };
+    for (int k = 0; k < nsys; k++) {
+        CgSys& s = sys[k];
+        if (M > 0) {
+            gvk::cg_step_b(st, s.r, s.d, 0.0, diag, s.z, s.mu, M, part_of(k), multi ? red_of(k) : nullptr);   // z = r / diag (:1152), <r,z> ...
+            const double* vv[1] = {s.v};
+            gvk::dots(st, 1, vv, vv, M, part_of(k) + 4 * RED_BLOCKS, multi ? red_of(k) + 4 : nullptr);         // ... and ||v||^2
+            gvk::copy(st, s.p, s.z, M);                                                                         // p = z (:1154)
+        } else
+            gvk::fill(st, red_of(k), 8, 0.0);
+        s.phase = 1;
+        s.req = s.p;
+        s.res = s.d;
     }
     KCHK(c);
+    if (multi && comm_allreduce(c, c->red_out, (size_t)8 * nsys)) return 1;
+    for (int k = 0; k < nsys; k++) {
+        CgSys& s = sys[k];
+        double* stb = c->cgx_state + k * gvm::ST_SIZE;
+        double q[gvm::ST_SIZE];
+        for (int i = 0; i < gvm::ST_SIZE; i++) q[i] = 0.0;
+        q[gvm::ST_ACTIVE] = 1.0;
+        q[gvm::ST_DENOISER] = s.denoiser;
+        if (multi) gvk::state_from_scalars(st, stb, q, red_of(k), red_of(k) + 4, true);
+        else gvk::state_from_partials(st, stb, q, part_of(k), 4, 0, part_of(k) + 4 * RED_BLOCKS, M, true);
+        KCHK(c);
+        if (!(s.ata_v && s.ata_v_known && !s.mu0)) continue;
+        // the first step from the known product (cg_first_step_from_known_product)
+        if (M > 0) {
+            gvk::axpby(st, s.d, tau / diag, s.ata_v, gam2, s.p, M);
+            const double *xs[1] = {s.d}, *ys[1] = {s.p};
+            gvk::dots(st, 1, xs, ys, M, part_of(k), multi ? red_of(k) : nullptr);
+        } else
+            gvk::fill(st, red_of(k), 8, 0.0);
+        KCHK(c);
+        if (multi && comm_allreduce(c, red_of(k), 8)) return 1;                    // <d,p>
+        double *a_st[1] = {stb}, *a_mu[1] = {s.mu}, *a_r[1] = {s.r}, *a_z[1] = {s.z}, *a_part[1] = {part_of(k) + 4 * RED_BLOCKS},
+               *a_red[1] = {red_of(k)};
+        const double *a_p[1] = {s.p}, *a_v[1] = {s.v}, *a_d[1] = {s.d}, *a_dp[1] = {red_of(k)}, *a_dpp[1] = {part_of(k)};
+        int nb_ab = 0;
+        if (M > 0)
+            nb_ab = gvk::cgx_ab(st, 1, a_st, a_mu, a_p, a_v, a_r, a_d, a_z, a_dp, a_part, a_red, diag, M, multi ? nullptr : a_dpp,
+                                multi ? 0 : gvm::atx_dot_blocks(c->plan));
+        else
+            gvk::fill(st, red_of(k), 8, 0.0);
+        KCHK(c);
+        if (multi && comm_allreduce(c, red_of(k), 8)) return 1;                    // <v,mu>, <r,z>, <r,r>
+        const double* c_red[1] = {red_of(k)};
+        const double* c_part[1] = {a_part[0]};
+        double* c_rel[1] = {s.relres ? c->cgx_rel + (size_t)k * c->cgx_relcap : nullptr};
+        // (nobody waits for this status: the loop's first step publishes the state of every system)
+        gvk::cgx_decide(st, 1, a_st, c_red, c_rel, gam2, max_iter, c->cgx_go, c->mbox_dev,
+                        reinterpret_cast<unsigned long long*>(c->mbox_dev + RED_MAXK), ++c->mbox_seq, nullptr, nullptr, nullptr,
+                        multi ? nullptr : c_part, nb_ab);
+        KCHK(c);
+        s.iters = 1;                                // (the host's count of steps that cost no product: cg_run_device starts from it)
+    }
     return 0;
 }
 
@@ -577,9 +605,9 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
     const bool multi = is_multi(c);
     const double diag = tau * (double)(c->N - 1) / (double)c->N + gam2;   // :1137-1138
     const bool device_loop = cgx_usable(c);
-    // one rank, every system opening without an operator application of its own (zero start, or a warm start whose products are
-    // known): the opening runs on the device too (cg_open_device) -- chosen by nothing rank-local
-    bool dev_open = device_loop && !multi && M > 0 && max_iter > 0;
+    // every system opening without an operator application of its own (zero start, or a warm start whose products are known): the
+    // opening runs on the device too (cg_open_device) -- chosen by nothing rank-local (an empty shard takes it with its peers)
+    bool dev_open = device_loop && max_iter > 0 && (multi || M > 0);
     for (int k = 0; k < nsys; k++) dev_open = dev_open && !(sys[k].mu0 && !sys[k].ata0);
     if (dev_open && cgx_alloc(c, max_iter)) return 1;
     for (int k = 0; k < nsys; k++) {
@@ -593,7 +621,7 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             if (s.az && s.amu0 != s.az)
                 gvk::copy(c->stream, s.az, s.amu0, c->npad);   // A mu0
             KCHK(c);
-            if (dev_open ? cg_open_device(c, s, k, tau, gam2, diag, max_iter) : cg_finish_init(c, s, diag, multi)) return 1;
+            if (!dev_open && cg_finish_init(c, s, diag, multi)) return 1;
         } else if (s.mu0) {
             gvk::copy(c->stream, s.mu, s.mu0, M);
             s.phase = 0;
@@ -603,10 +631,11 @@ static int cg_run(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam2, int 
             gvk::fill(c->stream, s.mu, M, 0.0);
             if (s.az) gvk::fill(c->stream, s.az, c->npad, 0.0);
             gvk::copy(c->stream, s.r, s.v, M);
-            if (dev_open ? cg_open_device(c, s, k, tau, gam2, diag, max_iter) : cg_finish_init(c, s, diag, multi)) return 1;
+            if (!dev_open && cg_finish_init(c, s, diag, multi)) return 1;
         }
         if (max_iter <= 0 && s.phase == 1) s.active = false;
     }
+    if (dev_open && cg_open_device(c, sys, nsys, tau, gam2, diag, max_iter, multi)) return 1;
     for (int k = 0; k < nsys && !dev_open; k++)
         if (cg_first_step_from_known_product(c, sys[k], tau, gam2, diag, max_iter, multi)) return 1;
     for (;;) {
