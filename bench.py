@@ -405,7 +405,8 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if (pm["N"], pm["Mt"], pm["n_gpus"], pm["kernel_mode"]) == (N, Mt, world, a.mode) and \
                     pm.get("kernel_sources_sha256") == ksha:
-                traffic, traffic_src = pm["ax"]["hbm_bytes"], "profiles/" + name
+                # (the counters of the kernel this run's roofline names: the tile layout's Ax kernel or the stripe sets')
+                traffic, traffic_src = pm["tile_ax" if layout == 2 else "ax"]["hbm_bytes"], "profiles/" + name
                 break
         except (OSError, KeyError, ValueError):
             continue

@@ -23,18 +23,20 @@ python3 scripts/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/$R > /dev/null
 rm -rf $O/stats $O/stats2 $O/pmc_fetch $O/pmc_write $O/tune_cache
 else
 if [ "$PART" = b ]; then
-python3 scripts/bench_rows.py > $O/${R}_rows.json 2>$O/rows.err
-GV_LAYOUT=2 python3 scripts/bench_rows.py > $O/${R}_rows_tile.json 2>$O/rows_tile.err
+python3 bench.py --rows-only > $O/${R}_rows.json 2>$O/rows.err
+python3 bench.py --rows-only --rows-layout 1 > $O/${R}_rows_two_stripe_sets.json 2>$O/rows_l1.err
+python3 scripts/bench_rows.py "p-values" > $O/${R}_pvals_row.json 2>$O/pvals_row.err
 python3 scripts/ingest_rate.py > $O/${R}_ingest.json 2>$O/ingest.err
 python3 scripts/hostptr_probe.py > $O/${R}_hostptr_probe.txt 2>&1
 fi
 run() {  # name N M iters fuse xxt last-streaming-launches
   rocprofv3 --kernel-trace --output-format csv -d $O/$1 -o t -- python3 scripts/trace_run.py $2 $3 $4 $5 $6 > $O/$1.out 2>$O/$1.err
   f=$(find $O/$1 -name "*kernel_trace.csv" | head -1)
-  python3 scripts/trace_gaps.py $f $7 > $O/${R}_$1_gaps.txt 2>&1
+  { python3 scripts/trace_gaps.py $f $7; echo; echo "== where the non-streaming time of an iteration goes (scripts/trace_phases.py)"; python3 scripts/trace_phases.py $f 4;
+    echo; echo "== one steady-state CG step (scripts/trace_step.py)"; python3 scripts/trace_step.py $f; echo; cat $O/$1.out; } > $O/${R}_$1_gaps.txt 2>&1
   rm -rf $O/$1
 }
-run cfg5 50000 200000 6 4 1 -27        # the last three iterations (9 passes each): steady state, set-up excluded
+run cfg5 50000 200000 6 4 1 -26        # the last three iterations (8-9 passes each): steady state, set-up excluded
 run shard125k 400000 125000 6 4 0 -10
 run cfg2 100000 500000 6 4 0 -18
 [ "$PART" = c ] && { ls -la $O; exit 0; }      # part c: the three kernel timelines only

@@ -13,8 +13,10 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 fuse = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 xxt = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 with capi.Shard(N, M) as sh:
-    sh.set_layout(False, int(os.environ.get("GV_LAYOUT", "1")))
-    sh.set_kernel_mode(1)
+    if os.environ.get("GV_LAYOUT"):
+        sh.set_layout(False, int(os.environ["GV_LAYOUT"]))      # 1 two stripe sets, 2 one tile layout
+    else:
+        sh.set_expected_passes(iters * 12)                      # what the drivers announce: the layout a run of this length gets
     sh.synth_bed(4242, 5000)
     sh.compute_markers_statistics()
     beta, y = hostapi.sim_phen(sh, 0.5, max(1, M // 100), 1)

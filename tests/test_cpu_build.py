@@ -154,8 +154,12 @@ def test_committed_bench_line_honours_the_contract():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) < 1.0
     pm = json.load(open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")))   # the counter passes of the same call
-    assert pm["ax"]["hbm_bytes"] >= r["alg_bytes_per_launch"]                # HBM traffic cannot undercut the algorithm
-    assert pm["ax"]["hbm_bytes"] <= 1.02 * r["alg_bytes_per_launch"] and pm["atx"]["hbm_bytes"] <= 1.02 * r["alg_bytes_per_launch"]
+    tile = "tile" in r["kernel"]                                              # (the default layout since round 5: one tile layout)
+    k_ax, k_atx = ("tile_ax", "tile_atx") if tile else ("ax", "atx")
+    assert pm[k_ax]["hbm_bytes"] >= r["alg_bytes_per_launch"]                # HBM traffic cannot undercut the algorithm
+    assert pm[k_ax]["hbm_bytes"] <= 1.02 * r["alg_bytes_per_launch"] and pm[k_atx]["hbm_bytes"] <= 1.02 * r["alg_bytes_per_launch"]
+    if r["traffic"] is not None:
+        assert r["traffic"] == pm[k_ax]["hbm_bytes"]
     assert "library defaults" in d["config"]["engine"] and d["hostptr_GBps"] > 0.9 * d["value"]
     step_bytes = 2 * r["alg_bytes_per_launch"]                               # one Ax + one ATx per step
     assert abs(d["value"] - step_bytes / (d["ms_per_step"] * 1e-3) / 1e9) < 1.0
@@ -170,7 +174,21 @@ def test_committed_bench_line_honours_the_contract():
     assert v["x_hat_rel_l2"] < 1e-9 and v["iters_per_s"] > v["reference_sequence"]["iters_per_s"]
     ld = d["vamp_ld"]                  # the LD leg carries its own parity fields since round 3
     assert ld["x_hat_rel_l2"] < 1e-9 and ld["counts_equal_reference_sequence"] is True and max(ld["cg_iters"]) >= 30
-    assert d["tile_layout"]["bit_identical_to_two_layouts"] is True
+    side = d.get("two_stripe_sets") or d["tile_layout"]      # the same step on the other resident layout, in the same process
+    assert side.get("bit_identical_to_main_leg", side.get("bit_identical_to_two_layouts")) is True
+    if rnd >= "r5":
+        # round 5: the mid-size rows ride in the driver-run line, the CPU baseline is a timing build with measured iterations
+        assert [w["row"] for w in d["rows"]] == ["config2", "shard_8gpu", "config4", "config5"]
+        for w in d["rows"]:
+            for lvl in ("fuse_4", "fuse_0"):
+                q = w[lvl]
+                assert abs(q["frac"] - q["pass_GBps"] / 8000.0) < 1e-3 and q["iters_per_s"] > 0 and q["passes"] > 0
+            assert w["fuse_4"]["iters_per_s"] > w["fuse_0"]["iters_per_s"] and w["x_hat_rel_l2_fuse4_vs_0"] < 1e-9
+        assert "-O3 -march=native" in c["flags"] or "parity build" in c["flags"]
+        m = c["vamp_iter_s_measured"]
+        assert "config1_N2000_M10000" in m and any(k.startswith("slice_") for k in m) and c["measured_over_model"] > 0.5
+        assert c["vamp_iter_s_extrapolated"] > 0
+        assert v["time_to_solution_s"] < 4.0
 
 
 def test_run_sharded_launcher_sets_the_rank_environment(tmp_path):
