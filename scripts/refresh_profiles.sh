@@ -12,12 +12,12 @@ python3 bench.py 2>$O/bench_n1.err | tail -1 > $O/${R}_bench_n1.json
 # kernel statistics of the timed region's kernels: the matvec legs only (--vamp-iterations 0) -- inside the VAMP legs a CG step
 # enqueued before the host knew that both solves had converged returns at once on the device, and those ~3 us launches
 # would pull the per-kernel averages down; the whole-run statistics are kept beside them (..._fullrun_kernel_stats.csv)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --vamp-iterations 0 2>$O/stats.err | tail -1 > $O/${R}_bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --vamp-iterations 0 --no-rows --no-side-leg 2>$O/stats.err | tail -1 > $O/${R}_bench_under_rocprof.json
 cp $O/stats/bench_kernel_stats.csv $O/${R}_bench_kernel_stats.csv 2>/dev/null || cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${R}_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>$O/stats2.err
 cp $O/stats2/bench_kernel_stats.csv $O/${R}_bench_fullrun_kernel_stats.csv 2>/dev/null || cp $(ls $O/stats2/*/*kernel_stats.csv | head -1) $O/${R}_bench_fullrun_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --vamp-iterations 0 > /dev/null 2>$O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --vamp-iterations 0 > /dev/null 2>$O/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --vamp-iterations 0 --no-rows > /dev/null 2>$O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --vamp-iterations 0 --no-rows > /dev/null 2>$O/pmc_write.err
 for d in pmc_fetch pmc_write; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && [ "$f" != "$O/$d/bench_counter_collection.csv" ] && cp $f $O/$d/bench_counter_collection.csv; done
 python3 scripts/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/$R > /dev/null
 rm -rf $O/stats $O/stats2 $O/pmc_fetch $O/pmc_write $O/tune_cache
