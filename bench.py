@@ -143,7 +143,7 @@ def kernel_sources_sha256():
     """identity of the streaming-kernel sources a PMC profile belongs to (scripts/pmc_summary.py stamps the same hash)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gv_mfma.hip", "gv_mfma.h"):
+    for f in ("gv_mfma.hip", "gv_mfma.h", "gv_pval_dev.h"):      # (gv_pval_dev.h is compiled into k_fin_pvals)
         with open(os.path.join(ROOT, "gvamp_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -17,7 +17,7 @@ def kernel_src_hash():
     scripts/pmc_summary.py compute the same)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gv_mfma.hip", "gv_mfma.h"):
+    for f in ("gv_mfma.hip", "gv_mfma.h", "gv_pval_dev.h"):      # (gv_pval_dev.h is compiled into k_fin_pvals)
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -1896,7 +1896,10 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
     };
 #define PV_TRY(expr) do { if ((rc = (expr)) != 0) { cleanup(); return rc; } } while (0)
 #define PV_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(c, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    double* pv_dev = c->cg_d->d;                // an M-space work vector: nothing else runs between here and the copy-out
+    // an M-space work vector of the CG: INVARIANT -- ax_device / ax_overlapped (run per chromosome between the marker passes of the LOCO
+    // loop below) never touch the CG work vectors cg_r / cg_z / cg_p / cg_d; gv_ax / gv_atx (which stage through cg_d) are host entry
+    // points and cannot run inside this call
+    double* pv_dev = c->cg_d->d;
     double *pa = c->w_n->d, *pb = c->w_n2->d;   // operands of the fused pass: p and p^2
     gvm::PvArgs pva{c->counts, nullptr, 0.0, nullptr, 0};
     if (!fused) {

@@ -18,7 +18,7 @@ def kernel_sources_sha256():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("gv_mfma.hip", "gv_mfma.h"):
+    for f in ("gv_mfma.hip", "gv_mfma.h", "gv_pval_dev.h"):      # (gv_pval_dev.h is compiled into k_fin_pvals)
         with open(os.path.join(root, "gvamp_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
