@@ -1770,27 +1770,45 @@ static int fill_prior(gv_ctx* c, gv_prior& pr, const double* probs, const double
     return 0;
 }
 
-int gv_denoise(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
-               gv_vec* x1_out, gv_vec* d_out, double* sums2) {
+static int denoise_impl(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+                        gv_vec* x1_out, gv_vec* d_out, double* sums2, bool global) {
     NEED(c, r1->space == GV_SPACE_M && x1_out->space == GV_SPACE_M, "gv_denoise: M-space vectors required");
     gv_prior pr;
     if (fill_prior(c, pr, probs, vars, L)) return 1;
-    arm_scalars(c);
+    const bool multi = global && is_multi(c);
+    if (!multi) arm_scalars(c);
     gvk::denoise(c->stream, r1->d, c->M, gam1, pr, x1_out->d, d_out ? d_out->d : nullptr, c->red_partial, c->red_out);
     KCHK(c);
-    return read_scalars(c, 2, sums2);
+    return read_scalars_global(c, 2, sums2, multi);       // (sharded: all-reduced on the device buffer, in stream, before the read-back)
+}
+int gv_denoise(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+               gv_vec* x1_out, gv_vec* d_out, double* sums2) {
+    return denoise_impl(c, r1, gam1, probs, vars, L, x1_out, d_out, sums2, false);
+}
+int gv_denoise_global(gv_ctx* c, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+                      gv_vec* x1_out, gv_vec* d_out, double* sums2) {
+    return denoise_impl(c, r1, gam1, probs, vars, L, x1_out, d_out, sums2, true);
 }
 
-int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, const double* omegas,
-                   const double* vars, int L, double* sums) {
+static int prior_estep_impl(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                            const double* vars, int L, double* sums, bool global) {
     NEED(c, r1->space == GV_SPACE_M, "gv_prior_estep: M-space vector required");
     NEED(c, L >= 2, "gv_prior_estep: L >= 2");
     gv_prior pr;
     if (fill_prior(c, pr, omegas, vars, L)) return 1;
-    arm_scalars(c);
+    const bool multi = global && is_multi(c);
+    if (!multi) arm_scalars(c);
     gvk::prior_estep(c->stream, r1->d, c->M, gam1, lambda, pr, c->red_partial, c->red_out);
     KCHK(c);
-    return read_scalars(c, 1 + 2 * (L - 1), sums);
+    return read_scalars_global(c, 1 + 2 * (L - 1), sums, multi);
+}
+int gv_prior_estep(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                   const double* vars, int L, double* sums) {
+    return prior_estep_impl(c, r1, gam1, lambda, omegas, vars, L, sums, false);
+}
+int gv_prior_estep_global(gv_ctx* c, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                          const double* vars, int L, double* sums) {
+    return prior_estep_impl(c, r1, gam1, lambda, omegas, vars, L, sums, true);
 }
 
 // ---- probit: z-side denoiser of vamp::infere_bin_class (vamp_probit.cpp:335-352) -------------------------------------

@@ -230,8 +230,8 @@ void vamp::updatePrior(int verbose_) {
         std::vector<double> probs_prev = probs, vars_prev = vars;
         if (L >= 2) {
             std::vector<double> sums(1 + 2 * (L - 1));
-            ck(gv_prior_estep(ctx, r1, gam1, lambda, omegas.data(), vars.data(), L, sums.data()), "gv_prior_estep");
-            ck(gv_allreduce_host(ctx, sums.data(), (int)sums.size()), "gv_allreduce_host");
+            // (:990, :1012-1013: the sums over the ranks, all-reduced on the device buffer before the one read-back)
+            ck(gv_prior_estep_global(ctx, r1, gam1, lambda, omegas.data(), vars.data(), L, sums.data()), "gv_prior_estep_global");
             const double sum_of_pin = sums[0];
             lambda = sum_of_pin / Mt;
             for (int j = 0; j < L - 1; j++) {
@@ -354,14 +354,19 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         for (; it_revar <= auto_var_max_iter; it_revar++) {               // vamp.cpp:289-338
             double sums[2];
             gv_vec* dout = use_freeze == 1 ? dvec : nullptr;
+            // (:313 + the l2_norm2 of :326 in one message: summed over the ranks on the device before the one read-back -- except
+            // with a freeze mask, where the first sum is replaced by a local one before the exchange)
+            auto denoise = use_freeze == 1 ? gv_denoise : gv_denoise_global;
             if (it == 1 && init_est == 1) {                               // :295-296: x1_hat = r1, g1d still evaluated
-                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), tM, dout, sums), "gv_denoise");
+                ck(denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), tM, dout, sums), "gv_denoise");
                 ck(gv_vec_copy(ctx, x1_hat, r1), "gv_vec_copy");
                 sums[1] = 0.0;
             } else
-                ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, dout, sums), "gv_denoise");
-            if (use_freeze == 1) ck(gv_vec_dot(ctx, dvec, unfrozen, 0, &sums[0]), "gv_vec_dot");   // :308: unfrozen markers only
-            ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");     // :313 (+ the l2_norm2 of :326, same message)
+                ck(denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, dout, sums), "gv_denoise");
+            if (use_freeze == 1) {
+                ck(gv_vec_dot(ctx, dvec, unfrozen, 0, &sums[0]), "gv_vec_dot");   // :308: unfrozen markers only
+                ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");
+            }
             alpha1 = sums[0] / Mt;
             eta1 = gam1 / alpha1;
             if (it <= 1) break;
@@ -807,8 +812,7 @@ std::vector<double> vamp::infere_bin_class(data* dataset) {
         int it_revar = 1;
         for (; it_revar <= 50; it_revar++) {                              // :117-160
             double sums[2];
-            ck(gv_denoise(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, nullptr, sums), "gv_denoise");
-            ck(gv_allreduce_host(ctx, sums, 2), "gv_allreduce_host");
+            ck(gv_denoise_global(ctx, r1, gam1, probs.data(), vars.data(), (int)probs.size(), x1_hat, nullptr, sums), "gv_denoise_global");
             alpha1 = sums[0] / Mt;
             eta1 = gam1 / alpha1;
             if (it <= 1) break;

@@ -219,6 +219,14 @@ int gv_denoise(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, 
                gv_vec* x1_out, gv_vec* d_out, double* sums2);
 /* one E-step of vamp::updatePrior (vamp.cpp:953-1013): sums[0] = sum_i pi_i, sums[1+2j] = sum_i beta_ij pi_i,
  * sums[2+2j] = sum_i beta_ij (m_ij^2 + v_j) pi_i for j = 0..L-2 (local sums; caller all-reduces 1+2(L-1)). */
+/* The same two with their sums taken over the ranks (the MPI_Allreduce of vamp.cpp:313 / :326 and of :990 / :1012-1013 folded in):
+ * the device buffer is all-reduced in stream before the one read-back, where gv_denoise + gv_allreduce_host make a second round trip
+ * (host -> device -> all-reduce -> host) per call -- about seven per VAMP iteration on a sharded job.  One rank: identical to the
+ * local forms. */
+int gv_denoise_global(gv_ctx* ctx, const gv_vec* r1, double gam1, const double* probs, const double* vars, int L,
+                      gv_vec* x1_out, gv_vec* d_out, double* sums2);
+int gv_prior_estep_global(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
+                          const double* vars, int L, double* sums);
 int gv_prior_estep(gv_ctx* ctx, const gv_vec* r1, double gam1, double lambda, const double* omegas,
                    const double* vars, int L, double* sums);
 /* ---- --model bin_class (vamp_probit.cpp): the z-side probit denoiser over the N individuals ------------------------
