@@ -20,7 +20,7 @@ EXPORTS = [
     "gv_upload_bed", "gv_upload_bed_file", "gv_synth_bed", "gv_synth_bed_ld", "gv_download_bed", "gv_set_mask", "gv_marker_stats", "gv_get_marker_stats",
     "gv_ax", "gv_atx", "gv_set_layout", "gv_get_layout", "gv_set_kernel_mode", "gv_get_kernel_mode", "gv_vec_alloc", "gv_vec_free", "gv_vec_len",
     "gv_vec_upload", "gv_vec_download", "gv_vec_fill", "gv_vec_copy", "gv_vec_axpby", "gv_vec_mul", "gv_vec_dot", "gv_vec_dots", "gv_vec_dots_ex",
-    "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_ax3_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
+    "gv_ax_dev", "gv_atx_dev", "gv_ax2_dev", "gv_atx2_dev", "gv_set_phen", "gv_lmmse_mult", "gv_cg_solve", "gv_cg_solve2", "gv_cg_solve2x",
     "gv_denoise", "gv_prior_estep", "gv_denoise_global", "gv_prior_estep_global",
     "gv_probit_denoise", "gv_probit_denoise_cov", "gv_people_stats", "gv_cg_solve_aat", "gv_cg_solve_aat2", "gv_cg_solve_aat2w", "gv_cg_solve2w", "gv_pvals_loo", "gv_pvals_loco", "gv_pvals_loco_pred", "gv_allreduce_host", "gv_comm_unique_id", "gv_comm_init", "gv_comm_init_local", "gv_comm_init_callback", "gv_comm_share", "gv_set_overlap", "gv_debug_force_multi", "gv_comm_rank", "gv_comm_size", "gv_bind_host_numa", "gv_set_timing",
     "gv_get_counters", "gv_reset_counters", "gv_get_decomp", "gv_set_decomp", "gv_tune_info", "gv_ingest_info", "gv_ingest_info2", "gv_set_expected_passes", "gv_copy_bandwidth", "gv_read_bandwidth",
@@ -137,7 +137,6 @@ def load():
     L.gv_atx_dev.argtypes = [vp, vp, vp]
     L.gv_ax2_dev.argtypes = [vp, vp, vp, vp, vp]
     L.gv_atx2_dev.argtypes = [vp, vp, vp, vp, vp]
-    L.gv_ax3_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gv_cg_solve2.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
                                C.POINTER(CgStats), dp, dp]
     L.gv_cg_solve2x.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, C.POINTER(CgStats),
@@ -396,9 +395,6 @@ class Shard:
 
     def ax2_dev(self, xa, xb, outa, outb):
         self._ck(self.L.gv_ax2_dev(self.h, xa.h, xb.h, outa.h, outb.h))
-
-    def ax3_dev(self, xa, xb, xc, outa, outb, outc):
-        self._ck(self.L.gv_ax3_dev(self.h, xa.h, xb.h, xc.h, outa.h, outb.h, outc.h))
 
     def atx2_dev(self, pa, pb, outa, outb):
         self._ck(self.L.gv_atx2_dev(self.h, pa.h, pb.h, outa.h, outb.h))

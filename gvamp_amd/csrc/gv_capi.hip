@@ -886,55 +886,6 @@ int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, doub
     }
     return 0;
 }
-// three M-vectors in ONE pass (tile layout, one rank or sharded): slots 0 / 1 as ax2_device (hook included), slot 2 a plain product.
-bool ax3_usable(const gv_ctx* c) {
-    return c->kernel_mode == 1 && c->have_stripes && gvm::ax3_available(c->plan) && !use_overlap(c);
-}
-int ax3_device(gv_ctx* c, const double* xa, const double* xb, const double* xc, double* outa, double* outb, double* outc,
-               const gvm::CgHook* cg) {
-    NEED(c, c->have_stats && c->mask2, "Ax: bed, mask and marker statistics must be set first");
-    NEED(c, ax3_usable(c), "ax3: needs kernel mode 1 on the tile layout, no overlapped exchange");
-    const double scale = 1.0 / sqrt((double)c->N);
-    const bool multi = is_multi(c);
-    if (c->M == 0) {      // an empty shard contributes zeros through the same collectives as its peers
-        gvk::fill(c->stream, outa, c->npad, 0.0);
-        gvk::fill(c->stream, outb, c->npad, 0.0);
-        gvk::fill(c->stream, outc, c->npad, 0.0);
-        KCHK(c);
-    } else {
-        if (!c->ks_tuned && autotune_ks(c)) return 1;
-        Timer t(c, &c->cnt.ms_ax);
-        gv_ctx::EvRec* er = ev_next(c, 0);
-        c->plan.ev0 = er ? er->a : nullptr;
-        c->plan.ev1 = er ? er->b : nullptr;
-        gvm::ax3(c->stream, c->plan, xa, xb, xc, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, outa, outb, outc, cg);
-        KCHK(c);
-        t.stop();
-    }
-    c->cnt.n_ax += 3;
-    c->cnt.n_ax_pass += 1;
-    if (multi) {
-        Timer t(c, &c->cnt.ms_allreduce);
-        gv_ctx::EvRec* er = ev_next(c, 2);
-        if (er) (void)hipEventRecord(er->a, c->stream);
-        if (outb == outa + c->npad) {      // w_n | w_n2 (one allocation): one message
-            if (comm_allreduce(c, outa, 2 * c->npad)) return 1;
-            gvk::scale_vec(c->stream, outa, 2 * c->npad, scale);
-        } else {
-            if (comm_allreduce(c, outa, c->npad)) return 1;
-            if (comm_allreduce(c, outb, c->npad)) return 1;
-            gvk::scale_vec(c->stream, outa, c->npad, scale);
-            gvk::scale_vec(c->stream, outb, c->npad, scale);
-        }
-        if (comm_allreduce(c, outc, c->npad)) return 1;
-        gvk::scale_vec(c->stream, outc, c->npad, scale);
-        if (er) (void)hipEventRecord(er->b, c->stream);
-        KCHK(c);
-        t.stop();
-        if (c->timing == 1) c->cnt.n_allreduce++;
-    }
-    return 0;
-}
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa,
                 const double* addxb, double tau, double gam2, const gvm::CgHook* cg) {
     if (c->M == 0) {   // empty shard: no local markers, no collective in ATx
@@ -984,7 +935,7 @@ void free_dataset(gv_ctx* c) {
         c->plan.stripes_m = c->plan.stripes_n = nullptr;
     }
     F(c->plan.stripes_m); F(c->plan.stripes_n); F(c->plan.tiles); F(c->plan.dig0); F(c->plan.dig1); F(c->plan.cv); F(c->plan.ev);
-    F(c->plan.cv2); F(c->plan.ev2); F(c->plan.cv3); F(c->plan.ev3); F(c->plan.dig2); F(c->plan.dig3);
+    F(c->plan.cv2); F(c->plan.ev2);
     F(c->plan.scal); F(c->plan.partial);
     F(c->cgx_state); F(c->cgx_go);
     if (c->cgx_rel_h) (void)hipHostFree(c->cgx_rel_h);
@@ -1396,8 +1347,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             pl.stripes_m = pl.stripes_n = nullptr;
         }
         for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
-                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.cv3, (void**)&pl.ev3, &pl.dig2, &pl.dig3, (void**)&pl.scal,
-                         (void**)&pl.partial})
+                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         if (plan_decomps(c)) return 1;
     }
@@ -1444,16 +1394,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
             if (!A(hipMalloc(&pl.ev, sizeof(double) * Mn), "hipMalloc(ev)")) return;
             if (!A(hipMalloc(&pl.cv2, sizeof(double) * Mn), "hipMalloc(cv2)")) return;
             if (!A(hipMalloc(&pl.ev2, sizeof(double) * Mn), "hipMalloc(ev2)")) return;
-            if (want_layout) {      // the third vector of a three-vector Ax pass (tile layout: gvm::ax3)
-                const size_t dsz = (size_t)(nkbmax > 0 ? nkbmax : 1) * 4096;
-                if (!A(hipMalloc(&pl.cv3, sizeof(double) * Mn), "hipMalloc(cv3)")) return;
-                if (!A(hipMalloc(&pl.ev3, sizeof(double) * Mn), "hipMalloc(ev3)")) return;
-                if (!A(hipMalloc(&pl.dig2, dsz), "hipMalloc(dig2)")) return;
-                if (!A(hipMalloc(&pl.dig3, dsz), "hipMalloc(dig3)")) return;
-                if (!A(hipMemset(pl.dig2, 0, dsz), "hipMemset(dig2)")) return;      // (columns 8..15: no fourth vector)
-                if (!A(hipMemset(pl.dig3, 0, dsz), "hipMemset(dig3)")) return;
-            }
-            if (!A(hipMalloc(&pl.scal, sizeof(double) * 12), "hipMalloc(scal)")) return;
+            if (!A(hipMalloc(&pl.scal, sizeof(double) * 8), "hipMalloc(scal)")) return;
             auto pieces = [](const std::vector<gvm::Decomp>& cand, int64_t nkb) {   // room for every candidate of autotune_ks
                 int k = 1;
                 for (const gvm::Decomp& d : cand) {
@@ -1510,8 +1451,7 @@ static int ingest(gv_ctx* c, const uint8_t* host_bed, bool synth, uint64_t seed,
         // pointers), and the streaming kernels must never meet a layout whose digit / partial-sum buffers are missing
         if (c->stripes_slab) { (void)hipFree(c->stripes_slab); c->stripes_slab = nullptr; pl.stripes_m = pl.stripes_n = nullptr; }
         for (void** q : {&pl.stripes_m, &pl.stripes_n, &pl.tiles, &pl.dig0, &pl.dig1, (void**)&pl.cv, (void**)&pl.ev,
-                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.cv3, (void**)&pl.ev3, &pl.dig2, &pl.dig3, (void**)&pl.scal,
-                         (void**)&pl.partial})
+                         (void**)&pl.cv2, (void**)&pl.ev2, (void**)&pl.scal, (void**)&pl.partial})
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         (void)hipGetLastError();
         if (!rc) rc = fail(c, "ingest: allocating the resident layout failed: %s", alloc_err.c_str());
@@ -1779,17 +1719,6 @@ int gv_ax2_dev(gv_ctx* c, const gv_vec* xa, const gv_vec* xb, gv_vec* outa, gv_v
                 outa != outb, "gv_ax2_dev: x M-space, out N-space, distinct outputs");
     if (ensure_work(c)) return 1;
     return ax2_device(c, xa->d, xb->d, outa->d, outb->d);
-}
-int gv_ax3_dev(gv_ctx* c, const gv_vec* xa, const gv_vec* xb, const gv_vec* xc, gv_vec* outa, gv_vec* outb, gv_vec* outc) {
-    NEED(c, xa->space == GV_SPACE_M && xb->space == GV_SPACE_M && xc->space == GV_SPACE_M && outa->space == GV_SPACE_N &&
-                outb->space == GV_SPACE_N && outc->space == GV_SPACE_N && outa != outb && outa != outc && outb != outc,
-         "gv_ax3_dev: x M-space, out N-space, distinct outputs");
-    if (ensure_work(c)) return 1;
-    if (!ax3_usable(c)) {      // two stripe sets, kernel mode 0, overlapped exchange: the same products in two passes
-        if (ax2_device(c, xa->d, xb->d, outa->d, outb->d)) return 1;
-        return ax_device(c, xc->d, outc->d);
-    }
-    return ax3_device(c, xa->d, xb->d, xc->d, outa->d, outb->d, outc->d, nullptr);
 }
 int gv_atx2_dev(gv_ctx* c, const gv_vec* pa, const gv_vec* pb, gv_vec* outa, gv_vec* outb) {
     NEED(c, pa->space == GV_SPACE_N && pb->space == GV_SPACE_N && outa->space == GV_SPACE_M && outb->space == GV_SPACE_M &&

@@ -245,9 +245,6 @@ int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg = n
 int atx_device(gv_ctx* c, const double* p, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0,
                const gvm::CgHook* cg = nullptr);
 int ax2_device(gv_ctx* c, const double* xa, const double* xb, double* outa, double* outb, const gvm::CgHook* cg = nullptr);
-bool ax3_usable(const gv_ctx* c);     // three vectors in one Ax pass: kernel mode 1 on the tile layout, no overlapped exchange
-int ax3_device(gv_ctx* c, const double* xa, const double* xb, const double* xc, double* outa, double* outb, double* outc,
-               const gvm::CgHook* cg = nullptr);
 int atx2_device(gv_ctx* c, const double* pa, const double* pb, double* outa, double* outb, const double* addxa = nullptr,
                 const double* addxb = nullptr, double tau = 1.0, double gam2 = 0.0, const gvm::CgHook* cg = nullptr);
 int lmmse_device(gv_ctx* c, const double* v, double tau, double gam2, double* out);

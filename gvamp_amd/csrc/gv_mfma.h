@@ -82,12 +82,7 @@ struct Plan {
     double* ev = nullptr;           // M doubles: e = (mave - 3) * c
     double* cv2 = nullptr;          // the same for the second vector of a two-vector Ax
     double* ev2 = nullptr;
-    // third vector of a three-vector Ax pass (tile layout: gvm::ax3): its operands and its own pair of digit buffers
-    double* cv3 = nullptr;
-    double* ev3 = nullptr;
-    void* dig2 = nullptr;
-    void* dig3 = nullptr;
-    double* scal = nullptr;         // 3 x 4 doubles: amax, sum, 2^(54-e), 2^(e-54) per vector of a pass (second set also: marker_sums2's p2)
+    double* scal = nullptr;         // 2 x 4 doubles: amax, sum, 2^(54-e), 2^(e-54) (second set: marker_sums2's p2)
     int32_t* partial = nullptr;     // per-(K-split, plane, row) digit sums
     size_t partial_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // when set: recorded around the matvec kernel launch (roofline timing)
@@ -127,9 +122,9 @@ void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, cons
 
 // the two stages of ax / ax2, for callers that cut the product into individual-range chunks (row groups [rg0, rg1) of pl.rows_n)
 void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
-             double* red_partial, const CgHook* cg = nullptr, const double* xc = nullptr);
+             double* red_partial, const CgHook* cg = nullptr);
 void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
-             double* outa, double* outb, const CgHook* cg = nullptr, double* outc = nullptr);
+             double* outa, double* outb, const CgHook* cg = nullptr);
 
 int atx_dot_blocks(const Plan& pl);   // number of block partials of the fused <d, p> (CgHook::dot_part)
 
@@ -142,14 +137,6 @@ void ax_people(hipStream_t s, const Plan& pl, int kind, const double* mave, cons
                int64_t npad, double* red_partial, double* out);
 void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb,
-         const CgHook* cg = nullptr);
-// THREE M-vectors in one pass (tile layout only: ax3_available): slots 0 / 1 as ax2 (CG hook included), slot 2 a plain product --
-// the z1 = A x1_hat of a VAMP iteration (vamp.cpp:429), which otherwise takes a pass of its own whenever the two solves of the
-// iteration leave no slot free (their Ax products + z1 are an odd number on two-slot passes).  Same integers per vector as ax / ax2:
-// bit-identical results.  The pass uses the two-vector Ax decomposition of the shard on pairs of row groups (k_mfma_tile MODE 5).
-bool ax3_available(const Plan& pl);
-void ax3(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* xc, const double* mave, const double* msig,
-         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, double* outc,
          const CgHook* cg = nullptr);
 
 }  // namespace gvm

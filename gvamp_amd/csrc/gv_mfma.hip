@@ -25,8 +25,6 @@
 #include <cstdlib>
 
 #include "gv_internal.h"
-#include <type_traits>
-
 #include "gv_mfma.h"
 #include "gv_pval_dev.h"
 
@@ -253,8 +251,8 @@ constexpr int PREP_STRIDE = 2 * RED_BLOCKS;   // doubles of block partials per v
 // block partials: [0] = max(|c|,|e|), [1] = sum mave*c
 // CG hook (device-resident CG): x is the search direction p of system st; when that system took a step and is still
 // running, p <- z + beta p (vamp.cpp:1209-1210) happens here, on the way into the operands, instead of in a launch of its own.
-struct PrepAx { const double* x[3]; double* cv[3]; double* ev[3]; const double* st[3]; double* pw[3]; const double* z[3];
-                const int* ride; const double* alt_x; const int* go; };      // (slot 2: the plain third vector of gvm::ax3)
+struct PrepAx { const double* x[2]; double* cv[2]; double* ev[2]; const double* st[2]; double* pw[2]; const double* z[2];
+                const int* ride; const double* alt_x; const int* go; };
 __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restrict__ mave, const double* __restrict__ msig,
                                                  int64_t M, double* __restrict__ partial) {
     __shared__ double shm[4], shs[4];
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     const double* st = a.st[v];
     // the rider takes the slot of the one system that has finished (uniform over the launch: nothing changes these flags
     // between the k_cgx_decide of the previous step and the one of this step)
-    if (v < 2 && a.ride && *a.ride == 1 && st && st[gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) x = a.alt_x;
+    if (a.ride && *a.ride == 1 && st && st[gvm::ST_ACTIVE] == 0.0 && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) x = a.alt_x;
     const bool upd = st && a.pw[v] && st[gvm::ST_STEPPED] != 0.0 && st[gvm::ST_ACTIVE] != 0.0;   // (a slot may name a state for the rider's sake only)
     const double beta = upd ? st[gvm::ST_BETA] : 0.0;
     const double* zz = a.z[v];
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(256) void k_prep_pv(const double* __restrict__ y, c
 // ncol = 8 (ATx: 2 KiB per K-block) or 16 (Ax: [c | e], 4 KiB per K-block); col0 = first column of this vector.
 // part[j] / nblocks: the block partials the prep launch left for the vector of slot j; scal[j]: where block 0 of a slot with
 // wr[j] != 0 stores the vector's four scalars (two slots may quantise two operands of ONE vector -- c and e -- with one scale)
-struct QuantArgs { const double* v[6]; double* scal[6]; const double* part[6]; uint32_t* out[6]; int col0[6]; int wr[6]; int nblocks; };
+struct QuantArgs { const double* v[4]; double* scal[4]; const double* part[4]; uint32_t* out[4]; int col0[4]; int wr[4]; int nblocks; };
 // the scale of this block's vector from the prep launch's block partials (every block for itself, same order: same bits)
 __device__ __forceinline__ double quant_scale(const QuantArgs& a) {
     __shared__ double shm[256], shs[256];
@@ -850,52 +848,6 @@ __device__ __forceinline__ void compute_ax_t(const ABufT& a, const u32x4* sb, in
     }
 }
 
-// ---- MODE 5 (Ax side): THREE (up to four) vectors per pass.  The MFMA B operand has 16 columns = two vectors x 8 digit columns, so a
-// third vector is a second pair of digit blocks (dig2 = [c_c | -], dig3 = [e_c | -]) multiplied with the SAME expanded operands into a
-// second set of accumulators: MFMAs, not bytes.  Outputs are rows x columns, so a wave that kept its 256 rows would need 128
-// accumulator registers (tried: 256 VGPRs and spills at two waves per SIMD); instead a wave takes HALF the tiles of a super-block --
-// the tiles (d, s2) of two of the four dwords d of every 16-byte piece, loaded as 8-byte half-pieces -- for both pairs: 8 + 8 tiles =
-// the 64 accumulator registers of the two-vector kernel.  A workgroup is then 2 row groups x 2 halves; the two half-waves of a row
-// group read complementary halves of the same 128-byte lines within one barrier interval (the second finds them in cache).
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-struct ABufH { u32x2 t[4]; };
-__device__ __forceinline__ void load_h(ABufH& a, const u32x4* __restrict__ sb, int lane, int h) {
-    const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int off = (r >> 2) * 64 + (4 * i + g) * 4 + (r & 3);
-        a.t[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sb + off) + h);
-    }
-}
-// one K-step (64 markers) of a half-wave: 8 tiles (dl, s2) <-> dword d = 2 h + dl, both B pairs
-__device__ __forceinline__ void compute_ax_h(const ABufH& a, const u32x4* sb, int lane, v4i (&acc)[8], v4i (&acc2)[8]) {
-    const u32x4 q0 = sb[lane], q1 = sb[64 + lane], q2 = sb[128 + lane], q3 = sb[192 + lane];
-    const v4i B0 = {(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w};
-    const v4i B1 = {(int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
-    const v4i B2 = {(int)q2.x, (int)q2.y, (int)q2.z, (int)q2.w};
-    const v4i B3 = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
-#pragma unroll
-    for (int dl = 0; dl < 2; dl++) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) {
-            const uint32_t w0 = dl ? a.t[0].y : a.t[0].x, w1 = dl ? a.t[1].y : a.t[1].x, w2 = dl ? a.t[2].y : a.t[2].x,
-                           w3 = dl ? a.t[3].y : a.t[3].x;
-            const uint32_t e0 = (w0 >> (2 * s2)) & 0x03030303u, e1 = (w1 >> (2 * s2)) & 0x03030303u,
-                           e2 = (w2 >> (2 * s2)) & 0x03030303u, e3 = (w3 >> (2 * s2)) & 0x03030303u;
-            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
-            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
-            acc[dl * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B0, acc[dl * 4 + s2], 0, 0, 0);
-            acc[dl * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B1, acc[dl * 4 + s2], 0, 0, 0);
-            acc2[dl * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B2, acc2[dl * 4 + s2], 0, 0, 0);
-            acc2[dl * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B3, acc2[dl * 4 + s2], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // The streaming kernel on the tile layout.  Same skeleton as k_mfma_matvec: a workgroup = 4 waves = 4 consecutive row
 // groups over the same K range (digits once per workgroup through a two-stage LDS ring, one bare s_barrier per step), three
 // super-block register buffers rotating by name, uniform / tapered K-split or balanced decomposition, progress-based wave
@@ -905,33 +857,25 @@ __device__ __forceinline__ void compute_ax_h(const ABufH& a, const u32x4* sb, in
 // DIR 0: (rg nkb + kb), DIR 1: (kb nrg + rg) -- the layout is stored marker-group-major.
 // partial layout as k_mfma_matvec: [(piece * P + plane) * rows_p + row] * 8 + digit; DIR 0: rows_p = 64 nrg, P = 2 (MODE 0)
 // or 4 (MODE 2); DIR 1: rows_p = 256 nrg, P = nv.
-// MODE 5 (DIR 1): the half-wave form above; quads become PAIRS of row groups (nq = ceil(nrg / 2)), everything else -- K-splits,
-// balanced and hybrid decompositions, the digit ring -- is the same arithmetic on that unit.
 template <int DIR, int MODE, bool SK, bool GO>
 __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ stripes, const u32x4* __restrict__ dig0,
                                                       const u32x4* __restrict__ dig1, int64_t nrg, int64_t nkb, int ksplit,
                                                       int64_t skL, int prio, KBounds kbnd, int32_t* __restrict__ partial, int nv,
-                                                      const int* __restrict__ go, int64_t rstride, uint32_t piv,
-                                                      const u32x4* __restrict__ dig2, const u32x4* __restrict__ dig3) {
-    constexpr bool H = (DIR == 1 && MODE == 5);
-    using AB = typename std::conditional<H, ABufH, ABufT>::type;
+                                                      const int* __restrict__ go, int64_t rstride, uint32_t piv) {
     // rstride (DIR 1): row groups per K-step in memory -- nrg, or more when this launch covers a sub-range of the row groups
     if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (DIR == 1) ? 64 : ((MODE == 0) ? 128 : 256);   // u32x4 per K-step of one digit buffer
-    constexpr int SS = (DIR == 1 && !H) ? 128 : 256;                   // u32x4 per LDS stage
+    constexpr int SS = (DIR == 1) ? 128 : 256;                         // u32x4 per LDS stage
     constexpr int ROWS = (DIR == 1) ? 256 : 64;                        // rows per row group
     __shared__ u32x4 sB[2][SS];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t nq = H ? (nrg + 1) >> 1 : (nrg + 3) >> 2;
+    const int64_t nq = (nrg + 3) >> 2;
     const int c = lane & 15, g = lane >> 4;
-    const int hw = (tid >> 6) & 1;      // MODE 5: which half of the tiles this wave takes
     // the digit copy: DIR 0: thread -> piece (MODE 0: pieces 0..127, threads 128..255 copy them again into the unused half);
-    // DIR 1: threads 0..63 -> dig0, 64..127 -> dig1, 128..255 repeat (no divergent branch in the loop body) -- MODE 5: -> dig2, dig3
+    // DIR 1: threads 0..63 -> dig0, 64..127 -> dig1, 128..255 repeat (no divergent branch in the loop body)
     const int dofs = (DIR == 1) ? (tid & 63) : ((MODE == 0) ? (tid & 127) : tid);
     const u32x4* digsel = (DIR == 1 && (tid & 64)) ? dig1 : dig0;
-    if constexpr (H)
-        if (tid & 128) digsel = (tid & 64) ? dig3 : dig2;
-    const int sofs = (DIR == 1 && !H) ? (tid & 127) : tid;
+    const int sofs = (DIR == 1) ? (tid & 127) : tid;
     uint32_t u, uend;
     const uint32_t nkb32 = (uint32_t)nkb, skL32 = (uint32_t)skL;
     if (SK) {
@@ -952,7 +896,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     const uint32_t p_quarter = (uend - u + 3) / 4;
     uint32_t p_thr = prio ? u + p_quarter : 0xffffffffu, p_lvl = 3;
     if (prio) __builtin_amdgcn_s_setprio(3);
-    AB a0, a1, a2;
+    ABufT a0, a1, a2;
     u32x4 r0;
     bool primed = false;
     uint32_t par = 0;
@@ -969,21 +913,20 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
                       : (int)(blockIdx.x / (uint32_t)nq);
     const uint32_t useg0 = u;
     u += seg;
-    int64_t rg = H ? q * 2 + (tid >> 7) : q * 4 + (tid >> 6);
+    int64_t rg = q * 4 + (tid >> 6);
     const bool live = rg < nrg;
     if (!live) rg = nrg - 1;
 
-    constexpr int NX = (DIR == 1) ? (H ? 8 : 16) : 4, NY = (DIR == 1) ? (H ? 8 : 1) : 4;   // (MODE 5: accY = the second pair's sums)
-    v4i accX[NX], accY[NY];
+    v4i accX[(DIR == 1) ? 16 : 4], accY[(DIR == 1) ? 1 : 4];
 #pragma unroll
-    for (int i = 0; i < NX; i++) accX[i] = (v4i){0, 0, 0, 0};
+    for (int i = 0; i < ((DIR == 1) ? 16 : 4); i++) accX[i] = (v4i){0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < NY; i++) accY[i] = (v4i){0, 0, 0, 0};
+    for (int i = 0; i < ((DIR == 1) ? 1 : 4); i++) accY[i] = (v4i){0, 0, 0, 0};
     const int64_t last = nsteps - 1;
     const u32x4* ap = stripes + ((DIR == 1) ? (kb0 * rstride + rg) * 256 : (rg * nkb + kb0) * 256);
     const u32x4* g0 = digsel + kb0 * KBS + dofs;
     const bool has_next = SK && u < uend && nkb32 >= 2;
-    int64_t rgn = H ? (q + 1) * 2 + (tid >> 7) : (q + 1) * 4 + (tid >> 6);
+    int64_t rgn = (q + 1) * 4 + (tid >> 6);
     if (rgn >= nrg) rgn = nrg - 1;
     const u32x4* apn = has_next ? stripes + ((DIR == 1) ? rgn * 256 : rgn * nkb * 256) : ap + last * kstride;
     const u32x4* g0n = has_next ? digsel + dofs : g0 + last * KBS;
@@ -991,15 +934,10 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
 #define GV_A_AT(I) ((I) <= last ? ap + (I) * kstride : apn + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * kstride)
 #define GV_D_AT(I) ((I) <= last ? g0 + (I) * KBS : g0n + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * KBS)
 
-#define GV_LOAD_T(BUF, PTR)                                                            \
-    {                                                                                  \
-        if constexpr (H) load_h(BUF, PTR, lane, hw);                                   \
-        else load_t<DIR>(BUF, PTR, lane);                                              \
-    }
     if (!primed) {
         r0 = g0[0];
-        GV_LOAD_T(a0, ap)
-        GV_LOAD_T(a1, GV_A_AT((int64_t)1))
+        load_t<DIR>(a0, ap, lane);
+        load_t<DIR>(a1, GV_A_AT((int64_t)1), lane);
         sB[par][sofs] = r0;
         wg_barrier_lds();
     }
@@ -1008,10 +946,8 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
         const int64_t sv = (S);                                                        \
         const int64_t n2 = sv + 2, n1 = sv + 1;                                        \
         r0 = *GV_D_AT(n1);                                                             \
-        GV_LOAD_T(NXT, GV_A_AT(n2))                                                    \
-        if constexpr (H)                                                               \
-            compute_ax_h(CUR, sB[(sv + par) & 1], lane, accX, accY);                   \
-        else if constexpr (DIR == 1)                                                   \
+        load_t<DIR>(NXT, GV_A_AT(n2), lane);                                           \
+        if constexpr (DIR == 1)                                                        \
             compute_ax_t<MODE == 4>(CUR, sB[(sv + par) & 1], lane, accX);              \
         else                                                                           \
             compute_atx_t<MODE>(CUR, sB[(sv + par) & 1], lane, accX, accY);            \
@@ -1040,7 +976,6 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
         GV_T_STEP(a2, a1, st + 2)
     }
 #undef GV_T_STEP
-#undef GV_LOAD_T
 #undef GV_A_AT
 #undef GV_D_AT
     par = (par + (uint32_t)nsteps) & 1u;
@@ -1048,20 +983,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     if (!live) continue;
     const int64_t rows_p = nrg * ROWS;
     const int cd = c & 7;
-    if constexpr (H) {
-        // tile (dl, s2) of this half-wave = tile t = 4 (2 hw + dl) + s2 of the row group; pair 0: vectors 0 / 1, pair 1: vectors 2 / 3
-        const int pv = c >> 3;
-#pragma unroll
-        for (int tl = 0; tl < 8; tl++) {
-            const int t = 8 * hw + tl;
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int64_t row = rg * 256 + 16 * (4 * g + reg) + t;
-                if (pv < nv) partial[(((int64_t)ks * nv + pv) * rows_p + row) * 8 + cd] = accX[tl][reg];
-                if (2 + pv < nv) partial[(((int64_t)ks * nv + 2 + pv) * rows_p + row) * 8 + cd] = accY[tl][reg];
-            }
-        }
-    } else if constexpr (DIR == 1) {
+    if constexpr (DIR == 1) {
         // tile (d, s2): D[row 4g + reg][col c] <-> individual 256 rg + 16 (4g + reg) + 4d + s2; vector c >> 3, digit c & 7
         const int pv = c >> 3;
         if (pv < nv) {
@@ -1404,8 +1326,8 @@ __global__ __launch_bounds__(256) void k_fin_atx_dot(const int32_t* __restrict__
 // dq_p / dq_part (gvm::CgHook::dq_p): slot v closes an application of tau A A^T + gam2 I to p (gv_cg_solve_aat2w, one rank): while
 // its system is running, out = tau * product + gam2 * p and the block partials of <out, p> -- what gvk::aat_step's k_aat_dq does in
 // a launch of its own, bit for bit (one entry per thread there too when the vector fits RED_BLOCKS blocks, which the caller checks)
-struct FinAx { double* out[3]; const int* ride; const double* st[3]; double* ride_out; const double* dq_p[3]; double* dq_part[3];
-               double tau, gam2; };      // (slot 2: the plain third vector of gvm::ax3 -- no state, no fused update)
+struct FinAx { double* out[2]; const int* ride; const double* st[2]; double* ride_out; const double* dq_p[2]; double* dq_part[2];
+               double tau, gam2; };
 __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p,
                                                 int64_t npad, const double* __restrict__ scal_base,
                                                 const uint32_t* __restrict__ mask2, double post, FinAx a, int ppk,
@@ -1417,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     const double* __restrict__ scal = scal_base + 4 * v;
     double* __restrict__ out = a.out[v];
     const bool sys_done = a.st[v] && a.st[v][gvm::ST_ACTIVE] == 0.0;
-    if (v < 2 && a.ride_out && a.ride && *a.ride == 1 && sys_done && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) out = a.ride_out;
+    if (a.ride_out && a.ride && *a.ride == 1 && sys_done && a.st[1 - v] && a.st[1 - v][gvm::ST_ACTIVE] != 0.0) out = a.ride_out;
     const bool dq = a.dq_p[v] && !sys_done;          // (uniform over the launch slice)
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double val = 0.0;
@@ -1459,7 +1381,7 @@ template <int DIR, int MODE>
 void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const void* dig1, int64_t nrg, int64_t nkb,
                  const gvm::Decomp& d, int nv, const int* go) {
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
-    const int64_t nq = (MODE == 5) ? (nrg + 1) / 2 : (nrg + 3) / 4;      // MODE 5: workgroup = a PAIR of row groups
+    const int64_t nq = (nrg + 3) / 4;
     const int64_t grid = gvm::grid_of(d, nq, nkb);
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
@@ -1467,7 +1389,7 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
 #define GV_LAUNCH_T(SKV, GOV)                                                                                              \
     hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,     \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride, \
-                       (uint32_t)gvm::piv_of(d, nq), (const u32x4*)pl.dig2, (const u32x4*)pl.dig3)
+                       (uint32_t)gvm::piv_of(d, nq))
     if (MODE == 4 || !go) {
         if (d.skL > 0) GV_LAUNCH_T(true, false); else GV_LAUNCH_T(false, false);
     } else if constexpr (MODE != 4) {
@@ -1661,13 +1583,8 @@ static void quant_ax(hipStream_t s, const Plan& pl, int nv, const double* red_pa
     q.nblocks = nb;
     q.part[0] = q.part[1] = red_partial;                      // slots 0, 1: c and e of vector a; 2, 3: of vector b
     q.part[2] = q.part[3] = red_partial + PREP_STRIDE;
-    q.part[4] = q.part[5] = red_partial + 2 * PREP_STRIDE;   // (the third vector of gvm::ax3)
-    q.wr[0] = q.wr[2] = q.wr[4] = 1;
-    if (nv == 3) {
-        q.v[4] = pl.cv3; q.scal[4] = pl.scal + 8; q.out[4] = (uint32_t*)pl.dig2; q.col0[4] = 0;
-        q.v[5] = pl.ev3; q.scal[5] = pl.scal + 8; q.out[5] = (uint32_t*)pl.dig3; q.col0[5] = 0;
-    }
-    if (pl.layout == 1 || nv >= 2) {
+    q.wr[0] = q.wr[2] = 1;
+    if (pl.layout == 1 || nv == 2) {
         q.v[0] = pl.cv;  q.scal[0] = pl.scal;     q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
         q.v[1] = pl.ev;  q.scal[1] = pl.scal;     q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;
         q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
@@ -1683,19 +1600,16 @@ static void quant_ax(hipStream_t s, const Plan& pl, int nv, const double* red_pa
     hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
 }
 static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64_t npad, const uint32_t* mask2, double post,
-                   double* outa, double* outb, const CgHook* cg = nullptr, int64_t n0 = 0, double* outc = nullptr) {
-    FinAx f{{outa, outb, outc}, nullptr, {nullptr, nullptr, nullptr}, nullptr, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, 0.0, 0.0};
+                   double* outa, double* outb, const CgHook* cg = nullptr, int64_t n0 = 0) {
+    FinAx f{{outa, outb}, nullptr, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, {nullptr, nullptr}, 0.0, 0.0};
     if (cg && cg->ride_out && nv == 2) { f.ride = cg->ride; f.st[0] = cg->state[0]; f.st[1] = cg->state[1]; f.ride_out = cg->ride_out + n0; }
     if (cg && n0 == 0)
-        for (int v = 0; v < nv && v < 2; v++)
+        for (int v = 0; v < nv; v++)
             if (cg->dq_p[v]) {     // (whole-vector launches only: the block partials are those of a launch over all of npad)
                 f.st[v] = cg->state[v]; f.dq_p[v] = cg->dq_p[v]; f.dq_part[v] = cg->dq_part[v]; f.tau = cg->dq_tau; f.gam2 = cg->dq_gam2;
             }
-    // (three vectors: the pass ran on PAIRS of row groups -- 512 rows per decomposition unit, ax_rows doubled the hybrid's whole units)
-    const int qshift = nv == 3 ? 9 : (pl.rows_n == 256 ? 10 : 8);
-    const int64_t nq = nv == 3 ? (pl.nrg_n + 1) / 2 : (pl.nrg_n + 3) / 4;
     hipLaunchKernelGGL(k_fin_ax, dim3(nblk(npad, 256), nv), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad,
-                       pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, qshift, piv_of(d, nq));
+                       pl.scal, mask2, post, f, nv, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8, piv_of(d, (pl.nrg_n + 3) / 4));
 }
 
 // ---- data::Ax in two stages: the operands of the whole vector (ax_prep), then the product for a range of row groups
@@ -1703,19 +1617,19 @@ static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64
 // can run behind the next chunk (GV_OVERLAP, gv_capi.hip).  A chunk is a smaller problem of the same shape: the layouts are
 // row-group-major on this side (tile layout: with the row stride of the whole shard), so it only takes pointer offsets.
 void ax_prep(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* mave, const double* msig,
-             double* red_partial, const CgHook* cg, const double* xc) {
-    const int nv = xc ? 3 : (xb ? 2 : 1), nb = prep_blocks(pl.M);
-    PrepAx pa{{xa, xb, xc}, {pl.cv, pl.cv2, pl.cv3}, {pl.ev, pl.ev2, pl.ev3}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
-              {nullptr, nullptr, nullptr}, nullptr, nullptr, cg ? cg->go : nullptr};
+             double* red_partial, const CgHook* cg) {
+    const int nv = xb ? 2 : 1, nb = prep_blocks(pl.M);
+    PrepAx pa{{xa, xb}, {pl.cv, pl.cv2}, {pl.ev, pl.ev2}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, nullptr, nullptr,
+              cg ? cg->go : nullptr};
     if (cg) {
-        for (int v = 0; v < nv && v < 2; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
+        for (int v = 0; v < nv; v++) { pa.st[v] = cg->state[v]; pa.pw[v] = cg->p[v]; pa.z[v] = cg->z[v]; }
         if (nv == 2) { pa.ride = cg->ride; pa.alt_x = cg->alt_x; }
     }
     hipLaunchKernelGGL(k_prep_ax, dim3(nb, nv), dim3(256), 0, s, pa, mave, msig, pl.M, red_partial);
     quant_ax(s, pl, nv, red_partial, nb);
 }
 void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, const uint32_t* mask2, int64_t npad, double post,
-             double* outa, double* outb, const CgHook* cg, double* outc) {
+             double* outa, double* outb, const CgHook* cg) {
     if (rg1 <= rg0) return;
     Plan q = pl;
     const int64_t n0 = rg0 * pl.rows_n;
@@ -1727,13 +1641,10 @@ void ax_rows(hipStream_t s, const Plan& pl, int nv, int64_t rg0, int64_t rg1, co
         q.rstride_n = pl.rstride_n > 0 ? pl.rstride_n : pl.nrg_n;
     } else
         q.stripes_n = (char*)pl.stripes_n + (size_t)rg0 * pl.nkb_n * 4096;
-    Decomp d = nv >= 2 ? pl.dn[1] : pl.dn[0];
-    if (nv == 3) {      // (tile layout only: ax3_available) the two-vector decomposition on pairs of row groups: a hybrid's whole units double
-        if (d.skL > 0) d.piv *= 2;
-        launch_tile<1, 5>(s, q, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, 3, cg ? cg->go : nullptr);
-    } else if (nv == 2) launch_stream<3>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
+    const Decomp& d = nv == 2 ? pl.dn[1] : pl.dn[0];
+    if (nv == 2) launch_stream<3>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
     else         launch_stream<1>(s, q, q.stripes_n, pl.dig0, pl.dig1, q.nrg_n, pl.nkb_n, d, cg ? cg->go : nullptr);
-    fin_ax(s, q, d, nv, nrows, mask2 + n0 / 16, post, outa + n0, outb ? outb + n0 : nullptr, cg, n0, outc ? outc + n0 : nullptr);
+    fin_ax(s, q, d, nv, nrows, mask2 + n0 / 16, post, outa + n0, outb ? outb + n0 : nullptr, cg, n0);
 }
 
 void ax(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
@@ -1760,14 +1671,6 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, const CgHook* cg) {
     ax_prep(s, pl, xa, xb, mave, msig, red_partial, cg);
     ax_rows(s, pl, 2, 0, pl.nrg_n, mask2, npad, post, outa, outb, cg);
-}
-
-bool ax3_available(const Plan& pl) { return pl.layout == 1 && pl.cv3 && pl.ev3 && pl.dig2 && pl.dig3; }
-void ax3(hipStream_t s, const Plan& pl, const double* xa, const double* xb, const double* xc, const double* mave, const double* msig,
-         const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, double* outc,
-         const CgHook* cg) {
-    ax_prep(s, pl, xa, xb, mave, msig, red_partial, cg, xc);
-    ax_rows(s, pl, 3, 0, pl.nrg_n, mask2, npad, post, outa, outb, cg, outc);
 }
 
 void tile_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* tiles, int64_t rg0, int64_t nkb) {

@@ -138,10 +138,6 @@ int gv_atx_dev(gv_ctx* ctx, const gv_vec* p, gv_vec* out); /* data::ATx on handl
  * outa = A^T pa, outb = A^T pb.  Results are bit-identical to the one-vector calls (exact integer accumulation). */
 int gv_ax2_dev(gv_ctx* ctx, const gv_vec* xa, const gv_vec* xb, gv_vec* outa, gv_vec* outb);
 int gv_atx2_dev(gv_ctx* ctx, const gv_vec* pa, const gv_vec* pb, gv_vec* outa, gv_vec* outb);
-/* THREE M-vectors per pass (kernel mode 1 on the tile layout; a two-vector pass and a single one otherwise): the MFMA B operand
- * holds two vectors' digits, a third vector is a second B pair fed from the same 2-bit -> byte expansion -- MFMAs, not bytes.  What
- * the solvers use to take z1 = A x1_hat (vamp.cpp:429) along in the first pass of an iteration's solves.  Bit-identical results. */
-int gv_ax3_dev(gv_ctx* ctx, const gv_vec* xa, const gv_vec* xb, const gv_vec* xc, gv_vec* outa, gv_vec* outb, gv_vec* outc);
 /* phenotype y (length N) -> N-space handle with NA / pad slots zeroed: data::filter_pheno (data.cpp:1065-1079) */
 int gv_set_phen(gv_ctx* ctx, gv_vec* y_out, const double* y_host);
 
