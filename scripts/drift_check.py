@@ -14,6 +14,8 @@ from gvamp_amd import capi, hostapi
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
 IT = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+XXT = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # 1: --use-XXT-denoiser 1 (level 4 also carries A r1 / A r2 by linearity)
+REANCHOR = int(sys.argv[5]) if len(sys.argv) > 5 else -1   # --reanchor-every (-1: the drivers' default, 10; 0: never)
 
 
 def rel(a, b):
@@ -23,7 +25,6 @@ def rel(a, b):
 out = []
 for ld in (0, 64):
     with capi.Shard(N, M) as sh:
-        sh.set_layout(False, 1)
         sh.set_kernel_mode(1)
         if ld:
             sh.synth_bed(77, 5000, ld_block=ld, ld_ppm=900000)
@@ -32,10 +33,11 @@ for ld in (0, 64):
         sh.compute_markers_statistics()
         beta, y = hostapi.sim_phen(sh, 0.5, max(1, M // 100), 1)
         kw = dict(iterations=IT, CG_max_iter=50, rho=0.5, seed=1, gam1=1e-8, gamw=2.0, true_signal=beta, history=True,
-                  stop_criteria_thr=1e-14)
+                  stop_criteria_thr=1e-14, use_XXT_denoiser=XXT, reanchor_every=REANCHOR)
         runs = {f: hostapi.infere_linear(sh, y, None, None, fuse_solves=f, **kw) for f in (0, 1, 2, 3, 4)}
     r0, r3 = runs[0], runs[4]
     row = {"genotypes": "LD blocks of %d" % ld if ld else "independent markers", "N": N, "M": M, "iterations": r3.niter,
+           "use_XXT_denoiser": XXT, "reanchor_every": REANCHOR,
            "cg_iters": [t["cg_iters"] for t in r0.trace],
            "passes": {f: sum(t["n_ax_pass"] + t["n_atx_pass"] for t in runs[f].trace) for f in runs},
            "seconds": {f: round(sum(t["seconds"] for t in runs[f].trace), 3) for f in runs}}
