@@ -455,7 +455,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
 // accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
-constexpr int GV_TUNE_VERSION = 6;   // bump when the candidate set or the line format changes shape
+constexpr int GV_TUNE_VERSION = 7;   // bump when the candidate set or the line format changes shape
 #ifndef GV_KERNEL_SRC_HASH
 #error "build with -DGV_KERNEL_SRC_HASH=\"...\" (gvamp_amd/build.py computes it from the streaming-kernel sources)"
 #endif
@@ -494,6 +494,7 @@ static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
         pieces = d.ks;
     }
     if (!(d.taper >= 0.f && d.taper < 1.f) || !(d.geo >= 0.f && d.geo < 1.f) || (d.geo > 0.f && d.skL > 0) || (d.prio != 0 && d.prio != 1)) return false;
+    if (d.occ != 0 && d.occ != 2 && d.occ != 3) return false;
     return (size_t)pieces * 4 * nrg * (side ? pl.rows_n : 64) * 8 * 4 <= pl.partial_bytes;
 }
 static bool tune_cache_load(gv_ctx* c) {
@@ -508,9 +509,10 @@ static bool tune_cache_load(gv_ctx* c) {
         if (strncmp(line, key.c_str(), key.size()) != 0) continue;
         gvm::Decomp d[4];
         long long sk[4], pv[4];
-        if (sscanf(line + key.size(), "%d %lld %lld %d %f %f %d %lld %lld %d %f %f %d %lld %lld %d %f %f %d %lld %lld %d %f %f", &d[0].ks, &sk[0],
-                   &pv[0], &d[0].prio, &d[0].taper, &d[0].geo, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[1].geo, &d[2].ks, &sk[2], &pv[2],
-                   &d[2].prio, &d[2].taper, &d[2].geo, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper, &d[3].geo) != 24)
+        if (sscanf(line + key.size(), "%d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d", &d[0].ks, &sk[0],
+                   &pv[0], &d[0].prio, &d[0].taper, &d[0].geo, &d[0].occ, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[1].geo, &d[1].occ,
+                   &d[2].ks, &sk[2], &pv[2], &d[2].prio, &d[2].taper, &d[2].geo, &d[2].occ, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper,
+                   &d[3].geo, &d[3].occ) != 28)
             continue;
         for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; d[k].piv = pv[k]; got[k] = d[k]; }
         have = true;
@@ -551,8 +553,8 @@ static void tune_cache_store(gv_ctx* c) {
     char buf[1024];
     int n = snprintf(buf, sizeof(buf), "%s", key.c_str());
     for (int k = 0; k < 4; k++)
-        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f %.2f ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
-                      d[k]->taper, d[k]->geo);
+        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f %.2f %d ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
+                      d[k]->taper, d[k]->geo, d[k]->occ);
     n += snprintf(buf + n, sizeof(buf) - n, "\n");
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
     if (fd < 0) return;
@@ -567,11 +569,15 @@ static void tune_cache_store(gv_ctx* c) {
 // the cache above.  Protocol, sized so that the cold cost stays a fraction of a second at 100 GB:
 //   stage A  the uniform splits short-listed by the cost model and the balanced grids, without / with their natural priority
 //            setting;  stage B  on the winner only: progress-based wave priority (uniform splits), then tapered segment
-//            lengths 0.5 / 0.9 (uniform splits with more than one segment).  At most 8 timed candidates per class.
+//            lengths 0.5 / 0.9 (uniform splits with more than one segment), then two workgroups per CU instead of three.
+//            At most 16 timed candidates per class.
 //   long kernels (>= 4 ms): ONE run of the product being tuned per candidate -- at that length neither the clocks nor what
-//            ran before move the result; short kernels: one untimed and a batch of timed Ax -> ATx PAIRS as the solvers
-//            issue them, the side not being tuned on its current pick -- a decomposition that won by 2 % back to back with
-//            itself was measured 10 % behind inside the alternating sequence (N = 50k x M = 200k, two-vector Ax).
+//            ran before move the result; short kernels: one untimed pair, then two batches of products of the side being tuned,
+//            each timed on its own inside the alternating Ax -> ATx sequence the solvers issue (the other side on its current
+//            pick, untimed) -- a decomposition that won by 2 % back to back with itself was measured 10 % behind inside the
+//            alternating sequence (N = 50k x M = 200k, two-vector Ax); the faster batch counts (one launch in 20-30 of some
+//            decompositions lands 15-35 % above the rest).  Operands are pseudo-random: a constant vector populates one digit
+//            plane and ranks the candidates differently.
 // Results do not depend on the decomposition (exact integer accumulation), so tuning never changes a bit of output.
 int autotune_ks(gv_ctx* c) {
     c->ks_tuned = true;
@@ -595,9 +601,14 @@ int autotune_ks(gv_ctx* c) {
         (void)hipGetLastError();
         return done(0);                      // no room for the scratch vectors: keep the model's pick
     }
-    gvk::fill(c->stream, xm, c->M, 1.0);
-    gvk::fill(c->stream, pn, c->npad, 1.0);
+    gvk::fill_hash(c->stream, xm, c->M, 1);           // representative operands: every digit plane populated
+    gvk::fill_hash(c->stream, pn, c->npad, 2);
     pl.ev0 = pl.ev1 = nullptr;
+    constexpr int TUNE_MAXREPS = 12;
+    hipEvent_t tev[2 * TUNE_MAXREPS] = {};
+    for (hipEvent_t& e : tev)
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    struct EvGuard { hipEvent_t* e; int n; ~EvGuard() { for (int i = 0; i < n; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{tev, 2 * TUNE_MAXREPS};
     // side: 0 = both products (the pair the solvers issue), 1 = Ax side only, 2 = ATx side only
     auto run = [&](int dual, int side) {
         if (side != 2) {
@@ -618,6 +629,27 @@ int autotune_ks(gv_ctx* c) {
         (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
         return ms / reps;
     };
+    // short kernels: the product being tuned alone, timed launch by launch INSIDE the alternating sequence the solvers issue (the
+    // other side runs, untimed, before every timed product): ms per product, prepare / quantise / finalise included.  Timing the
+    // pair diluted a 5 % difference on one side to 2.5 % of a number that moves by 1-2 % from batch to batch.
+    auto timed_side = [&](int dual, bool ax_side, int reps) -> double {
+        if (reps > TUNE_MAXREPS) reps = TUNE_MAXREPS;
+        for (int r = 0; r < reps; r++) {
+            if (!tev[2 * r] || !tev[2 * r + 1]) return -1.0;
+            run(dual, ax_side ? 2 : 1);
+            (void)hipEventRecord(tev[2 * r], c->stream);
+            run(dual, ax_side ? 1 : 2);
+            (void)hipEventRecord(tev[2 * r + 1], c->stream);
+        }
+        if (hipEventSynchronize(tev[2 * reps - 1]) != hipSuccess) return -1.0;
+        double tot = 0.0;
+        for (int r = 0; r < reps; r++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, tev[2 * r], tev[2 * r + 1]);
+            tot += ms;
+        }
+        return tot / reps;
+    };
     const bool verbose = getenv("GV_AUTOTUNE_VERBOSE") != nullptr;
     if (timed(0, 0, 1) < 0) { KCHK(c); return done(1); }        // clocks and caches up before anything is compared
     for (int step = 0; step < 4; step++) {
@@ -633,15 +665,23 @@ int autotune_ks(gv_ctx* c) {
         if (t_pair < 0) { KCHK(c); return done(1); }
         const bool solo = t_pair >= 8.0;                // both products >= ~4 ms
         const int side = solo ? (is_ax ? 1 : 2) : 0;
-        int reps = solo ? 1 : (int)(6.0 / (t_pair > 1e-3 ? t_pair : 1e-3)) + 1;
+        int reps = solo ? 1 : (int)(8.0 / (t_pair > 1e-3 ? t_pair : 1e-3)) + 1;     // (timed products per batch; the other side runs beside each)
         if (reps > 8) reps = 8;
         auto measure = [&](const gvm::Decomp& cd) -> double {
             d = cd;
             if (!solo && timed(dual, 0, 1) < 0) return -1.0;   // untimed: the first launch of a new grid shape
-            const double t = timed(dual, side, reps);
+            // short kernels: two batches, the faster one counts.  One launch in 20-30 of some decompositions lands 15-35 % above
+            // the rest (profiles/r6_launch_dist_shard.txt); a single batch of 2-8 pairs that catches one ranks its candidate by
+            // the accident -- round 5's table held a pick 2.5 % behind its own priority variant that way.
+            double t = solo ? timed(dual, side, reps) : timed_side(dual, is_ax, reps);
+            if (!solo && t >= 0) {
+                const double t2 = timed_side(dual, is_ax, reps);
+                if (t2 < 0) return -1.0;
+                if (t2 < t) t = t2;
+            }
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f : %.4f ms / %s\n", cls, cd.ks,
-                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, cd.geo, t, solo ? "product" : "pair");
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d : %.4f ms / %s\n", cls, cd.ks,
+                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, cd.geo, cd.occ, t, "product");
             return t;
         };
         gvm::Decomp best = cand[0];
@@ -675,10 +715,23 @@ int autotune_ks(gv_ctx* c) {
                 }
             }
         }
+        // ... then two workgroups per CU instead of three, on the winner and on the best geometric split (which is what gains from it
+        // where anything does: many short workgroups late in the launch)
+        {
+            const gvm::Decomp base = best;
+            gvm::Decomp t = base; t.occ = 2;
+            if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
+            for (const gvm::Decomp& cd : cand)
+                if (cd.geo > 0.f && cd.ks >= 6 && !(cd.ks == base.ks && cd.geo == base.geo)) {
+                    gvm::Decomp g = cd; g.occ = 2;
+                    if (consider(g)) { d = cand[0]; KCHK(c); return done(1); }
+                    break;
+                }
+        }
         d = best;
         if (verbose)
-            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f\n", cls, d.ks, (long long)d.skL,
-                    (long long)d.piv, d.prio, d.taper, d.geo);
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d\n", cls, d.ks, (long long)d.skL,
+                    (long long)d.piv, d.prio, d.taper, d.geo, d.occ);
     }
     KCHK(c);
     c->tune_source = 1;
@@ -943,6 +996,8 @@ void free_dataset(gv_ctx* c) {
     F(c->aat_slab);
     c->aat_slab_cap = 0;
     c->cgx_relcap = 0;
+    c->spec_hint_steps[0] = c->spec_hint_steps[1] = c->spec_hint_steps[2] = 0;
+    c->spec_hint_passes = 0;
     c->plan = gvm::Plan();
     c->have_raw = c->have_stripes = false;
     for (gv_vec** v : {&c->w_n, &c->cg_r, &c->cg_z, &c->cg_p, &c->cg_d, &c->mave_p, &c->msig_p, &c->numb_p, &c->w_n2,
@@ -1051,16 +1106,32 @@ static int plan_decomps(gv_ctx* c) {
             }
         }
         // geometric splits (big first): ks segments per quad, segment j = geo^j of segment 0, every one at least 8 K-blocks long.
-        // Ax side only: measured in-process against the tuner's picks (profiles/r4_decomp_ab_inprocess.txt) they gain 1-2.4 % on the
-        // Ax classes of 12.5 GB and 2.5 GB shards and lose 1-10 % on every ATx class (GV_TUNE_GEO=1 lists them there too)
-        if (prio_only != 0 && (geo_side || getenv("GV_TUNE_GEO")))
-            for (const auto& gk : {std::pair<int, float>{6, 0.6f}, {8, 0.65f}, {8, 0.8f}}) {
+        // Many short segments (6-8): Ax side only -- measured in-process against the tuner's picks
+        // (profiles/r4_decomp_ab_inprocess.txt) they gain 1-2.4 % on the Ax classes of 12.5 GB and 2.5 GB shards and lose 1-10 % on
+        // every ATx class (GV_TUNE_GEO=1 lists them there too).  Two to four segments: both sides.  A launch of nq < 768 whole-K
+        // workgroups (one round that does not fill the chip) streams with nq of the 768 slots for its
+        // whole length and ends on the spread of their speeds; a short second segment fills the idle slots for the first part of
+        // the launch instead: two-vector ATx of the 8-GPU shard (N = 400k x M = 125k, 489 quads, tile layout), per-launch
+        // distributions of 80 launches each in one process (profiles/r6_launch_dist_shard.txt): ks 1 p50 2.016 ms with 3 launches
+        // of 80 at 2.2-2.7 ms, ks 2 geo 0.5 p50 1.904 ms, max 1.941.  Just above a round (config 5's two-vector ATx, 782 quads): ks 4
+        // geo 0.5 0.424 ms with no launch above 0.431 against the hybrid's 0.441 with 4 of 30 at 0.49-0.56.
+        if (prio_only != 0) {
+            std::vector<std::pair<int, float>> gks;
+            const int64_t nq_ = (nrg + 3) / 4;
+            (void)nq_;
+            for (const auto& gk : {std::pair<int, float>{2, 0.5f}, {2, 0.35f}, {3, 0.5f}, {4, 0.5f}}) gks.push_back(gk);
+            if (geo_side || getenv("GV_TUNE_GEO")) for (const auto& gk : {std::pair<int, float>{6, 0.6f}, {8, 0.65f}, {8, 0.8f}}) gks.push_back(gk);
+            for (const auto& gk : gks) {
                 double tot = 0.0, wlast = 1.0;
                 for (int j = 0; j < gk.first; j++) { tot += wlast; if (j + 1 < gk.first) wlast *= gk.second; }
                 if ((double)nkb * wlast / tot < 8.0 || gk.first < min_ks_u) continue;
+                bool dup = false;
+                for (const gvm::Decomp& o : out) dup |= o.skL <= 0 && o.ks == gk.first && o.geo == gk.second;
+                if (dup) continue;
                 gvm::Decomp d; d.ks = gk.first; d.skL = 0; d.prio = 1; d.geo = gk.second;
                 out.push_back(d);
             }
+        }
         if (balanced_ok && prio_only != 0 && nkb >= 2) {
             // hybrid: whole rounds of the 768 resident workgroups go one quad per workgroup (in step over K), the quads that are
             // left over are cut into 768 balanced ranges -- for quad counts just above a multiple of 768 (gv_mfma.hip).  Listed
@@ -1183,14 +1254,28 @@ int gv_create(int device, gv_ctx** out) {
     if (const char* ov = getenv("GV_OVERLAP")) c->overlap_tiles = atoi(ov) > 64 ? 64 : (atoi(ov) < 0 ? 0 : atoi(ov));
     *out = c;
     // GVAMP_FORCE_MULTI=<transport>[:<delay_us>] -- gv_debug_force_multi for every context of the process (drivers, bench.py)
+    // The fault-injection bit (4) is reachable through the explicit call only, and a forced context says so once per process:
+    // a job that inherits the variable must not run the loop-back transport silently.
     if (const char* fm = getenv("GVAMP_FORCE_MULTI")) {
         const int tr = atoi(fm);
         const char* colon = strchr(fm, ':');
-        if (tr > 0 && gv_debug_force_multi(c, tr, colon ? atoi(colon + 1) : 0)) {
-            g_create_err = "gv_create: GVAMP_FORCE_MULTI: " + c->err;
+        if (tr < 0 || tr > 3) {
+            g_create_err = "gv_create: GVAMP_FORCE_MULTI=" + std::string(fm) + ": transport must be 0..3 (the fault-injection bit is gv_debug_force_multi only)";
             *out = nullptr;
             gv_destroy_locked(c);
             return 1;
+        }
+        if (tr > 0) {
+            if (gv_debug_force_multi(c, tr, colon ? atoi(colon + 1) : 0)) {
+                g_create_err = "gv_create: GVAMP_FORCE_MULTI: " + c->err;
+                *out = nullptr;
+                gv_destroy_locked(c);
+                return 1;
+            }
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "[gvamp] GVAMP_FORCE_MULTI=%s: one-rank contexts take the multi-rank branches over a loop-back exchange "
+                                "(test hook; results are unchanged, every pass pays the exchange)\n", fm);
         }
     }
     return 0;
@@ -1231,6 +1316,9 @@ const char* gv_last_error(const gv_ctx* c) { return c ? c->err.c_str() : g_creat
 
 int gv_synchronize(gv_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the overlapped exchange's side stream normally joins c->stream through ev_comm; a caller that synchronises wants the
+    // context quiescent whatever edges were (or, under fault injection, were not) recorded
+    if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
     return 0;
 }
 
@@ -2103,6 +2191,7 @@ int gv_debug_force_multi(gv_ctx* c, int transport, int delay_us) {
     NEED(c, transport == 0 || (c->nranks == 1 && !c->local && !c->cb), "gv_debug_force_multi: only a one-rank context can be forced");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));     // work a dropped join (bit 4) left behind
     if ((transport & 2) && !c->comm) {
         ncclUniqueId id;
         NCCLCHK(c, ncclGetUniqueId(&id));
@@ -2217,6 +2306,7 @@ int gv_get_decomp(gv_ctx* c, gv_decomp_info* out4) {
         out4[k].prio = d[k]->prio;
         out4[k].taper = d[k]->taper;
         out4[k].geo = d[k]->geo;
+        out4[k].wgs_per_cu = d[k]->occ == 2 ? 2 : 3;
         out4[k].tuned = c->ks_tuned ? 1 : 0;
     }
     return 0;
@@ -2227,6 +2317,8 @@ int gv_set_decomp(gv_ctx* c, int cls, const gv_decomp_info* in) {
     gvm::Decomp d;
     d.ks = in->ks; d.skL = in->balanced_cells; d.piv = in->balanced_cells > 0 ? in->whole_quads : 0; d.prio = in->prio;
     d.taper = in->taper; d.geo = in->geo;
+    NEED(c, in->wgs_per_cu == 0 || in->wgs_per_cu == 2 || in->wgs_per_cu == 3, "gv_set_decomp: wgs_per_cu is 0 (default), 2 or 3");
+    d.occ = in->wgs_per_cu == 2 ? 2 : 0;
     if (d.skL > 0) d.ks = 1;
     NEED(c, decomp_ok(c, d, cls >> 1), "gv_set_decomp: the decomposition is not admissible for this shard (range, or too many pieces for the partial-sum buffer)");
     (cls >> 1 ? c->plan.dn : c->plan.dm)[cls & 1] = d;

@@ -89,7 +89,11 @@ struct gv_ctx {
     // previous solve of the same kind needed.  From that count on the host reads the status of the step it has just enqueued before
     // it enqueues another -- consecutive VAMP iterations repeat their step counts, and a step enqueued after the last one costs a
     // dozen dropped launches (~60 us) where a wrong guess the other way costs one host round trip (~15 us).  0 = no hint yet.
-    int spec_hint_steps = 0, spec_hint_passes = 0;
+    // The hint holds for TWO counts (hint, hint + 1): a solve that outgrows it (cg_iters 2 -> 27 -> 31 on LD genotypes) goes back to
+    // reading one step behind, so the run-ahead is not lost for the rest of the solve.  One hint per solver kind (LMMSE alone,
+    // Onsager alone, the two in lock-step; the joint N-space solver): a --fuse-solves 0 run alternates kinds with different counts.
+    // Reset with the data set (free_dataset).
+    int spec_hint_steps[3] = {0, 0, 0}, spec_hint_passes = 0;
     void* stripes_slab = nullptr;  // owner of plan.stripes_n | plan.stripes_m when the two stripe sets share one allocation (ingest)
     double* aat_slab = nullptr;    // work vectors of the N-space solvers (gv_solvers.hip: aat_scratch), kept between calls
     size_t aat_slab_cap = 0;
@@ -165,6 +169,7 @@ void scale_vec(hipStream_t s, double* v, int64_t n, double a);
 void atx_f64(hipStream_t s, const uint8_t* bed, int64_t M, int64_t pitch, const double* p, const double* mave,
              const double* msig, double scale, double* out);
 void fill(hipStream_t s, double* v, int64_t n, double a);
+void fill_hash(hipStream_t s, double* v, int64_t n, uint64_t seed);
 void publish(hipStream_t s, const double* src, int K, double* mailbox, unsigned long long* flag, unsigned long long seq);
 // the finalisation of the NEXT reduction launched from this thread also publishes its scalars (no k_publish launch)
 void arm_publish(double* mailbox, unsigned long long* flag, unsigned long long seq, unsigned int* counter);
@@ -190,6 +195,7 @@ int cgx_ab(hipStream_t s, int nsys, double* const* st, double* const* mu, const 
 void finalize(hipStream_t s, const double* partial, int nb, int K, double* out);   // ordered sum of block partials
 void state_init(hipStream_t s, double* dst, const double* q);   // q: gvm::ST_SIZE doubles, by value in the launch
 void set_ints(hipStream_t s, int* dst, int a, int b);
+void go_from_states(hipStream_t s, int* dst, const double* st0, const double* st1, int b);
 // the state block of a system at its start from the block partials of its two opening reductions over n entries (one rank)
 void state_from_partials(hipStream_t s, double* dst, const double* q, const double* part_rz, int K_rz, int k_rz, const double* part_vv,
                          int64_t n, bool sqrt_norm);

@@ -802,6 +802,14 @@ __global__ void k_state_from_scalars(double* __restrict__ dst, StateInit a, cons
 __global__ void k_set_ints(int* __restrict__ dst, int a, int b) {
     if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
 }
+// go word from the state blocks the device-side opening left (cg_open_device): a system its first step already ended must not
+// be stepped again because the host, which has read no status yet, still believes it active
+__global__ void k_go_from_states(int* __restrict__ dst, const double* __restrict__ st0, const double* __restrict__ st1, int b) {
+    if (threadIdx.x == 0) {
+        dst[0] = (st0[gvm::ST_ACTIVE] != 0.0 || st1[gvm::ST_ACTIVE] != 0.0) ? 1 : 0;
+        dst[1] = b;
+    }
+}
 // the rider's product (see gvm::CgHook::ride) out of the slot that carried it
 __global__ void k_ride_copy(double* __restrict__ out, const double* __restrict__ w0, const double* __restrict__ w1,
                             const double* __restrict__ st0, const double* __restrict__ st1, const int* __restrict__ ride,
@@ -1168,6 +1176,21 @@ void fill(hipStream_t s, double* v, int64_t n, double a) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_fill, dim3(nblk(n, 256)), dim3(256), 0, s, v, n, a);
 }
+// pseudo-random entries in (-1, 1) with every mantissa bit in play (autotune_ks: a representative operand -- a constant vector has
+// one non-zero digit plane, the matrix pipe multiplies zeros and the ranking of the decompositions changes)
+__global__ void k_fill_hash(double* __restrict__ v, int64_t n, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    v[i] = (double)(int64_t)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;      // 53 bits -> [-1, 1)
+}
+void fill_hash(hipStream_t s, double* v, int64_t n, uint64_t seed) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill_hash, dim3(nblk(n, 256)), dim3(256), 0, s, v, n, seed);
+}
 
 void axpby(hipStream_t s, double* out, double a, const double* x, double b, const double* y, int64_t n) {
     if (n == 0) return;
@@ -1292,6 +1315,9 @@ void state_from_scalars(hipStream_t s, double* dst, const double* q, const doubl
     hipLaunchKernelGGL(k_state_from_scalars, dim3(1), dim3(64), 0, s, dst, a, rz, vv, sqrt_norm ? 1 : 0);
 }
 void set_ints(hipStream_t s, int* dst, int a, int b) { hipLaunchKernelGGL(k_set_ints, dim3(1), dim3(64), 0, s, dst, a, b); }
+void go_from_states(hipStream_t s, int* dst, const double* st0, const double* st1, int b) {
+    hipLaunchKernelGGL(k_go_from_states, dim3(1), dim3(64), 0, s, dst, st0, st1, b);
+}
 void ride_mark(hipStream_t s, const double* st0, const double* st1, int* ride) {
     hipLaunchKernelGGL(k_ride_mark, dim3(1), dim3(64), 0, s, st0, st1, ride);
 }

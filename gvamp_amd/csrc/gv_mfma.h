@@ -16,7 +16,13 @@ struct Decomp {
     float geo = 0.f;     // uniform split only, 0 < geo < 1: K-segment j is geo^j times segment 0 (big first, geometrically
                          // smaller behind): the dispatcher hands the short workgroups out as slots free up, which evens out
                          // the 10-20 % spread in the time equal shares take (takes precedence over taper)
+    int occ = 0;         // workgroups a CU may hold: 0 / 3 = what the registers allow (three), 2 = two (the launch reserves dynamic
+                         // LDS to that end).  Fewer resident workgroups keep fewer K ranges and rows open at a time: the two-vector
+                         // Ax of the 8-GPU shard on the tile layout streams 4 % faster with 512 than with 768 (profiles/r6_launch_dist_shard.txt),
+                         // the 100 GB headline kernels 2-6 % slower -- one more thing the tuner measures
 };
+// dynamic LDS bytes that cap a CU at d.occ workgroups of the streaming kernels (160 KiB per CU, <= 8 KiB static per workgroup)
+inline unsigned lds_pad_of(const Decomp& d) { return d.occ == 2 ? 60000u : 0u; }
 
 // workgroups of a launch over nq quads x nkb K-blocks, and pieces (int32 partial sums per row) the epilogues add up at most
 inline int64_t piv_of(const Decomp& d, int64_t nq) { return d.skL > 0 && d.piv > 0 ? (d.piv < nq ? d.piv : nq) : 0; }

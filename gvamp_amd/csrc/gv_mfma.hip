@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         unsigned xcc, hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        g_wgt[4 * blockIdx.x + 2] = xcc & 0xf;
+        g_wgt[4 * blockIdx.x + 2] = (xcc & 0xf) | ((unsigned long long)(uend - u) << 8);     // XCC id | cells of this workgroup
         g_wgt[4 * blockIdx.x + 3] = hw;
     }
 #endif
@@ -901,6 +901,16 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     bool primed = false;
     uint32_t par = 0;
     if (u >= uend) return;
+#ifdef GV_WGTIME
+    if (tid == 0 && blockIdx.x < 16384) {
+        g_wgt[4 * blockIdx.x] = wall_clock64();
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_wgt[4 * blockIdx.x + 2] = (xcc & 0xf) | ((unsigned long long)(uend - u) << 8);     // XCC id | cells of this workgroup
+        g_wgt[4 * blockIdx.x + 3] = hw;
+    }
+#endif
     // super-block (row group rg_, K-step kb_) in u32x4 units
     const int64_t kstride = (DIR == 1) ? rstride * 256 : 256;   // from one K-step to the next
 #pragma unroll 1
@@ -1022,6 +1032,9 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
     }
     }
   } while (SK && u < uend);
+#ifdef GV_WGTIME
+    if (tid == 0 && blockIdx.x < 16384) g_wgt[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ---- tile layout from a raw chunk: markers [m0, m0 + mc) of the shard, m0 % 64 == 0.  block = super-block (rg_local, kb);
@@ -1386,8 +1399,9 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
     const int64_t rstride = pl.rstride_n > 0 ? pl.rstride_n : nrg;
+    const unsigned lds_pad = gvm::lds_pad_of(d);     // Decomp::occ: two workgroups per CU instead of three
 #define GV_LAUNCH_T(SKV, GOV)                                                                                              \
-    hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)pl.tiles,     \
+    hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), lds_pad, s, (const u32x4*)pl.tiles,     \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride, \
                        (uint32_t)gvm::piv_of(d, nq))
     if (MODE == 4 || !go) {
@@ -1437,8 +1451,9 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     const int64_t grid = gvm::grid_of(d, nq, nkb);
     if (grid <= 0) return;          // an empty shard: nothing to stream (a zero-size grid is an invalid launch)
     const KBounds kb = make_bounds(d, nkb);
+    const unsigned lds_pad = gvm::lds_pad_of(d);
 #define GV_LAUNCH_MV(SKV, GOV)                                                                                             \
-    hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), 0, s, (const u32x4*)stripes,         \
+    hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), lds_pad, s, (const u32x4*)stripes,   \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go,        \
                        (uint32_t)gvm::piv_of(d, nq))
     if (MODE == 4 || !go) {            // (the people-statistics plane is never part of a CG step)

@@ -277,6 +277,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
     if (M > 0 && !c->ks_tuned && autotune_ks(c)) return 1;
     c->plan.ev0 = c->plan.ev1 = nullptr;       // no per-launch events inside the loop
     const bool riding = ride_x != nullptr && nsys == 2;
+    const int hint_kind = nsys == 2 ? 2 : (sys[0].denoiser == 0 ? 1 : 0);      // gv_ctx::spec_hint_steps
     // ---- initial states -> device
     int go0 = 0;
     for (int k = 0; k < 2; k++) {
@@ -292,7 +293,10 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         if (!state_on_device || k >= nsys)
             gvk::state_init(st, c->cgx_state + k * gvm::ST_SIZE, q);    // (by value in the launch: no pinned staging to protect)
     }
-    gvk::set_ints(st, c->cgx_go, go0, riding ? 1 : 0);                    // rider word: 1 pending, 2 rode
+    // rider word: 1 pending, 2 rode.  The go word: after a device-side opening the host has read no status and believes every system
+    // active; the opening's first step may have ended them all (max_iter == 1, rel < 1e-5 in step 1) -- the state blocks know
+    if (state_on_device) gvk::go_from_states(st, c->cgx_go, c->cgx_state, c->cgx_state + gvm::ST_SIZE, riding ? 1 : 0);
+    else gvk::set_ints(st, c->cgx_go, go0, riding ? 1 : 0);
     KCHK(c);
     double* dst[2] = {c->cgx_state, c->cgx_state + gvm::ST_SIZE};
     double* drel[2] = {c->cgx_rel, c->cgx_rel + c->cgx_relcap};
@@ -403,7 +407,8 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         }
         // ---- the status of the step BEFORE the one just enqueued -- or, once the solve has made as many steps as the previous one
         // needed (gv_ctx::spec_hint_steps), of the step just enqueued: it is probably the last
-        const bool likely_last = c->spec_hint_steps > 0 && (int)steps.size() >= c->spec_hint_steps;
+        const int hint = c->spec_hint_steps[hint_kind];
+        const bool likely_last = hint > 0 && ((int)steps.size() == hint || (int)steps.size() == hint + 1);
         if (likely_last || steps.size() >= 2) {
             CgxStatus s2[2];
             if (cgx_wait(c, likely_last ? steps.back() : steps[steps.size() - 2], s2)) return 1;
@@ -429,7 +434,7 @@ static int cg_run_device(gv_ctx* c, CgSys* sys, int nsys, double tau, double gam
         if (rode) c->cnt.n_ax += 1;
         c->cnt.n_ax_pass += executed;
         c->cnt.n_atx_pass += executed;
-        c->spec_hint_steps = executed;
+        c->spec_hint_steps[hint_kind] = executed;
         for (int k = 0; k < nsys; k++) {
             CgSys& s = sys[k];
             s.active = false;
@@ -1286,7 +1291,9 @@ int gv_cg_solve_aat2w(gv_ctx* c, gv_vec* v_a, const gv_vec* mu_start_a, const gv
                         kind = 1 - kind;
                         // the status of everything but the step just enqueued -- of that one too once the solve has made as many
                         // passes as the previous one needed (gv_ctx::spec_hint_passes): it is probably the last
-                        const bool likely_last = c->spec_hint_passes > 0 && (int)passes.size() >= c->spec_hint_passes;
+                        // -- for the next two passes only (one more A-step): a solve that outgrows the hint reads one step behind again
+                        const bool likely_last = c->spec_hint_passes > 0 && (int)passes.size() >= c->spec_hint_passes &&
+                                                 (int)passes.size() <= c->spec_hint_passes + 2;
                         while (applied + (likely_last ? 0 : 1) < steps.size()) {
                             CgxStatus s2[2];
                             MIX_TRY(cgx_wait(c, steps[applied].seq, s2));

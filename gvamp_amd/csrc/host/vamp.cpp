@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <random>
@@ -44,6 +45,7 @@ void vamp::common_init(const Options& opt) {
     store_iterates = opt.get_store_iterates();
     fuse_solves = opt.get_fuse_solves();
     reanchor_every = opt.get_reanchor_every();
+    if (const char* lm = getenv("GV_LINEARITY_MAX")) linearity_max = atof(lm);
     if (opt.get_redglob() != 0) {   // vamp.cpp:57,:594: CG on a sub-range of individuals (cross-validation variants)
         std::cout << "FATAL: --red " << opt.get_redglob() << " (sub-range CG / cross-validation) is not built" << std::endl;
         exit(EXIT_FAILURE);
@@ -518,7 +520,14 @@ std::vector<double> vamp::infere_linear(data* dataset) {
             // (z1 then found no free slot and took a pass of its own).  Every reanchor_every-th iteration takes the explicit products.
             for (gv_vec** v : {&ar1, &ar2})
                 if (inside && !*v) ck(gv_vec_alloc(ctx, GV_SPACE_N, v), "gv_vec_alloc");       // (zero-filled: A r1 of r1 = 0)
-            const bool by_linearity = inside && have_ar1 && !reanchor_now();
+            // The combination cancels: c1 - c2 = 1 while c1 + c2 = (eta1 + gam1) / (eta1 - gam1) = (1 + alpha1) / (1 - alpha1), and
+            // the rounding of z1 and A r1 is amplified by that factor in y - A r2; the A r1 carried from the previous iteration is
+            // (eta2 A x2_hat - gam2 A r2) / gam1 with gam1 = eta2 - gam2: (1 + alpha2) / (1 - alpha2).  Measured (scripts/drift_check.py,
+            // profiles/r6_fuse_level_drift.json): the first stays at 1.06-1.8; the second is ~1.5e4 after iteration 1 (gam1 starts at
+            // 1e-8: alpha2 ~ 1) -- that one product put 1.5e-13 into iteration 2 of round 5's LD run where the explicit form has 2e-15 --
+            // and 5-90 afterwards.  Beyond linearity_max (100: two digits) the iteration takes A r2 explicitly (pre_x = r2, z1
+            // riding), as on a re-anchoring iteration; have_ar1 carries the test for the combination that formed A r1.
+            const bool by_linearity = inside && have_ar1 && !reanchor_now() && std::fabs(r2_c1) + std::fabs(r2_c2) <= linearity_max;
             auto z1_outputs = [&]() {
                 double tz = now_s();
                 z1_outputs_a();
@@ -671,7 +680,10 @@ std::vector<double> vamp::infere_linear(data* dataset) {
         ck(gv_vec_axpby(ctx, r1, eta2 / gam1, x2_hat, -gam2 / gam1, r2), "gv_vec_axpby");   // :706-707
         if (reverse == 1 && fuse_solves >= 4 && ar1 && have_derived) {   // A r1 of the next iteration, from A x2_hat and A r2
             ck(gv_vec_axpby(ctx, ar1, eta2 / gam1, ax2_der, -gam2 / gam1, ar2), "gv_vec_axpby");
-            have_ar1 = true;
+            // ... which cancels the same way: coefficients (eta2, gam2) / gam1 with gam1 = eta2 - gam2, amplification
+            // (1 + alpha2) / (1 - alpha2).  Beyond linearity_max the carried A r1 is not used: the next iteration takes A r2
+            // explicitly, and the chain starts afresh from that product.
+            have_ar1 = (std::fabs(eta2) + std::fabs(gam2)) <= linearity_max * std::fabs(gam1);
         }
         st.gam1_next = gam1;
         if (verbose && rank == 0) std::cout << "gam2 re-est = " << gam2 << std::endl << "gam1 = " << gam1 << std::endl;

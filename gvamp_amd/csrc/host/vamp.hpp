@@ -43,6 +43,7 @@ private:
     int reanchor_every = 10;    // levels 3 / 4: iterations between explicit re-anchors of the chained products (0 = never)
     int cur_it = 0;             // iteration infere_linear is in (read by fused_solves)
     int probe_product_state = 0;   // vamp_iter_stats::probe_product of the solve just made
+    double linearity_max = 100.0; // XXT level 4: A r2 = c1 z1 - c2 A r1 only while both combinations amplify rounding by <= this (development override: GV_LINEARITY_MAX)
     bool reanchor_now() const { return reanchor_every > 0 && cur_it > 1 && cur_it % reanchor_every == 0; }
     double probit_var = 1;   // options.hpp:124
     // covariates of the probit model (--C > 0, --cov-file): effects fitted once in iteration 1 (vamp_probit.cpp:110-126)

@@ -39,6 +39,10 @@ for ld in (0, 64):
     row = {"genotypes": "LD blocks of %d" % ld if ld else "independent markers", "N": N, "M": M, "iterations": r3.niter,
            "use_XXT_denoiser": XXT, "reanchor_every": REANCHOR,
            "cg_iters": [t["cg_iters"] for t in r0.trace],
+           # r2 = c1 x1_hat - c2 r1 with c1 - c2 = 1: what XXT level 4's A r2 by linearity amplifies rounding by (vamp.cpp: linearity_max)
+           "c1_plus_c2": [float("%.3g" % ((2 * t["eta1"] - t["gam2"]) / t["gam2"])) for t in r0.trace],
+           # ... and r1 = (eta2 x2_hat - gam2 r2) / gam1 the same way for the A r1 carried into the next iteration
+           "r1_amplification": [float("%.3g" % ((t["eta2"] + t["gam2_reest"]) / t["gam1_next"])) for t in r0.trace],
            "passes": {f: sum(t["n_ax_pass"] + t["n_atx_pass"] for t in runs[f].trace) for f in runs},
            "seconds": {f: round(sum(t["seconds"] for t in runs[f].trace), 3) for f in runs}}
     for f in (1, 2, 3, 4):

@@ -1,7 +1,9 @@
-"""Development: in-process A/B of work decompositions of one streaming-kernel class on ONE resident shard (what differs between
-processes -- the placement of the resident allocations, +-3 % -- cancels).   python scripts/ab_decomp.py N M cls [layout] -- spec ...
-cls: atx | atx2 | ax | ax2;  spec: "ks=4,geo=0.5,prio=1" | "cells=995,prio=1" | "cells=218,quads=1536,prio=1" | "ks=6,geo=0.6,prio=1,occ=2" | "tuned" (the library's pick)
-Candidates are run round-robin, `--rounds` times `--reps` products each (HIP events around the whole product, prep / finalise included)."""
+"""Development: the DISTRIBUTION of single-launch durations of one streaming-kernel class under candidate work decompositions, on ONE
+resident shard (scripts/ab_decomp.py prints means over groups of launches; a class whose launches are bimodal -- some land 25-35 %
+above the rest -- hides in a mean).  HIP events around every streaming-kernel launch (gv_set_timing(2)), one counter read per launch.
+  python scripts/launch_dist.py N M cls [--layout L] [--launches K] spec ...
+cls: atx | atx2 | ax | ax2;  spec: "ks=4,geo=0.5,prio=1" | "cells=995,prio=1" | "cells=218,quads=1536,prio=1" | "ks=6,geo=0.6,prio=1,occ=2" | "tuned"
+"""
 import argparse
 import os
 import sys
@@ -14,24 +16,26 @@ ap = argparse.ArgumentParser()
 ap.add_argument("N", type=int)
 ap.add_argument("M", type=int)
 ap.add_argument("cls")
-ap.add_argument("--layout", type=int, default=1)
-ap.add_argument("--rounds", type=int, default=6)
-ap.add_argument("--reps", type=int, default=6)
+ap.add_argument("--layout", type=int, default=0, help="0: the library's choice (default), 1 two stripe sets, 2 tile")
+ap.add_argument("--launches", type=int, default=40)
+ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("specs", nargs="+")
 a = ap.parse_args()
 cls = ("atx", "atx2", "ax", "ax2").index(a.cls)
 with capi.Shard(a.N, a.M) as sh:
-    sh.set_layout(False, a.layout)
+    if a.layout:
+        sh.set_layout(False, a.layout)
+        sh.set_kernel_mode(1)
     sh.synth_bed(1234, 5000)
     sh.compute_markers_statistics()
     rng = np.random.default_rng(0)
     x, x2, p, p2, w, w2 = sh.vecM(rng.standard_normal(a.M)), sh.vecM(rng.standard_normal(a.M)), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM()
     sh.ax_dev(x, p); sh.ax_dev(x2, p2)          # (tunes / loads the picks)
     tuned = sh.decomp()[a.cls]
-    print("library pick:", tuned, sh.tune_info(), flush=True)
+    print("N=%d M=%d %s layout %d; library pick: %s %s" % (a.N, a.M, a.cls, sh.get_layout(), tuned, sh.tune_info()), flush=True)
     f = {0: lambda: sh.atx_dev(p, w), 2: lambda: sh.ax_dev(x, p), 1: lambda: sh.atx2_dev(p, p2, w, w2), 3: lambda: sh.ax2_dev(x, x2, p, p2)}[cls]
     other = {0: lambda: sh.ax_dev(x, p), 1: lambda: sh.ax2_dev(x, x2, p, p2), 2: lambda: sh.atx_dev(p, w), 3: lambda: sh.atx2_dev(p, p2, w, w2)}[cls]
-    key = "ms_atx" if cls < 2 else "ms_ax"
+    kms, kn = ("ms_atx_kernel", "n_atx_kernel") if cls < 2 else ("ms_ax_kernel", "n_ax_kernel")
 
     def apply(spec):
         if spec == "tuned":
@@ -45,19 +49,24 @@ with capi.Shard(a.N, a.M) as sh:
 
     f(); ref = w.download() if cls < 2 else p.download()
     res = {s: [] for s in a.specs}
-    sh.set_timing(1)
+    sh.set_timing(2)
     for r in range(a.rounds):
         for s in a.specs:
             apply(s)
-            other(); f()                                      # the pair the solvers issue; first launch of a new grid shape untimed
-            sh.counters(reset=True)
-            for _ in range(a.reps):
-                other(); f()
-            res[s].append(sh.counters()[key] / a.reps)
+            other(); f()                                      # first launch of a new grid shape untimed
+            for _ in range(a.launches):
+                other()
+                sh.counters(reset=True)
+                f()
+                c = sh.counters()
+                res[s].append(c[kms] / max(1, c[kn]))
             got = w.download() if cls < 2 else p.download()
             assert np.array_equal(got, ref), "decomposition changed the result: " + s
     mb = (a.N + 3) // 4
     nbytes = a.M * mb + 24 * a.M + 32 * mb
+    print("%-34s %7s %7s %7s %7s %7s  %s" % ("streaming kernel alone, ms", "p10", "p50", "p90", "max", "mean", "launches > 1.1 x p50;  GB/s at p50 / mean"))
     for s in a.specs:
         v = np.array(res[s])
-        print("%-40s ms mean %.4f min %.4f max %.4f   %.0f GB/s" % (s, v.mean(), v.min(), v.max(), nbytes / v.mean() / 1e6))
+        p50 = np.percentile(v, 50)
+        print("%-34s %7.4f %7.4f %7.4f %7.4f %7.4f  %d of %d;  %.0f / %.0f" % (s, np.percentile(v, 10), p50, np.percentile(v, 90), v.max(), v.mean(),
+                                                                          int((v > 1.1 * p50).sum()), len(v), nbytes / p50 / 1e6, nbytes / v.mean() / 1e6))

@@ -40,7 +40,8 @@ for N, M in SHAPES:
                 d = (capi.DecompInfo * 4)()
                 sh._ck(sh.L.gv_get_decomp(sh.h, d))
                 for k in range(4):
-                    votes[k][(d[k].ks, int(d[k].balanced_cells), int(d[k].whole_quads), d[k].prio, round(float(d[k].taper), 2), round(float(d[k].geo), 2))] += 1
+                    votes[k][(d[k].ks, int(d[k].balanced_cells), int(d[k].whole_quads), d[k].prio, round(float(d[k].taper), 2), round(float(d[k].geo), 2),
+                              2 if d[k].wgs_per_cu == 2 else 0)] += 1
         picks = [v.most_common(1)[0][0] for v in votes]
         print(N, M, layout, picks, [dict(v) for v in votes], flush=True)
         rows.append((N, M, layout - 1, picks))
@@ -49,7 +50,7 @@ src = open(os.path.join(build.CSRC, "gv_tune_builtin.h")).read()      # (the hea
 head = src[:src.index("static const char* const GV_BUILTIN_FOR_HASH")]
 body = 'static const char* const GV_BUILTIN_FOR_HASH = "%s";\nstatic const BuiltinPick GV_BUILTIN_PICKS[] = {\n' % h
 for N, M, lay, picks in rows:
-    ds = ", ".join("{%d, %d, %d, %d, %.2ff, %.2ff}" % (ks, skl, piv, prio, taper, geo) for ks, skl, piv, prio, taper, geo in picks)
+    ds = ", ".join("{%d, %d, %d, %d, %.2ff, %.2ff, %d}" % (ks, skl, piv, prio, taper, geo, occ) for ks, skl, piv, prio, taper, geo, occ in picks)
     body += "    {%d, %d, %d, {%s}},\n" % (N, M, lay, ds)
 body += "};\n}  // namespace gvi\n"
 open(a.out, "w").write(head + body)

@@ -108,6 +108,39 @@ def test_dual_solve_with_by_products_device_loop_equals_host_loop(N, M, warm, ri
         assert np.array_equal(d["mu_a"], d2["mu_a"]) and np.array_equal(d["ra"], d2["ra"]) and np.array_equal(d["rb"], d2["rb"])
 
 
+@pytest.mark.parametrize("max_iter", [1, 2])
+def test_opening_on_the_device_that_ends_a_system_before_the_loop(max_iter):
+    """The Onsager solve's first step from the known product A^T A u runs inside the device-side opening (cg_open_device); with
+    CG-max-iter 1 that step ENDS the system before the host has read any status.  The loop must take the go word from the state
+    blocks, not from what the host believes: same iterates, step and pass counts as the host-driven loop, which knows the outcome."""
+    N, M = 1600, 2100
+    sh, _ = _shard(N, M, seed=23)
+    with sh:
+        rng = np.random.default_rng(5)
+        va = sh.vecM(rng.standard_normal(M))
+        vb = sh.vecM(np.sign(rng.standard_normal(M)) / np.sqrt(M))
+        atau = sh.vecM(sh.ATx(sh.Ax(vb.download())))
+        tau, gam2 = 1.7, 0.8
+
+        def run():
+            mu_a, mu_b, ata = sh.vecM(), sh.vecM(), sh.vecM()
+            sh.counters(reset=True)
+            (sa, ra), (sb, rb) = sh.cg_solve2x(va, None, vb, tau, gam2, max_iter, mu_a, mu_b, ata_mu_b=ata, ata_v_b=atau, have_ata_v_b=True)
+            return dict(sa=(sa.iters, sa.converged, sa.n_relres), sb=(sb.iters, sb.converged, sb.n_relres), ra=ra, rb=rb,
+                        ons=sb.onsager, mu_a=mu_a.download(), mu_b=mu_b.download(), cnt=sh.counters())
+
+        d = run()
+        with host_loop():
+            h = run()
+        assert d["sa"] == h["sa"] and d["sb"] == h["sb"] and d["sb"][0] == max_iter
+        for k in ("n_ax", "n_atx", "n_ax_pass", "n_atx_pass"):
+            assert d["cnt"][k] == h["cnt"][k], (k, d["cnt"][k], h["cnt"][k])
+        assert d["cnt"]["n_ax_pass"] == max_iter            # system a's steps; system b's first one cost no pass
+        assert np.allclose(d["ra"], h["ra"], rtol=1e-10) and np.allclose(d["rb"], h["rb"], rtol=1e-10)
+        assert np.isclose(d["ons"], h["ons"], rtol=1e-12)
+        assert rel(d["mu_a"], h["mu_a"]) < 1e-12 and rel(d["mu_b"], h["mu_b"]) < 1e-12
+
+
 def test_full_vamp_run_device_loop_vs_host_loop_and_oracle(oracle):
     N, M = 2000, 6000
     bed = synth.synth_bed(N, M, seed=2024, miss_ppm=5000)

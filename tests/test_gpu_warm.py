@@ -140,7 +140,8 @@ def test_xxt_joint_solver_with_a_known_start_product():
 
 @pytest.mark.parametrize("level", [3, 4])
 @pytest.mark.parametrize("xxt", [0, 1])
-def test_vamp_runs_at_fuse_3_and_4_follow_fuse_2_and_the_oracle(oracle, xxt, level):
+def test_vamp_runs_at_fuse_3_and_4_follow_fuse_2_and_the_oracle(oracle, xxt, level, monkeypatch):
+    monkeypatch.setenv("GV_LINEARITY_MAX", "1e300")     # (product counts of the linearity path; its cancellation guard is tested below)
     N, M = 2000, 3000
     bed = synth.synth_bed(N, M, seed=44, miss_ppm=5000)
     beta, y = oracle.sim_phen(bed, N, M, 0.5, 150, 4)
@@ -314,7 +315,7 @@ def test_level_4_on_the_other_code_paths(oracle, monkeypatch, variant, xxt):
 
 
 @pytest.mark.parametrize("reanchor", [0, 2, 3])
-def test_xxt_level_4_takes_A_r2_by_linearity_and_reanchors(oracle, reanchor):
+def test_xxt_level_4_takes_A_r2_by_linearity_and_reanchors(oracle, reanchor, monkeypatch):
     """--use-XXT-denoiser 1 at level 4: r2 = (eta1 x1_hat - gam1 r1) / gam2 and r1 = (eta2 x2_hat - gam2 r2) / gam1 are linear in
     vectors whose products are at hand, so the joint solve's first pass carries z1 = A x1_hat and A r2 is never multiplied out
     (host/vamp.cpp: ar1 / ar2).  Follows level 0 and the oracle; one product fewer than the explicit form in every iteration but the
@@ -325,6 +326,9 @@ def test_xxt_level_4_takes_A_r2_by_linearity_and_reanchors(oracle, reanchor):
     probs, vars_ = [0.9, 0.07, 0.03], [0, 1e-3, 1e-2]
     kw = dict(iterations=7, CG_max_iter=40, rho=0.5, seed=9, true_signal=beta, history=True, use_XXT_denoiser=1)
     ref = oracle.infere(bed, N, M, y, probs, vars_, **{k: v for k, v in kw.items() if k != "history"})
+    # (the cancellation guard of host/vamp.cpp, linearity_max, lifted: this test is about the product counts of the linearity
+    # path on every iteration that is not re-anchored; the guard has its own test below)
+    monkeypatch.setenv("GV_LINEARITY_MAX", "1e300")
     with capi.Shard(N, M) as sh:
         sh.upload_bed(bed)
         sh.compute_markers_statistics()
@@ -349,3 +353,38 @@ def test_xxt_level_4_takes_A_r2_by_linearity_and_reanchors(oracle, reanchor):
         d = a["n_ax"] + a["n_atx"] - (b["n_ax"] + b["n_atx"])
         assert d in ({0, 2} if anchored else {1, 3}), (i, anchored, d)
         assert b["n_ax_pass"] + b["n_atx_pass"] <= a["n_ax_pass"] + a["n_atx_pass"], i
+
+
+def test_xxt_level_4_linearity_guard_falls_back_to_the_explicit_product(oracle, monkeypatch):
+    """A r2 = c1 z1 - c2 A r1 cancels (c1 - c2 = 1, c1 + c2 = (eta1 + gam1) / (eta1 - gam1)): iterations whose |c1| + |c2| exceeds
+    linearity_max (and the one after an iteration whose A r1 = (eta2 A x2_hat - gam2 A r2) / gam1 did) take A r2 explicitly, exactly as
+    a re-anchored iteration does.  With the guard at 0 every iteration falls back and
+    level 4 issues level 3's products plus the probe's known A^T A u; with the guard lifted it saves one more product per iteration;
+    the default sits between the two and every setting follows level 0."""
+    N, M = 1500, 2200
+    bed = synth.synth_bed(N, M, seed=61, miss_ppm=5000)
+    beta, y = oracle.sim_phen(bed, N, M, 0.5, 110, 9)
+    probs, vars_ = [0.9, 0.07, 0.03], [0, 1e-3, 1e-2]
+    kw = dict(iterations=7, CG_max_iter=40, rho=0.5, seed=9, true_signal=beta, history=False, use_XXT_denoiser=1, reanchor_every=0)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.compute_markers_statistics()
+        r0 = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=0, **kw)
+        runs = {}
+        for name, val in (("never", "0"), ("default", None), ("always", "1e300")):
+            if val is None:
+                monkeypatch.delenv("GV_LINEARITY_MAX", raising=False)
+            else:
+                monkeypatch.setenv("GV_LINEARITY_MAX", val)
+            runs[name] = hostapi.infere_linear(sh, y, probs, vars_, fuse_solves=4, **kw)
+    prods = {k: [t["n_ax"] + t["n_atx"] for t in r.trace] for k, r in runs.items()}
+    amp = [(2 * t["eta1"] - t["gam2"]) / t["gam2"] for t in r0.trace]          # c1 + c2 of each iteration
+    amp_r1 = [(t["eta2"] + t["gam2_reest"]) / t["gam1_next"] for t in r0.trace]   # of the A r1 the iteration leaves for the next
+    for i in range(1, 7):           # (iteration 1 has no A r1 yet: explicit whatever the guard says)
+        assert prods["never"][i] - prods["always"][i] == 1, (i, prods)
+        want = prods["always"][i] if max(amp[i], amp_r1[i - 1]) <= 100.0 else prods["never"][i]
+        assert prods["default"][i] == want, (i, amp[i], amp_r1[i - 1], prods)
+    for r in runs.values():
+        assert rel(r.x_est, r0.x_est) < 1e-9
+        for a, b in zip(r.trace, r0.trace):
+            assert (a["cg_iters"], a["onsager_iters"], a["L_after"]) == (b["cg_iters"], b["onsager_iters"], b["L_after"])
