@@ -1,5 +1,6 @@
 """Verdict over the JSON files scripts/first_8gpu.sh leaves: scaling table, the assertions each leg must hold, A/B deltas.
-Exit code 0 = all held (legs skipped for want of GPUs are reported, not failed)."""
+Exit code 0 = all held (legs skipped for want of GPUs are reported, not failed).  --strict-band: an 8-GPU line outside the band
+DESIGN.md section 6 predicted for it fails too."""
 import glob
 import json
 import os
@@ -14,7 +15,23 @@ def load(path):
         return {"failed": repr(e)}
 
 
-def main(out):
+# what the first 8-GPU line should read (DESIGN.md section 6: how each band was derived)
+PRED = {"ms_per_step": (3.85, 4.25), "value": (47000.0, 52000.0), "vamp_iters_per_s": (46.0, 58.0), "ms_allreduce_per_ax": (0.02, 0.15)}
+
+
+def prediction_verdict(d8, pred=None):
+    """[(key, lo, hi, measured, 'inside' | 'OUTSIDE' | 'n/a')] of an 8-GPU bench line against the predicted bands"""
+    pred = pred or PRED
+    got = {"ms_per_step": d8.get("ms_per_step"), "value": d8.get("value"), "vamp_iters_per_s": d8.get("vamp", {}).get("iters_per_s"),
+           "ms_allreduce_per_ax": d8.get("multi_gpu", {}).get("ms_allreduce_per_ax")}
+    out = []
+    for k, (lo, hi) in pred.items():
+        g = got[k]
+        out.append((k, lo, hi, g, "n/a" if g is None else ("inside" if lo <= g <= hi else "OUTSIDE")))
+    return out
+
+
+def main(out, strict_band=False):
     bad, rows = [], {}
     last = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_bench_n1.json")))
     ref = json.load(open(last[-1]))["value"] if last else None
@@ -59,18 +76,15 @@ def main(out):
         for n, d in sorted(rows.items()):
             s = d["value"] / rows[1]["value"]
             print("%-6d %12.0f %10.2f %12.3f %14s" % (n, d["value"], s, s / n, d.get("vamp", {}).get("iters_per_s")))
-    # DESIGN.md section 6 wrote down, before any multi-GPU run existed, what the 8-GPU line should read (round 5: the sharded branches
-    # measured on one GPU over an in-stream loop-back exchange, profiles/r5_forced_multi_gaps.txt, plus an assumed 40-100 us for a
-    # 3.2 MB all-reduce over xGMI).  Outside the band is not a failure of the run -- it is the first thing to explain.
-    PRED = {"ms_per_step": (4.05, 4.35), "value": (46000.0, 49500.0), "vamp_iters_per_s": (44.0, 56.0), "ms_allreduce_per_ax": (0.02, 0.15)}
+    # DESIGN.md section 6 wrote down, before any multi-GPU run existed, what the 8-GPU line should read (the sharded branches measured
+    # on one GPU over an in-stream loop-back exchange, profiles/r6_forced_multi_gaps.txt, plus an assumed 40-100 us for a 3.2 MB
+    # all-reduce over xGMI).  Outside the band is not a failure of the run -- it is the first thing to explain -- unless the caller
+    # asks for it to be one (strict_band: tests/test_gpu_multiproc.py on an 8-GPU node).
     if 8 in rows:
-        d = rows[8]
-        got = {"ms_per_step": d.get("ms_per_step"), "value": d.get("value"), "vamp_iters_per_s": d.get("vamp", {}).get("iters_per_s"),
-               "ms_allreduce_per_ax": d.get("multi_gpu", {}).get("ms_allreduce_per_ax")}
-        for k, (lo, hi) in PRED.items():
-            g = got[k]
-            where = "n/a" if g is None else ("inside" if lo <= g <= hi else "OUTSIDE")
+        for k, lo, hi, g, where in prediction_verdict(rows[8]):
             print("PREDICTION 8 GPUs %-22s predicted %.4g .. %.4g   measured %s   %s" % (k, lo, hi, g, where))
+            if strict_band and where != "inside":
+                bad.append("8-GPU %s = %s is %s the predicted band %.4g .. %.4g (DESIGN.md section 6)" % (k, g, "not reported: cannot be held against" if g is None else "outside", lo, hi))
     for fam, keys in (("overlap", (0, 2, 4)), ("cgdevice", (0, 1))):
         vals = {k: load(os.path.join(out, "%s_%d.json" % (fam, k))) for k in keys}
         if all("value" in v for v in vals.values()):
@@ -92,4 +106,5 @@ def main(out):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/first8"))
+    args = [x for x in sys.argv[1:] if x != "--strict-band"]
+    sys.exit(main(args[0] if args else "gpurun_out/first8", strict_band="--strict-band" in sys.argv[1:]))

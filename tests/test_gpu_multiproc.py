@@ -280,6 +280,60 @@ def test_bench_two_gpus(launcher):
     assert len(d["multi_gpu"]["per_rank"]) == 2 and d["vamp"]["x_hat_rel_l2"] < 1e-9
 
 
+# ---- first contact with an 8-GPU node (skipped below 8 GPUs): RCCL with nranks = 8 has never executed on this pool; the day
+# `pytest -m gpu` runs on such a node these hold the product to what the one-GPU work predicts ----------------------------------
+@pytest.mark.skipif(_gpu_count() < 8, reason="needs 8 GPUs (RCCL with nranks = 8)")
+def test_rccl_eight_ranks_gvamp_sim_vs_real_reference_np8(tmp_path):
+    """gvamp_sim as `mpirun -np 8` (utilities.cpp:259-291: 1 250 markers per rank; the Hutchinson probe of rank g is seeded with
+    its shard start, vamp.cpp:875): one process per GPU, every collective an ncclAllReduce over xGMI, against the files the real
+    reference wrote at np = 8 (tests/golden/survey_probe/sim_np8_*)."""
+    bed = _toy_bed(tmp_path)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_sharded.py"), "-n", "8", "--master-port", str(_free_port()), "--",
+           os.path.join(ROOT, "gvamp_amd", "gvamp_sim"), "--bed-file", bed, "--N", "2000", "--Mt", "10000",
+           "--out-dir", out, "--out-name", "toy", "--iterations", "3", "--num-mix-comp", "3", "--probs", "0.90,0.07,0.03",
+           "--vars", "0,0.001,0.01", "--CV", "500", "--h2", "0.5", "--rho", "0.5", "--CG-max-iter", "20", "--model",
+           "linear", "--seed", "7", "--store-pvals", "0", "--kernel-mode", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    for name in ("it_1_x2_hat", "it_3", "it_3_x2_hat"):
+        assert rel(np.fromfile(out + "toy_%s.bin" % name), np.fromfile(os.path.join(G, "sim_np8_%s.bin" % name))) < TIGHT, name
+
+
+@pytest.mark.skipif(_gpu_count() < 8, reason="needs 8 GPUs (RCCL with nranks = 8)")
+def test_first_contact_eight_gpus(tmp_path):
+    """bench.py --gpus 1 and --gpus 8 at the headline shape (N = 400k x Mt = 1M, 125 000 markers per GPU), as the driver launches
+    them, judged by scripts/first_8gpu_check.py with --strict-band: rccl_nranks == 8, the shards tile the marker range in rank order,
+    x_hat of the 8-rank VAMP run against its own reference sequence < 1e-9, the CG steps of the 1-GPU run, the 1-GPU value within
+    3 % of the committed line, and step time / aggregate rate / VAMP iterations per second / all-reduce time per Ax INSIDE the bands
+    DESIGN.md section 6 predicted from one-GPU measurements."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    flags = ["--no-cpu-baseline", "--no-rows", "--no-side-leg", "--ld-block", "0"]
+    legs = {}
+    for n in (1, 8):
+        if n == 1:
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + flags
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8"] + flags
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[:2000]
+        legs[n] = json.loads(lines[0])
+        (tmp_path / ("bench_n%d.json" % n)).write_text(lines[0])
+    for name in ("bench_n2", "bench_n4", "overlap_0", "overlap_2", "overlap_4", "cgdevice_0", "cgdevice_1"):
+        (tmp_path / (name + ".json")).write_text(json.dumps({"skipped": "not part of this test (scripts/first_8gpu.sh runs them)"}))
+    d = legs[8]
+    assert d["n_gpus"] == 8 and d["multi_gpu"]["rccl_nranks"] == 8 and len(d["multi_gpu"]["per_rank"]) == 8
+    assert d["vamp"]["x_hat_rel_l2"] < 1e-9
+    assert d["multi_gpu"]["ms_allreduce_per_ax"] > 0
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "first_8gpu_check.py"), str(tmp_path), "--strict-band"],
+                         capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """A harness that asks for 8 GPUs must never get a 1-GPU line: under a launcher with another WORLD_SIZE bench.py
     exits non-zero; started bare with more GPUs than the box has, its self-launch fails loudly too."""
