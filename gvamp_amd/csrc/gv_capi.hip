@@ -812,14 +812,17 @@ int ax_device(gv_ctx* c, const double* x, double* out, const gvm::CgHook* cg) {
     } else if (c->M == 0) {   // an empty shard (Mt < ranks) contributes zeros through the same collective as its peers
         gvk::fill(c->stream, out, c->npad, 0.0);
         KCHK(c);
-    } else if (c->kernel_mode == 1) {
-        NEED(c, c->have_stripes, "Ax: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+    } else if (c->kernel_mode != 0) {
+        NEED(c, c->have_stripes, "Ax: kernel modes 1 and 2 need a re-encoded layout (gv_set_layout before ingest)");
         if (!c->ks_tuned && autotune_ks(c)) return 1;
         Timer t(c, &c->cnt.ms_ax);
         gv_ctx::EvRec* er = ev_next(c, 0);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out, cg);
+        if (c->kernel_mode == 2)      // two-level fixed point: head and residual of x in the two slots of one pass (no CG hooks in this mode)
+            gvm::ax_wide(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out);
+        else
+            gvm::ax(c->stream, c->plan, x, c->mave, c->msig, c->mask2, c->npad, multi ? 1.0 : scale, c->red_partial, out, cg);
         KCHK(c);
         t.stop();
     } else {
@@ -861,14 +864,17 @@ int atx_device(gv_ctx* c, const double* p, double* out, const double* addx, doub
         c->cnt.n_atx_pass++;
         return 0;
     }
-    if (c->kernel_mode == 1 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
+    if (c->kernel_mode != 0 && c->have_stripes && !c->ks_tuned && autotune_ks(c)) return 1;
     Timer t(c, &c->cnt.ms_atx);
-    if (c->kernel_mode == 1 && c->M > 0) {
-        NEED(c, c->have_stripes, "ATx: kernel mode 1 needs the stripe layouts (gv_set_layout before ingest)");
+    if (c->kernel_mode != 0 && c->M > 0) {
+        NEED(c, c->have_stripes, "ATx: kernel modes 1 and 2 need a re-encoded layout (gv_set_layout before ingest)");
         gv_ctx::EvRec* er = ev_next(c, 1);
         c->plan.ev0 = er ? er->a : nullptr;
         c->plan.ev1 = er ? er->b : nullptr;
-        gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2, cg);
+        if (c->kernel_mode == 2)
+            gvm::atx_wide(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2);
+        else
+            gvm::atx(c->stream, c->plan, p, c->npad, c->mave, c->msig, 1.0 / sqrt((double)c->N), c->red_partial, out, addx, tau, gam2, cg);
     } else {
         NEED(c, c->have_raw, "ATx: kernel mode 0 needs the raw row layout (not the default: gv_set_layout(ctx, 1, ..) before ingest)");
         gv_ctx::EvRec* er = ev_next(c, 1);
@@ -1673,10 +1679,10 @@ int gv_set_mask(gv_ctx* c, const uint8_t* mask4, int64_t nonas) {
 
 int gv_marker_stats(gv_ctx* c, double alpha_scale) {
     NEED(c, (c->have_raw || c->have_stripes) && c->mask2, "gv_marker_stats: bed and mask must be set first");
-    if (c->have_stripes && c->plan.layout == 1 && (c->kernel_mode == 1 || !c->have_raw))
+    if (c->have_stripes && c->plan.layout == 1 && (c->kernel_mode != 0 || !c->have_raw))
         gvm::stats_from_tiles(c->stream, c->plan.tiles, c->mask2, c->M, c->plan.nrg_m, c->plan.nkb_m, c->pitch / 4,
                               (double)c->nonas, alpha_scale, c->mave, c->msig, c->counts);
-    else if (c->have_stripes && (c->kernel_mode == 1 || !c->have_raw))
+    else if (c->have_stripes && (c->kernel_mode != 0 || !c->have_raw))
         gvm::stats_from_stripes(c->stream, c->plan.stripes_m, c->mask2, c->M, c->plan.nkb_m, c->pitch / 4,
                                 (double)c->nonas, alpha_scale, c->mave, c->msig, c->counts);
     else
@@ -1698,7 +1704,7 @@ int gv_get_marker_stats(gv_ctx* c, double* mave, double* msig) {
 }
 
 int gv_set_kernel_mode(gv_ctx* c, int mode) {
-    NEED(c, mode == 0 || mode == 1, "gv_set_kernel_mode: mode must be 0 (fp64 VALU) or 1 (i8 MFMA fixed point)");
+    NEED(c, mode == 0 || mode == 1 || mode == 2, "gv_set_kernel_mode: mode must be 0 (fp64 VALU), 1 (i8 MFMA fixed point) or 2 (two-level fixed point)");
     c->kernel_mode = mode;
     return 0;
 }
@@ -1920,7 +1926,7 @@ int gv_probit_denoise(gv_ctx* c, const gv_vec* p1, const gv_vec* y, double tau1,
 // data::compute_people_statistics (data.cpp:558-716): three table passes of the fp64 Ax kernel over the raw rows.
 int gv_people_stats(gv_ctx* c, double* mave_people, double* msig_people, double* numb_people) {
     NEED(c, c->have_stats && c->mask2, "gv_people_stats: marker statistics must be computed first");
-    const bool from_stripes = c->have_stripes && (c->kernel_mode == 1 || !c->have_raw);
+    const bool from_stripes = c->have_stripes && (c->kernel_mode != 0 || !c->have_raw);
     NEED(c, c->have_raw || from_stripes, "gv_people_stats: no genotype layout resident");
     if (ensure_work(c)) return 1;
     for (gv_vec** v : {&c->mave_p, &c->msig_p, &c->numb_p})
@@ -1985,9 +1991,9 @@ static int pvals_impl(gv_ctx* c, const gv_vec* z1, const gv_vec* y, const gv_vec
     if (ensure_work(c) || ensure_w2(c)) return 1;
     const int64_t M = c->M;
     const double sqrtN = sqrt((double)c->N);
-    const bool fused = c->kernel_mode == 1;
+    const bool fused = c->kernel_mode != 0;      // (kernel mode 2: the p-value pass is mode 1's -- its sums run over exact planes already)
     if (fused && M > 0) {
-        NEED(c, c->have_stripes, "p-values: kernel mode 1 needs the stripe layouts");
+        NEED(c, c->have_stripes, "p-values: kernel modes 1 and 2 need a re-encoded layout");
         if (!c->ks_tuned && autotune_ks(c)) return 1;      // (a p-value call may be the first streaming pass of a context)
     }
     gv_vec *ymod = nullptr, *ych = nullptr, *sq = nullptr, *xch = nullptr;

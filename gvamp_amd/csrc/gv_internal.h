@@ -42,7 +42,7 @@ struct gv_ctx {
     // Defaults = the engine bench.py measures: i8 MFMA kernels on a re-encoded layout picked at ingest, no raw rows resident.
     // The fp64 VALU family (parity anchor) and the raw rows (gv_download_bed) are opt-in: gv_set_kernel_mode(ctx, 0),
     // gv_set_layout(ctx, 1, ..).
-    int kernel_mode = 1;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes
+    int kernel_mode = 1;            // 0 = fp64 VALU on raw rows, 1 = i8 MFMA on stripes, 2 = the same in two-level fixed point (gvm::ax_wide)
     bool want_raw = false, want_stripes = true;  // layouts built at ingest (gv_set_layout)
     bool want_auto = true;                       // gv_set_layout(.., 3): want_tile is decided at ingest from the free HBM
     bool want_tile = false;                      // the MFMA family's layout: false = two stripe sets, true = one tile layout

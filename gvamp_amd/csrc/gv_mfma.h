@@ -145,4 +145,11 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb,
          const CgHook* cg = nullptr);
 
+// kernel mode 2 (two-level fixed point, gv_mfma.hip MODE 5 / 6): the same products with ~108 bits below the vector's largest entry
+// and exact zeros at missing genotypes, one two-vector-shaped pass each
+void ax_wide(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
+             int64_t npad, double post, double* red_partial, double* out);
+void atx_wide(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig, double inv_sqrt_n,
+              double* red_partial, double* out, const double* addx = nullptr, double tau = 1.0, double gam2 = 0.0);
+
 }  // namespace gvm

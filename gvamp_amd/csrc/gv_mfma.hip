@@ -285,6 +285,22 @@ __global__ __launch_bounds__(256) void k_prep_ax(PrepAx a, const double* __restr
     }
     prep_block_partials(partial + v * PREP_STRIDE, mx, s, shm, shs);
 }
+// Ax operands of the two-level fixed point (kernel mode 2): c = msig * x for the a' plane, e = -(mave * c) for the present plane
+// (out = sum a' c + sum b e: a missing genotype contributes an exact 0 to both).  block partials: [0] = max(|c|, |e|), [1] = 0.
+__global__ __launch_bounds__(256) void k_prep_ax_wide(const double* __restrict__ x, const double* __restrict__ mave,
+                                                      const double* __restrict__ msig, int64_t M, double* __restrict__ cv,
+                                                      double* __restrict__ ev, double* __restrict__ partial) {
+    __shared__ double shm[4], shs[4];
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const double c = msig[i] * x[i];
+        const double e = -(mave[i] * c);
+        cv[i] = c;
+        ev[i] = e;
+        mx = (isfinite(c) && isfinite(e)) ? fmax(mx, fmax(fabs(c), fabs(e))) : __longlong_as_double(0x7ff0000000000000LL);
+    }
+    prep_block_partials(partial, mx, 0.0, shm, shs);
+}
 // Operands of the three per-individual sums behind data::compute_people_statistics (data.cpp:590-624), in the Ax form
 // out = sum_m plane_m c_m + sum_m miss_m e_m - K0 with sigma = msig, mu = mave:
 //   kind 0: count of non-missing markers          c = 0,             e = -1,            K0 = -M                  (r' plane)
@@ -389,6 +405,22 @@ __device__ __forceinline__ double quant_scale(const QuantArgs& a) {
     }
     return sc[2];
 }
+// WIDE (kernel mode 2, two-level fixed point): the vector's digits go to columns col0 .. col0 + 7 as always (the HEAD: q = rint(v *
+// 2^(54-e))), and the digits of the exact residual r = v - q 2^(e-54) -- |r| <= 2^(e-55), representable: v's own ulp is finer than
+// the grid wherever r != 0 -- quantised with the fixed second exponent e - 54 (q2 = rint(r 2^(108-e)), |q2| <= 2^53) go to columns
+// col0 + 8 .. col0 + 15.  v = q 2^(e-54) + q2 2^(e-108) to within 2^(e-109): ~108 bits below the vector's largest entry instead of
+// 54, in the two slots of ONE two-vector pass.  (A vector whose largest entry is below 2^-915 has no second level: its residual
+// multiplier would overflow.)
+__device__ __forceinline__ void digits_of(long long q, int t, uint32_t (&dig)[8]) {
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
+        long long dg = (long long)(signed char)(q & 0xFF);   // balanced digit in [-128, 127]
+        q = (q - dg) >> 8;
+        dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
+    }
+}
+__device__ __forceinline__ double wide_mult2(double mult) { return (mult > 0.0 && mult < 0x1p969) ? mult * 0x1p54 : 0.0; }
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_quant(QuantArgs a, int64_t n, int64_t nkb, int ncol) {
     const double* __restrict__ v = a.v[blockIdx.y];
     uint32_t* __restrict__ out = a.out[blockIdx.y];
@@ -398,23 +430,24 @@ __global__ __launch_bounds__(256) void k_quant(QuantArgs a, int64_t n, int64_t n
     if (tid >= nkb * 64) return;
     const int s = tid & 3, d = (tid >> 2) & 3, g = (tid >> 4) & 3;
     const int64_t kb = tid >> 6;
-    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double mult2 = WIDE ? wide_mult2(mult) : 0.0, sinv = (WIDE && mult > 0.0) ? 1.0 / mult : 0.0;   // (powers of two: exact)
+    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dig2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         int64_t k = kb * 256 + 64 * g + 16 * d + 4 * t + s;
         double val = (k < n) ? v[k] : 0.0;
-        long long q = (long long)rint(val * mult);
-#pragma unroll
-        for (int c = 0; c < 7; c++) {
-            long long dg = (long long)(signed char)(q & 0xFF);   // balanced digit in [-128, 127]
-            q = (q - dg) >> 8;
-            dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
-        }
+        const double qd = rint(val * mult);
+        digits_of((long long)qd, t, dig);
+        if (WIDE && mult2 > 0.0) digits_of((long long)rint(fma(-qd, sinv, val) * mult2), t, dig2);
     }
     // dword units: K-block = 64*ncol, dword-slot d = 16*ncol, lane-group g = 4*ncol, column = 4
     uint32_t* o = out + kb * (64 * ncol) + d * (16 * ncol) + g * (4 * ncol) + col0 * 4 + s;
 #pragma unroll
     for (int c = 0; c < 8; c++) o[c * 4] = dig[c];
+    if (WIDE) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) o[(8 + c) * 4] = dig2[c];
+    }
 }
 
 // ---- the matvec kernel ----------------------------------------------------------------------------------------------
@@ -445,15 +478,32 @@ __device__ __forceinline__ void load_a(ABuf& a, const u32x4* __restrict__ ap) {
     for (int i = 0; i < 4; i++) a.t[i] = __builtin_nontemporal_load(ap + i * 64);
 }
 
+// MODE 5 / 6 (kernel mode 2, "two-level fixed point"): the shapes of MODE 2 / 3 with the two vector slots holding the HEAD digits
+// and the RESIDUAL digits of ONE vector, and with planes that give a missing genotype an exact zero:
+//   first plane  a' = a if present else 0   (byte LUT r' -> {0,1,2,0}),   second plane  b = 1 if present else 0  (r' -> {1,1,1,0})
+// so that  Ax : out = sum_i a'_ni c_i - sum_i b_ni (mave_i c_i)      ATx : sum a p = a'.p,  sum b p = b.p
+// hold term by term as in the reference's table (data.cpp:951-988) -- no "3 c + (mave - 3) c - mave c" that cancels only to rounding.
+template <int MODE> struct MD {
+    static constexpr bool two_ax = MODE == 3 || MODE == 6;       // dig0 | dig1 hold one operand each of two slots
+    static constexpr bool two_atx = MODE == 2 || MODE == 5;
+    static constexpr int planes = MODE == 4 ? 1 : (MODE >= 5 ? 2 : 0);   // 0: r' / missing, 1: a^2 / missing, 2: a' / present
+};
+template <int PK> __device__ __forceinline__ uint32_t plane_x(uint32_t e) {
+    return PK == 0 ? e : __builtin_amdgcn_perm(PK == 1 ? 0x00040100u : 0x00020100u, PK == 1 ? 0x00040100u : 0x00020100u, e);
+}
+template <int PK> __device__ __forceinline__ uint32_t plane_y(uint32_t e) {
+    return __builtin_amdgcn_perm(PK == 2 ? 0x00010101u : 0x01000000u, PK == 2 ? 0x00010101u : 0x01000000u, e);
+}
+
 template <int MODE>
-struct BFrag { u32x4 d[4]; u32x4 e[MODE == 3 ? 4 : 1]; };
+struct BFrag { u32x4 d[4]; u32x4 e[MD<MODE>::two_ax ? 4 : 1]; };
 
 template <int MODE>
 __device__ __forceinline__ void lds_read_b(BFrag<MODE>& b, const u32x4* sb, int bofs) {
     constexpr int DS = (MODE == 0) ? 32 : 64;
 #pragma unroll
     for (int d = 0; d < 4; d++) b.d[d] = sb[d * DS + bofs];
-    if (MODE == 3) {
+    if (MD<MODE>::two_ax) {
 #pragma unroll
         for (int d = 0; d < 4; d++) b.e[d] = sb[256 + d * 64 + bofs];
     }
@@ -464,7 +514,7 @@ __device__ __forceinline__ void compute_step(const ABuf& a, const BFrag<MODE>& b
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const v4i BX = {(int)b.d[d].x, (int)b.d[d].y, (int)b.d[d].z, (int)b.d[d].w};
-        const u32x4 be = (MODE == 3) ? b.e[d] : b.d[d];
+        const u32x4 be = MD<MODE>::two_ax ? b.e[d] : b.d[d];
         const v4i BY = {(int)be.x, (int)be.y, (int)be.z, (int)be.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -472,17 +522,11 @@ __device__ __forceinline__ void compute_step(const ABuf& a, const BFrag<MODE>& b
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
             // MODE 4: the first plane is a^2 instead of r' (byte LUT r' -> {0,1,4,0}: code 3 = missing -> 0), for sums that are
-            // quadratic in the genotype (compute_people_statistics, data.cpp:608-624)
-            const v4i X = (MODE == 4) ? (v4i){(int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e0),
-                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e1),
-                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e2),
-                                              (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e3)}
-                                      : (v4i){(int)e0, (int)e1, (int)e2, (int)e3};
+            // quadratic in the genotype (compute_people_statistics, data.cpp:608-624); MODE 5 / 6: a' and the present plane
+            constexpr int PK = MD<MODE>::planes;
+            const v4i X = {(int)plane_x<PK>(e0), (int)plane_x<PK>(e1), (int)plane_x<PK>(e2), (int)plane_x<PK>(e3)};
             accX[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, BX, accX[i], 0, 0, 0);
-            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            const v4i Y = {(int)plane_y<PK>(e0), (int)plane_y<PK>(e1), (int)plane_y<PK>(e2), (int)plane_y<PK>(e3)};
             accY[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, BY, accY[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -538,7 +582,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     // device-resident CG: a step enqueued before the host knew that every system had converged is dropped here
     if (GO && __builtin_nontemporal_load(go) == 0) return;
     constexpr int KBS = (MODE == 0) ? 128 : 256;   // u32x4 per K-block of one digit buffer
-    constexpr int SS = (MODE == 3) ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
+    constexpr int SS = MD<MODE>::two_ax ? 512 : 256;    // u32x4 per LDS stage (MODE 0 uses the first 128; the rest is a dummy target)
     __shared__ u32x4 sB[2][SS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t nq = (nrg + 3) >> 2;
@@ -610,7 +654,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     const int64_t last = nsteps - 1;
     const u32x4* ap = stripes + (rg * nkb + kb0) * 256 + lane;
     const u32x4* g0 = dig0 + kb0 * KBS + dofs;
-    const u32x4* g1 = (MODE == 3) ? dig1 + kb0 * KBS + tid : nullptr;
+    const u32x4* g1 = MD<MODE>::two_ax ? dig1 + kb0 * KBS + tid : nullptr;
     // Look-ahead past the end of the segment.  Uniform K-split, or last segment of a balanced range: the last cell again
     // (clamped: no branches around loads).  Balanced range with another segment to come: that segment's first cells -- it
     // starts at K-block 0 of quad q + 1 -- so the stream of loads never drains at a quad boundary.
@@ -619,18 +663,18 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     if (rgn >= nrg) rgn = nrg - 1;
     const u32x4* apn = has_next ? stripes + rgn * nkb * 256 + lane : ap + last * 256;
     const u32x4* g0n = has_next ? dig0 + dofs : g0 + last * KBS;
-    const u32x4* g1n = (MODE == 3) ? (has_next ? dig1 + tid : g1 + last * KBS) : nullptr;
+    const u32x4* g1n = MD<MODE>::two_ax ? (has_next ? dig1 + tid : g1 + last * KBS) : nullptr;
     const int64_t nlastn = has_next ? (int64_t)(uend - u < nkb32 ? uend - u : nkb32) - 1 : 0;
 #define GV_A_AT(I) ((I) <= last ? ap + (I) * 256 : apn + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * 256)
 #define GV_D_AT(G, GN, I) ((I) <= last ? (G) + (I) * KBS : (GN) + ((I) - nsteps < nlastn ? (I) - nsteps : nlastn) * KBS)
 
     if (!primed) {
         r0 = g0[0];
-        if (MODE == 3) r1 = g1[0];
+        if (MD<MODE>::two_ax) r1 = g1[0];
         load_a(a0, ap);
         load_a(a1, GV_A_AT((int64_t)1));
         sB[par][tid] = r0;
-        if (MODE == 3) sB[par][256 + tid] = r1;
+        if (MD<MODE>::two_ax) sB[par][256 + tid] = r1;
         wg_barrier_lds();
     }
 
@@ -642,14 +686,14 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         const int64_t sv = (S);                                                        \
         const int64_t n2 = sv + 2, n1 = sv + 1;                                        \
         r0 = *GV_D_AT(g0, g0n, n1);                                                    \
-        if (MODE == 3) r1 = *GV_D_AT(g1, g1n, n1);                                     \
+        if (MD<MODE>::two_ax) r1 = *GV_D_AT(g1, g1n, n1);                              \
         load_a(NXT, GV_A_AT(n2));                                                      \
         BFrag<MODE> bf;                                                                \
         lds_read_b<MODE>(bf, sB[(sv + par) & 1], bofs);                                \
         compute_step<MODE>(CUR, bf, accX, accY);                                     \
         u32x4* sw = sB[(sv + 1 + par) & 1];                                            \
         sw[tid] = r0;                                                                  \
-        if (MODE == 3) sw[256 + tid] = r1;                                             \
+        if (MD<MODE>::two_ax) sw[256 + tid] = r1;                                      \
         wg_barrier_lds();                                                              \
     }
     // nsteps % 3 leading steps rotate the three supertile buffers by register moves; the main loop rotates them by NAME
@@ -684,7 +728,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
     if (!live) continue;
     const int64_t rows_p = nrg * 64;
     const int cd = c & 7;
-    if (MODE == 3) {
+    if (MD<MODE>::two_ax) {
         // vector v = c >> 3 needs r'.c_v + miss.e_v only: both sit in the same lanes, so one plane per vector is stored
         // (|sum| <= 512 K per digit, the bound gv_set_dims sizes the K-segments for)
         const int pv = c >> 3;
@@ -698,7 +742,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
         }
         continue;
     }
-    if (MODE == 2) {
+    if (MD<MODE>::two_atx) {
         const int pv = (c >> 3) * 2;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -790,9 +834,10 @@ __device__ __forceinline__ void load_t(ABufT& a, const u32x4* __restrict__ sb, i
 }
 
 // ATx side, one K-block (256 individuals): per load i a byte transpose, then 4 tiles x (r' plane, missing plane)
-template <int MODE>   // 0: one vector (8 digit columns, lanes c >= 8 alias), 2: two vectors
+template <int MODE>   // 0: one vector (8 digit columns, lanes c >= 8 alias), 2: two vectors, 5: head | residual of one vector (MD)
 __device__ __forceinline__ void compute_atx_t(const ABufT& a, const u32x4* sb, int lane, v4i (&accX)[4], v4i (&accY)[4]) {
     const int c = lane & 15, g = lane >> 4;
+    constexpr int PK = MD<MODE>::planes;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const u32x4 bq = (MODE == 0) ? sb[g * 32 + i * 8 + (c & 7)] : sb[g * 64 + i * 16 + c];
@@ -807,12 +852,9 @@ __device__ __forceinline__ void compute_atx_t(const ABufT& a, const u32x4* sb, i
             const uint32_t w = T[t];
             const uint32_t e0 = w & 0x03030303u, e1 = (w >> 2) & 0x03030303u, e2 = (w >> 4) & 0x03030303u,
                            e3 = (w >> 6) & 0x03030303u;
-            const v4i X = {(int)e0, (int)e1, (int)e2, (int)e3};
+            const v4i X = {(int)plane_x<PK>(e0), (int)plane_x<PK>(e1), (int)plane_x<PK>(e2), (int)plane_x<PK>(e3)};
             accX[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B, accX[t], 0, 0, 0);
-            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            const v4i Y = {(int)plane_y<PK>(e0), (int)plane_y<PK>(e1), (int)plane_y<PK>(e2), (int)plane_y<PK>(e3)};
             accY[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B, accY[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);      // (no barrier, or one MFMA per seven vector instructions through sched_group_barrier: 15.53-15.61 ms
@@ -821,7 +863,7 @@ __device__ __forceinline__ void compute_atx_t(const ABufT& a, const u32x4* sb, i
 }
 
 // Ax side, one K-step (64 markers): 16 tiles (d, s), operand register i from load i
-template <bool SQUARE>   // SQUARE: the first plane is a^2 (compute_people_statistics), else r'
+template <int PK>   // planes (MD::planes): 0 r' / missing, 1 a^2 / missing (compute_people_statistics), 2 a' / present (two-level fixed point)
 __device__ __forceinline__ void compute_ax_t(const ABufT& a, const u32x4* sb, int lane, v4i (&acc)[16]) {
     const u32x4 q0 = sb[lane], q1 = sb[64 + lane];
     const v4i B0 = {(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w};
@@ -832,15 +874,8 @@ __device__ __forceinline__ void compute_ax_t(const ABufT& a, const u32x4* sb, in
         for (int s2 = 0; s2 < 4; s2++) {
             const uint32_t e0 = (a.t[0][d] >> (2 * s2)) & 0x03030303u, e1 = (a.t[1][d] >> (2 * s2)) & 0x03030303u,
                            e2 = (a.t[2][d] >> (2 * s2)) & 0x03030303u, e3 = (a.t[3][d] >> (2 * s2)) & 0x03030303u;
-            const v4i X = SQUARE ? (v4i){(int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e0),
-                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e1),
-                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e2),
-                                         (int)__builtin_amdgcn_perm(0x00040100u, 0x00040100u, e3)}
-                                 : (v4i){(int)e0, (int)e1, (int)e2, (int)e3};
-            const v4i Y = {(int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e0),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e1),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e2),
-                           (int)__builtin_amdgcn_perm(0x01000000u, 0x01000000u, e3)};
+            const v4i X = {(int)plane_x<PK>(e0), (int)plane_x<PK>(e1), (int)plane_x<PK>(e2), (int)plane_x<PK>(e3)};
+            const v4i Y = {(int)plane_y<PK>(e0), (int)plane_y<PK>(e1), (int)plane_y<PK>(e2), (int)plane_y<PK>(e3)};
             acc[d * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, B0, acc[d * 4 + s2], 0, 0, 0);
             acc[d * 4 + s2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Y, B1, acc[d * 4 + s2], 0, 0, 0);
         }
@@ -958,7 +993,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
         r0 = *GV_D_AT(n1);                                                             \
         load_t<DIR>(NXT, GV_A_AT(n2), lane);                                           \
         if constexpr (DIR == 1)                                                        \
-            compute_ax_t<MODE == 4>(CUR, sB[(sv + par) & 1], lane, accX);              \
+            compute_ax_t<MD<MODE>::planes>(CUR, sB[(sv + par) & 1], lane, accX);       \
         else                                                                           \
             compute_atx_t<MODE>(CUR, sB[(sv + par) & 1], lane, accX, accY);            \
         sB[(sv + 1 + par) & 1][sofs] = r0;                                             \
@@ -1006,7 +1041,7 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
                 }
             }
         }
-    } else if constexpr (MODE == 2) {
+    } else if constexpr (MD<MODE>::two_atx) {
     // DIR 0: tile t, D[row 4g + reg][col c] <-> marker 64 rg + 4 (4g + reg) + t
         const int pv = (c >> 3) * 2;
 #pragma unroll
@@ -1152,6 +1187,7 @@ __global__ __launch_bounds__(256) void k_stats_tile(const uint4* __restrict__ ti
 // digits of an M-vector in the B-operand order of the tile layout's Ax side: K-step = 64 markers; entry
 // k = 64 kstep + 16 i + 4 gam + t is byte t of dword i of the 16-byte element (kstep, gam, column): dword index
 // kstep * 256 + (gam * 16 + col0 + c) * 4 + i.  Thread = (kstep, i, gam): four consecutive entries.
+template <bool WIDE>   // WIDE: head digits in columns col0 .., residual digits in col0 + 8 .. (k_quant)
 __global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t nsteps) {
     const double* __restrict__ v = a.v[blockIdx.y];
     uint32_t* __restrict__ out = a.out[blockIdx.y];
@@ -1161,22 +1197,23 @@ __global__ __launch_bounds__(256) void k_quant_t(QuantArgs a, int64_t n, int64_t
     if (tid >= nsteps * 16) return;
     const int gam = tid & 3, i = (tid >> 2) & 3;
     const int64_t kstep = tid >> 4;
-    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double mult2 = WIDE ? wide_mult2(mult) : 0.0, sinv = (WIDE && mult > 0.0) ? 1.0 / mult : 0.0;
+    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dig2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int64_t k = 4 * tid + t;                       // = 64 kstep + 16 i + 4 gam + t
         double val = (k < n) ? v[k] : 0.0;
-        long long q = (long long)rint(val * mult);
-#pragma unroll
-        for (int c = 0; c < 7; c++) {
-            long long dg = (long long)(signed char)(q & 0xFF);
-            q = (q - dg) >> 8;
-            dig[c] |= (uint32_t)(dg & 0xFF) << (8 * t);
-        }
+        const double qd = rint(val * mult);
+        digits_of((long long)qd, t, dig);
+        if (WIDE && mult2 > 0.0) digits_of((long long)rint(fma(-qd, sinv, val) * mult2), t, dig2);
     }
     uint32_t* o = out + kstep * 256 + (gam * 16 + col0) * 4 + i;
 #pragma unroll
     for (int c = 0; c < 8; c++) o[c * 4] = dig[c];
+    if (WIDE) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) o[(8 + c) * 4] = dig2[c];
+    }
 }
 
 __device__ __forceinline__ void combine(const long long (&s)[7], long long& hi, long long& lo);
@@ -1385,6 +1422,46 @@ __global__ __launch_bounds__(256) void k_fin_ax(const int32_t* __restrict__ part
     if (threadIdx.x == 0) a.dq_part[v][blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// ---- epilogues of the two-level passes (kernel mode 2): planes of the HEAD slot and of the RESIDUAL slot, each an exact integer,
+// each converted with one rounding and scaled by its own power of two; the second is 2^-54 of the first.
+__device__ __forceinline__ double two_level(const long long (&h)[7], const long long (&r)[7], double s1) {
+    long long hh, hl, rh, rl;
+    combine(h, hh, hl);
+    combine(r, rh, rl);
+    const double head = ((double)hh * 4294967296.0 + (double)hl) * s1;
+    const double res = ((double)rh * 4294967296.0 + (double)rl) * (s1 * 0x1p-54);
+    return head + res;
+}
+// data::Ax: out[n] = mask (sum_i a'_ni c_i - sum_i b_ni mave_i c_i) post; planes 0 / 1 of every piece = head / residual
+__global__ __launch_bounds__(256) void k_fin_ax_wide(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t npad,
+                                                     const double* __restrict__ scal, const uint32_t* __restrict__ mask2, double post,
+                                                     double* __restrict__ out, int64_t nkb, int64_t skL, int qshift, int64_t piv) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= npad) return;
+    double val = 0.0;
+    const uint32_t present = (mask2[n >> 4] >> (2 * (n & 15))) & 1u;
+    if (present && n < rows_p) {
+        long long sx[2][7];
+        gather_pieces<2>(partial, pieces_of(n, ksplit, nkb, skL, qshift, piv), 2, 0, rows_p, n, sx);
+        val = two_level(sx[0], sx[1], scal[3]) * post;
+    }
+    out[n] = val;
+}
+// data::ATx: out[m] = msig (sum a p - mave sum b p) / sqrt(N); planes 0..3 of every piece = a'.head, b.head, a'.residual, b.residual
+__global__ __launch_bounds__(256) void k_fin_atx_wide(const int32_t* __restrict__ partial, int ksplit, int64_t rows_p, int64_t M,
+                                                      const double* __restrict__ scal, const double* __restrict__ mave,
+                                                      const double* __restrict__ msig, double inv_sqrt_n, double* __restrict__ out,
+                                                      const double* __restrict__ addx, double tau, double gam2, int64_t nkb, int64_t skL,
+                                                      int64_t piv) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    long long sx[4][7];
+    gather_pieces<4>(partial, pieces_of(m, ksplit, nkb, skL, 8, piv), 4, 0, rows_p, m, sx);
+    const double sa = two_level(sx[0], sx[2], scal[3]), sb = two_level(sx[1], sx[3], scal[3]);
+    const double r = msig[m] * fma(-mave[m], sb, sa) * inv_sqrt_n;
+    out[m] = addx ? fma(tau, r, gam2 * addx[m]) : r;
+}
+
 inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 // launch of the streaming kernel of one matvec (HIP events around it when the roofline timing is on)
@@ -1404,9 +1481,9 @@ void launch_tile(hipStream_t s, const gvm::Plan& pl, const void* dig0, const voi
     hipLaunchKernelGGL((k_mfma_tile<DIR, MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), lds_pad, s, (const u32x4*)pl.tiles,     \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, nv, go, rstride, \
                        (uint32_t)gvm::piv_of(d, nq))
-    if (MODE == 4 || !go) {
+    if (MODE >= 4 || !go) {             // (the people-statistics plane and the two-level passes are never part of a device-resident CG step)
         if (d.skL > 0) GV_LAUNCH_T(true, false); else GV_LAUNCH_T(false, false);
-    } else if constexpr (MODE != 4) {
+    } else if constexpr (MODE < 4) {
         if (d.skL > 0) GV_LAUNCH_T(true, true); else GV_LAUNCH_T(false, true);
     }
 #undef GV_LAUNCH_T
@@ -1444,6 +1521,8 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
         if (MODE == 2) return launch_tile<0, 2>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
         if (MODE == 1) return launch_tile<1, 3>(s, pl, dig0, dig1, nrg, nkb, d, 1, go);
         if (MODE == 3) return launch_tile<1, 3>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
+        if (MODE == 5) return launch_tile<0, 5>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
+        if (MODE == 6) return launch_tile<1, 6>(s, pl, dig0, dig1, nrg, nkb, d, 2, go);
         return launch_tile<1, 4>(s, pl, dig0, dig1, nrg, nkb, d, 1, go);
     }
     if (pl.ev0) (void)hipEventRecord(pl.ev0, s);
@@ -1456,9 +1535,9 @@ void launch_stream(hipStream_t s, const gvm::Plan& pl, const void* stripes, cons
     hipLaunchKernelGGL((k_mfma_matvec<MODE, SKV, GOV>), dim3((unsigned)grid), dim3(256), lds_pad, s, (const u32x4*)stripes,   \
                        (const u32x4*)dig0, (const u32x4*)dig1, nrg, nkb, d.ks, d.skL, d.prio, kb, pl.partial, go,        \
                        (uint32_t)gvm::piv_of(d, nq))
-    if (MODE == 4 || !go) {            // (the people-statistics plane is never part of a CG step)
+    if (MODE >= 4 || !go) {            // (the people-statistics plane and the two-level passes are never part of a device-resident CG step)
         if (d.skL > 0) GV_LAUNCH_MV(true, false); else GV_LAUNCH_MV(false, false);
-    } else if constexpr (MODE != 4) {
+    } else if constexpr (MODE < 4) {
         if (d.skL > 0) GV_LAUNCH_MV(true, true); else GV_LAUNCH_MV(false, true);
     }
 #undef GV_LAUNCH_MV
@@ -1512,7 +1591,7 @@ static void prep_quant_atx(hipStream_t s, const Plan& pl, const double* pa, cons
     q.nblocks = nb;
     q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0; q.part[0] = red_partial; q.wr[0] = 1;
     q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8; q.part[1] = red_partial + PREP_STRIDE; q.wr[1] = 1;
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), nv), dim3(256), 0, s, q, npad, pl.nkb_m, nv == 2 ? 16 : 8);
+    hipLaunchKernelGGL(k_quant<false>, dim3(nblk(pl.nkb_m * 64, 256), nv), dim3(256), 0, s, q, npad, pl.nkb_m, nv == 2 ? 16 : 8);
 }
 
 // red_blocks of gvk::dots: the block partials of the fused <d, p> are taken in the same order
@@ -1580,7 +1659,7 @@ void marker_pvals(hipStream_t s, const Plan& pl, const double* y, const double* 
     q.nblocks = nb;
     q.v[0] = pa; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0; q.part[0] = red_partial; q.wr[0] = 1;
     q.v[1] = pb; q.scal[1] = pl.scal + 4; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8; q.part[1] = red_partial + PREP_STRIDE; q.wr[1] = 1;
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_m * 64, 256), 2), dim3(256), 0, s, q, npad, pl.nkb_m, 16);
+    hipLaunchKernelGGL(k_quant<false>, dim3(nblk(pl.nkb_m * 64, 256), 2), dim3(256), 0, s, q, npad, pl.nkb_m, 16);
     {
         gvm::Plan q2 = pl;      // no roofline events around the p-value pass
         q2.ev0 = q2.ev1 = nullptr;
@@ -1605,14 +1684,14 @@ static void quant_ax(hipStream_t s, const Plan& pl, int nv, const double* red_pa
         q.v[2] = pl.cv2; q.scal[2] = pl.scal + 4; q.out[2] = (uint32_t*)pl.dig0; q.col0[2] = 8;
         q.v[3] = pl.ev2; q.scal[3] = pl.scal + 4; q.out[3] = (uint32_t*)pl.dig1; q.col0[3] = 8;
         if (pl.layout == 1)
-            hipLaunchKernelGGL(k_quant_t, dim3(nblk(pl.nkb_n * 16, 256), 2 * nv), dim3(256), 0, s, q, pl.M, pl.nkb_n);
+            hipLaunchKernelGGL(k_quant_t<false>, dim3(nblk(pl.nkb_n * 16, 256), 2 * nv), dim3(256), 0, s, q, pl.M, pl.nkb_n);
         else
-            hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+            hipLaunchKernelGGL(k_quant<false>, dim3(nblk(pl.nkb_n * 64, 256), 4), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
         return;
     }
     q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;
     q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig0; q.col0[1] = 8;
-    hipLaunchKernelGGL(k_quant, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+    hipLaunchKernelGGL(k_quant<false>, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
 }
 static void fin_ax(hipStream_t s, const Plan& pl, const Decomp& d, int nv, int64_t npad, const uint32_t* mask2, double post,
                    double* outa, double* outb, const CgHook* cg = nullptr, int64_t n0 = 0) {
@@ -1686,6 +1765,41 @@ void ax2(hipStream_t s, const Plan& pl, const double* xa, const double* xb, cons
          const uint32_t* mask2, int64_t npad, double post, double* red_partial, double* outa, double* outb, const CgHook* cg) {
     ax_prep(s, pl, xa, xb, mave, msig, red_partial, cg);
     ax_rows(s, pl, 2, 0, pl.nrg_n, mask2, npad, post, outa, outb, cg);
+}
+
+// ---- kernel mode 2: one-vector products as a two-vector pass whose slots are the head and the residual of the vector ---------
+void ax_wide(hipStream_t s, const Plan& pl, const double* x, const double* mave, const double* msig, const uint32_t* mask2,
+             int64_t npad, double post, double* red_partial, double* out) {
+    const int nb = prep_blocks(pl.M);
+    hipLaunchKernelGGL(k_prep_ax_wide, dim3(nb), dim3(256), 0, s, x, mave, msig, pl.M, pl.cv, pl.ev, red_partial);
+    QuantArgs q{};
+    q.nblocks = nb;
+    q.part[0] = q.part[1] = red_partial;                      // c and e on ONE scale
+    q.wr[0] = 1;
+    q.v[0] = pl.cv; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0;     // a' plane: [c head | c residual]
+    q.v[1] = pl.ev; q.scal[1] = pl.scal; q.out[1] = (uint32_t*)pl.dig1; q.col0[1] = 0;     // present plane: [e head | e residual]
+    if (pl.layout == 1)
+        hipLaunchKernelGGL(k_quant_t<true>, dim3(nblk(pl.nkb_n * 16, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n);
+    else
+        hipLaunchKernelGGL(k_quant<true>, dim3(nblk(pl.nkb_n * 64, 256), 2), dim3(256), 0, s, q, pl.M, pl.nkb_n, 16);
+    const Decomp& d = pl.dn[1];
+    launch_stream<6>(s, pl, pl.stripes_n, pl.dig0, pl.dig1, pl.nrg_n, pl.nkb_n, d);
+    hipLaunchKernelGGL(k_fin_ax_wide, dim3(nblk(npad, 256)), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_n * pl.rows_n, npad, pl.scal, mask2,
+                       post, out, pl.nkb_n, d.skL, pl.rows_n == 256 ? 10 : 8, piv_of(d, (pl.nrg_n + 3) / 4));
+}
+void atx_wide(hipStream_t s, const Plan& pl, const double* p, int64_t npad, const double* mave, const double* msig, double inv_sqrt_n,
+              double* red_partial, double* out, const double* addx, double tau, double gam2) {
+    const int nb = prep_blocks(npad);
+    PrepAtx pa_{{p, nullptr}, nullptr, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    hipLaunchKernelGGL(k_prep_atx, dim3(nb, 1), dim3(256), 0, s, pa_, npad, red_partial);
+    QuantArgs q{};
+    q.nblocks = nb;
+    q.v[0] = p; q.scal[0] = pl.scal; q.out[0] = (uint32_t*)pl.dig0; q.col0[0] = 0; q.part[0] = red_partial; q.wr[0] = 1;
+    hipLaunchKernelGGL(k_quant<true>, dim3(nblk(pl.nkb_m * 64, 256), 1), dim3(256), 0, s, q, npad, pl.nkb_m, 16);
+    const Decomp& d = pl.dm[1];
+    launch_stream<5>(s, pl, pl.stripes_m, pl.dig0, nullptr, pl.nrg_m, pl.nkb_m, d);
+    hipLaunchKernelGGL(k_fin_atx_wide, dim3(nblk(pl.M, 256)), dim3(256), 0, s, pl.partial, d.ks, pl.nrg_m * 64, pl.M, pl.scal, mave, msig,
+                       inv_sqrt_n, out, addx, tau, gam2, pl.nkb_m, d.skL, piv_of(d, (pl.nrg_m + 3) / 4));
 }
 
 void tile_chunk(hipStream_t s, const uint8_t* raw, int64_t pitch, int64_t mc, int64_t N, void* tiles, int64_t rg0, int64_t nkb) {

@@ -91,7 +91,7 @@ int gv_set_layout(gv_ctx* ctx, int raw_rows, int stripes);
 int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0 none, 1 two stripe sets, 2 tile layout */
 /* kernel family for Ax/ATx: 1 (default) = i8 MFMA fixed-point kernels on the re-encoded layout (0.8 of the HBM roofline,
  * results within 2e-14 of fp64 sums, bit-reproducible); 0 = fp64 VALU kernels on the raw rows (parity anchor, 4-9 % of the
- * roofline; needs gv_set_layout(ctx, 1, ..) before ingest). */
+ * roofline; needs gv_set_layout(ctx, 1, ..) before ingest); 2 = two-level fixed point on the re-encoded layout (below). */
 /* Accuracy contract of kernel mode 1.  A vector enters a product in fixed point with ONE exponent for the whole vector
  * (|q| < 2^54 relative to its largest entry); the product itself is exact integer arithmetic with one final rounding.  Hence
  *   Ax : |out[n] - exact[n]| <= M * 2^-50 * max_i |msig[i] x[i]| / sqrt(N),
@@ -102,7 +102,17 @@ int gv_get_layout(const gv_ctx* ctx);   /* the re-encoded layout resident now: 0
  * output that does not see the large entries (Ax at an individual whose genotype is MISSING at the one marker carrying a huge
  * effect) is accurate to the bound above, not to its own last bits as the reference's fp64 sums are there.  The vectors of a VAMP
  * run span a few decades and never come near this; input with more than ~2^40 of dynamic range that needs per-entry relative
- * accuracy should use kernel mode 0.  tests/test_gpu_matvec.py asserts both bounds on such input. */
+ * accuracy should use kernel mode 2 (below).  tests/test_gpu_matvec.py asserts both bounds on such input.
+ * Kernel mode 2 (ABI 4) = the fast remedy: TWO-LEVEL fixed point on the same resident layout.  The vector is quantised as in mode 1
+ * (the head), the exact fp64 residual v - head is quantised once more with the exponent 54 below (v = head + residual to within
+ * 2^-109 of the largest entry: ~108 bits instead of 54), and head and residual travel as the two slots of ONE two-vector pass; the
+ * planes of that pass give a missing genotype an exact zero (a' = a if present else 0; b = present), as the reference's table does
+ * (data.cpp:951-988), instead of "3 c + (mave - 3) c - mave c", which cancels only to rounding.  An output entry that does not see
+ * the huge entries is then accurate to its own magnitude (the adversarial case above: 1e-9 ... 1e-3 relative in mode 1, < 1e-12 in
+ * mode 2) for up to ~2^55 of in-vector dynamic range.  Cost: one two-vector pass per product (1.0-1.1 x a one-vector pass); the
+ * two-vector entry points run two such passes; the solvers take the host-driven loops (the device-resident CG and GV_OVERLAP are
+ * mode-1 machinery); marker / people statistics and p-values are those of mode 1 (exact counts; their sums are not affected).
+ * Results are bit-reproducible and independent of layout and decomposition, as in mode 1 -- but not bit-equal to mode 1. */
 int gv_set_kernel_mode(gv_ctx* ctx, int mode);
 int gv_get_kernel_mode(const gv_ctx* ctx);
 

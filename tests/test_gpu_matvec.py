@@ -111,8 +111,8 @@ def test_fixed_point_per_entry_bound_on_adversarial_dynamic_range(oracle):
     genotype is missing there the exact product does not see the huge entry at all (the reference's table gives those terms an exact
     0, data.cpp:951-988), while the fixed-point product carries the quantisation of the other entries at the scale of the huge one:
     the bound holds, and the error relative to the entry's OWN magnitude is far above fp64's -- measured and asserted here so that
-    the deviation stays on record (kernel mode 0 is the remedy for such input).  Same for ATx with one huge individual, seen from a
-    monomorphic marker whose exact output is 0."""
+    the deviation stays on record (kernel mode 2 is the remedy for such input, at the cost of a two-vector pass; kernel mode 0, the
+    fp64 VALU family, the slow one).  Same for ATx with one huge individual, seen from a monomorphic marker whose exact output is 0."""
     N, M = 4000, 600
     rng = np.random.default_rng(5)
     bed = synth.synth_bed(N, M, seed=31, miss_ppm=20000).reshape(M, N // 4).copy()
@@ -142,6 +142,13 @@ def test_fixed_point_per_entry_bound_on_adversarial_dynamic_range(oracle):
         rel_blind = np.max(err[miss_j] / np.abs(ref[miss_j]))
         assert 1e-9 < rel_blind, rel_blind               # (the deviation is real: an entry's own magnitude is not the yardstick)
         assert np.max(np.abs(z0 - ref)[miss_j] / np.abs(ref[miss_j])) < 1e-11      # the fp64 family has no such floor
+        # ... nor has kernel mode 2, the two-level fixed point on the same resident layout (tests/test_gpu_mode2.py): the fast remedy
+        sh.set_kernel_mode(2)
+        z2 = sh.Ax(x)[:N]
+        rel_blind = np.max(np.abs(z2 - ref)[miss_j] / np.abs(ref[miss_j]))
+        assert rel_blind < 1e-12, rel_blind
+        assert np.max(np.abs(z2 - ref)[~miss_j] / np.abs(ref[~miss_j])) < 1e-12
+        sh.set_kernel_mode(1)
         # ATx: one individual 2^45 above the rest; the monomorphic marker's exact output is 0
         p = np.zeros(4 * (N // 4))
         p[:N] = rng.standard_normal(N)
