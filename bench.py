@@ -428,6 +428,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ax_gbps, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(ax_gbps / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": shard_bytes, "avg_kernel_ms": round(ms_ax, 4),
+                     # how avg_kernel_ms is measured: gv_set_timing(2) = HIP events recorded on the context's stream around EVERY
+                     # streaming-kernel launch of the timed region (the events stay inside `value`'s clock: conservative by their
+                     # ~2 us per launch); the rocprofv3 --kernel-trace --stats average of the same command is in profiles/
+                     "timing": "HIP events around every streaming-kernel launch inside the timed region (gv_set_timing(2))",
                      # context ("also report vs measured copy bandwidth"): what plain streaming kernels reach
                      # on this box, measured now -- a read-only stream over the same resident stripes, and a copy
                      "read_stream_GBps": round(sh.read_bandwidth(1 << 30, 3), 1),

@@ -217,6 +217,39 @@ def test_vamp_run_in_mode_2_follows_the_oracle(oracle):
     assert rel(r2.x_est, ref.x_est) < 1e-7 and rel(r2.x_est, r1.x_est) < 1e-9 and rel(r2f.x_est, r2.x_est) < 1e-9
 
 
+@pytest.mark.parametrize("transport", [1, 3])
+def test_mode_2_takes_the_multi_rank_branches_bit_for_bit(transport):
+    """gv_debug_force_multi in kernel mode 2: the exchange inside Ax (data.cpp:928/:995: partial sums un-scaled, all-reduce, 1/sqrt(N)
+    afterwards), the packed scalars of the host-driven CG loops -- a sum over one rank is the identity, so every output equals the
+    plain run's bit for bit."""
+    N, M = 3001, 2500
+    bed = synth.synth_bed(N, M, seed=5, miss_ppm=8000)
+    present, m4 = _mask(N, 0.02, 3)
+    rng = np.random.default_rng(1)
+    x, v = rng.standard_normal(M), rng.standard_normal(M)
+    with capi.Shard(N, M) as sh:
+        sh.upload_bed(bed)
+        sh.set_mask(m4, int(present.sum()))
+        sh.compute_markers_statistics()
+        sh.set_kernel_mode(2)
+
+        def run():
+            z = sh.Ax(x)
+            w = sh.ATx(z)
+            dv, mu = sh.vecM(v), sh.vecM()
+            st, rr = sh.cg_solve(dv, None, 2.0, 0.8, 1, 25, mu)
+            return z, w, mu.download(), rr
+
+        plain = run()
+        sh.force_multi(transport, 20)
+        try:
+            forced = run()
+        finally:
+            sh.force_multi(0)
+        for a, b in zip(plain, forced):
+            assert not np.isnan(b).any() and np.array_equal(a, b)
+
+
 def test_mode_2_at_the_8gpu_shard_shape_rate_and_parity(oracle):
     """N = 400k x M = 125k: sampled columns against the oracle in mode 2, and what the two-level pass costs beside mode 1's
     one-vector pass (asserted loosely: it is ONE two-vector pass, not two)."""
