@@ -24,7 +24,7 @@
     X(unsigned int, learn_vars, 1) X(unsigned int, seed, 1) X(unsigned int, init_est, 0) X(unsigned int, redglob, 0) \
     X(unsigned int, use_lmmse_damp, 0) X(unsigned int, use_XXT_denoiser, 0) X(unsigned int, use_freeze, 0)            \
     X(unsigned int, store_pvals, 0)                                                                                   \
-    /* [ext] --device (default: LOCAL_RANK or 0), --kernel-mode 0|1 (default 1: i8 MFMA), --synth-seed S (on-device   \
+    /* [ext] --device (default: LOCAL_RANK or 0), --kernel-mode 0|1|2 (default 1: i8 MFMA; 2: the same in two-level fixed point), --synth-seed S (on-device   \
        synthetic .bed when there is no --bed-file), --synth-miss-ppm, --diagnostics 1 (the 3 print-only Ax of         \
        vamp.cpp:646-681), --store-iterates 0 (skip the per-iteration .bin/.csv dumps), --fuse-solves (default 4): 0 the reference\
        sequence; 1 the LMMSE and Onsager CG solves share their passes (bit-identical); 2 also z1 = A x1_hat rides in  \

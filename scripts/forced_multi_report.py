@@ -1,5 +1,5 @@
-"""Assembles profiles/r5_forced_multi_gaps.txt from the directory scripts/forced_multi_trace.sh leaves (development tool).
-  python scripts/forced_multi_report.py gpurun_out/<tag> > profiles/r5_forced_multi_gaps.txt"""
+"""Assembles profiles/r<N>_forced_multi_gaps.txt from the directory scripts/forced_multi_trace.sh leaves (development tool).
+  python scripts/forced_multi_report.py gpurun_out/<tag> > profiles/r<N>_forced_multi_gaps.txt"""
 import csv
 import json
 import os
@@ -40,7 +40,7 @@ n1, s1 = small("forced")
 n2, s2 = small("forced_ov4")
 ch = chunks("forced_ov4")
 whole = chunks("forced")
-print("# r5: the product's multi-rank branches on ONE GPU over an asynchronous in-stream exchange (gv_debug_force_multi / GVAMP_FORCE_MULTI)")
+print("# the product's multi-rank branches on ONE GPU over an asynchronous in-stream exchange (gv_debug_force_multi / GVAMP_FORCE_MULTI)")
 print("# shape: one shard of the 8-GPU headline job, N=400k x M=125k (12.5 GB), tile layout, --fuse-solves 4, device-resident CG")
 print("# produced by scripts/forced_multi_trace.sh + scripts/forced_multi_report.py (rocprofv3 --kernel-trace; trace_gaps.py, trace_step.py)")
 print("#")

@@ -1,5 +1,5 @@
 # development: the forced multi-rank branches at the per-GPU shard of the 8-GPU headline job (N=400k x M=125k) on ONE GPU
-# (gv_debug_force_multi: 1-rank RCCL all-reduce followed by the loop-back) -> gpurun_out/$1/ ; see profiles/r5_forced_multi_gaps.txt
+# (gv_debug_force_multi: 1-rank RCCL all-reduce followed by the loop-back) -> gpurun_out/$1/ ; see profiles/r<N>_forced_multi_gaps.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-fm}; mkdir -p $O
 for leg in plain forced forced_ov4; do

@@ -107,10 +107,10 @@ def _toy_bed(tmp_path):
     return str(p)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gvamp_sim_executable_vs_reference_outputs(tmp_path, mode):
     """The reference-style driver with the reference's own command line, compared with the .bin files the real
-    reference wrote for it (survey probe, np = 1)."""
+    reference wrote for it (survey probe, np = 1); --kernel-mode 0 the fp64 VALU family, 1 the default, 2 the two-level fixed point."""
     bed = _toy_bed(tmp_path)
     out = str(tmp_path / "out") + "/"
     cmd = [os.path.join(ROOT, "gvamp_amd", "gvamp_sim"), "--bed-file", bed, "--N", "2000", "--Mt", "10000",
