@@ -1,11 +1,21 @@
-# development: per-workgroup clocks of the two-vector launches of the mid-size rows on the engine that ships (layout auto -> tile).
-# needs `bash scripts/build_variant.sh wgtime -DGV_WGTIME` first; writes gpurun_out/r6_wgtime/*.txt
+# development: per-workgroup clocks of the two-vector launches of the mid-size rows on the engine that ships (layout auto -> tile): round 5's
+# picks pinned beside what the library picks now.  Needs `bash scripts/build_variant.sh wgtime -DGV_WGTIME` first; writes gpurun_out/r6_wgtime/*.txt
 O=gpurun_out/r6_wgtime; mkdir -p $O
 export GV_DBG_LIB=$PWD/gpurun_wgtime_libgvamp.so
-for shape in "400000 125000" "100000 500000" "50000 200000"; do
-  set -- $shape
-  for which in ax2 atx2; do
-    python3 scripts/wgtime.py $1 $2 $which > $O/wg_$1x$2_$which.txt 2>&1 || { tail -5 $O/wg_$1x$2_$which.txt; exit 1; }
-  done
-done
-tail -n +1 $O/wg_400000x125000_*.txt
+run() { python3 scripts/wgtime.py "$@" > $O/tmp.txt 2>&1 || { tail -5 $O/tmp.txt; exit 1; }; cat $O/tmp.txt; echo; }
+{
+echo "## the 8-GPU shard shape, N=400k x M=125k"
+run 400000 125000 atx2 0 ks=1,prio=1
+run 400000 125000 atx2
+run 400000 125000 ax2 0 ks=8,geo=0.65,prio=1
+run 400000 125000 ax2
+echo "## config 2, N=100k x M=500k"
+run 100000 500000 atx2
+run 100000 500000 ax2 0 ks=5
+run 100000 500000 ax2
+echo "## config 5, N=50k x M=200k"
+run 50000 200000 atx2 0 cells=8,whole=768,prio=1
+run 50000 200000 atx2
+run 50000 200000 ax2
+} > $O/all.txt
+rm -f $O/tmp.txt
