@@ -69,7 +69,7 @@ class IngestStats(C.Structure):      # gv_ingest_stats
 
 class DecompInfo(C.Structure):
     _fields_ = [("ks", C.c_int), ("balanced_cells", C.c_int64), ("prio", C.c_int), ("taper", C.c_float), ("tuned", C.c_int),
-                ("whole_quads", C.c_int64), ("geo", C.c_float), ("wgs_per_cu", C.c_int)]
+                ("whole_quads", C.c_int64), ("geo", C.c_float), ("wgs_per_cu", C.c_int), ("xcd_skew", C.c_float)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
@@ -583,14 +583,15 @@ class Shard:
         names = ("atx", "atx2", "ax", "ax2")
         return {n: (({"balanced_cells": int(x.balanced_cells)} | ({"whole_quads": int(x.whole_quads)} if x.whole_quads > 0 else {}))
                     if x.balanced_cells > 0 else ({"ks": x.ks, "taper": round(float(x.taper), 2)} | ({"geo": round(float(x.geo), 2)} if x.geo > 0 else {})))
-                | ({"wgs_per_cu": 2} if x.wgs_per_cu == 2 else {}) | {"prio": x.prio, "tuned": bool(x.tuned)}
+                | ({"wgs_per_cu": 2} if x.wgs_per_cu == 2 else {}) | ({"xcd_skew": round(float(x.xcd_skew), 3)} if x.xcd_skew != 0 else {})
+                | {"prio": x.prio, "tuned": bool(x.tuned)}
                 for n, x in zip(names, d)}
 
-    def set_decomp(self, cls, ks=1, balanced_cells=0, whole_quads=0, prio=0, taper=0.0, geo=0.0, wgs_per_cu=0):
+    def set_decomp(self, cls, ks=1, balanced_cells=0, whole_quads=0, prio=0, taper=0.0, geo=0.0, wgs_per_cu=0, xcd_skew=0.0):
         """pins the decomposition of one streaming-kernel class (gv_set_decomp); cls: 0 atx, 1 atx2, 2 ax, 3 ax2 or its name"""
         if isinstance(cls, str):
             cls = ("atx", "atx2", "ax", "ax2").index(cls)
-        d = DecompInfo(ks, balanced_cells, prio, taper, 0, whole_quads, geo, wgs_per_cu)
+        d = DecompInfo(ks, balanced_cells, prio, taper, 0, whole_quads, geo, wgs_per_cu, xcd_skew)
         self._ck(self.L.gv_set_decomp(self.h, cls, C.byref(d)))
 
     def synchronize(self):

@@ -455,7 +455,7 @@ gv_ctx::EvRec* ev_next(gv_ctx* c, int kind) {
 // run on a shape pays for the measurement.  One line per key, the last matching line wins; a line is written with one
 // O_APPEND write (ranks of a sharded job may share the file).  Results never depend on the pick (exact integer
 // accumulation), so a stale or foreign line can cost time, never correctness; every loaded pick is range-checked.
-constexpr int GV_TUNE_VERSION = 7;   // bump when the candidate set or the line format changes shape
+constexpr int GV_TUNE_VERSION = 8;   // bump when the candidate set or the line format changes shape
 #ifndef GV_KERNEL_SRC_HASH
 #error "build with -DGV_KERNEL_SRC_HASH=\"...\" (gvamp_amd/build.py computes it from the streaming-kernel sources)"
 #endif
@@ -495,6 +495,7 @@ static bool decomp_ok(const gv_ctx* c, const gvm::Decomp& d, int side) {
     }
     if (!(d.taper >= 0.f && d.taper < 1.f) || !(d.geo >= 0.f && d.geo < 1.f) || (d.geo > 0.f && d.skL > 0) || (d.prio != 0 && d.prio != 1)) return false;
     if (d.occ != 0 && d.occ != 2 && d.occ != 3) return false;
+    if (!(d.xskew >= -0.2f && d.xskew <= 0.2f) || (d.xskew != 0.f && d.skL > 0)) return false;
     return (size_t)pieces * 4 * nrg * (side ? pl.rows_n : 64) * 8 * 4 <= pl.partial_bytes;
 }
 static bool tune_cache_load(gv_ctx* c) {
@@ -509,11 +510,17 @@ static bool tune_cache_load(gv_ctx* c) {
         if (strncmp(line, key.c_str(), key.size()) != 0) continue;
         gvm::Decomp d[4];
         long long sk[4], pv[4];
-        if (sscanf(line + key.size(), "%d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d %d %lld %lld %d %f %f %d", &d[0].ks, &sk[0],
-                   &pv[0], &d[0].prio, &d[0].taper, &d[0].geo, &d[0].occ, &d[1].ks, &sk[1], &pv[1], &d[1].prio, &d[1].taper, &d[1].geo, &d[1].occ,
-                   &d[2].ks, &sk[2], &pv[2], &d[2].prio, &d[2].taper, &d[2].geo, &d[2].occ, &d[3].ks, &sk[3], &pv[3], &d[3].prio, &d[3].taper,
-                   &d[3].geo, &d[3].occ) != 28)
-            continue;
+        {
+            const char* q = line + key.size();
+            int nread = 0, ok = 1;
+            for (int k = 0; k < 4 && ok; k++) {
+                if (sscanf(q, "%d %lld %lld %d %f %f %d %f%n", &d[k].ks, &sk[k], &pv[k], &d[k].prio, &d[k].taper, &d[k].geo, &d[k].occ, &d[k].xskew,
+                           &nread) != 8)
+                    ok = 0;
+                q += nread;
+            }
+            if (!ok) continue;
+        }
         for (int k = 0; k < 4; k++) { d[k].skL = sk[k]; d[k].piv = pv[k]; got[k] = d[k]; }
         have = true;
     }
@@ -553,8 +560,8 @@ static void tune_cache_store(gv_ctx* c) {
     char buf[1024];
     int n = snprintf(buf, sizeof(buf), "%s", key.c_str());
     for (int k = 0; k < 4; k++)
-        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f %.2f %d ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
-                      d[k]->taper, d[k]->geo, d[k]->occ);
+        n += snprintf(buf + n, sizeof(buf) - n, "%d %lld %lld %d %.2f %.2f %d %.3f ", d[k]->ks, (long long)d[k]->skL, (long long)d[k]->piv, d[k]->prio,
+                      d[k]->taper, d[k]->geo, d[k]->occ, d[k]->xskew);
     n += snprintf(buf + n, sizeof(buf) - n, "\n");
     const int fd = open(path.c_str(), O_WRONLY | O_APPEND | O_CREAT, 0644);
     if (fd < 0) return;
@@ -680,8 +687,8 @@ int autotune_ks(gv_ctx* c) {
                 if (t2 < t) t = t2;
             }
             if (verbose)
-                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d : %.4f ms / %s\n", cls, cd.ks,
-                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, cd.geo, cd.occ, t, "product");
+                fprintf(stderr, "[gvamp autotune] class %d ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d xskew %.3f : %.4f ms / %s\n", cls, cd.ks,
+                        (long long)cd.skL, (long long)cd.piv, cd.prio, cd.taper, cd.geo, cd.occ, cd.xskew, t, "product");
             return t;
         };
         gvm::Decomp best = cand[0];
@@ -715,6 +722,14 @@ int autotune_ks(gv_ctx* c) {
                 }
             }
         }
+        // ... then more work for the four faster XCDs (Decomp::xskew), on a winner whose quads have at least two segments
+        if (best.skL <= 0 && best.ks >= 2) {
+            const gvm::Decomp base = best;
+            for (float sk : {0.015f, 0.025f, 0.04f}) {
+                gvm::Decomp t = base; t.xskew = sk;
+                if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
+            }
+        }
         // ... then two workgroups per CU instead of three, on the winner and on the best geometric split (which is what gains from it
         // where anything does: many short workgroups late in the launch)
         {
@@ -730,8 +745,8 @@ int autotune_ks(gv_ctx* c) {
         }
         d = best;
         if (verbose)
-            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d\n", cls, d.ks, (long long)d.skL,
-                    (long long)d.piv, d.prio, d.taper, d.geo, d.occ);
+            fprintf(stderr, "[gvamp autotune] class %d -> ks %d skL %lld whole quads %lld prio %d taper %.1f geo %.2f occ %d xskew %.3f\n", cls, d.ks,
+                    (long long)d.skL, (long long)d.piv, d.prio, d.taper, d.geo, d.occ, d.xskew);
     }
     KCHK(c);
     c->tune_source = 1;
@@ -2313,6 +2328,7 @@ int gv_get_decomp(gv_ctx* c, gv_decomp_info* out4) {
         out4[k].taper = d[k]->taper;
         out4[k].geo = d[k]->geo;
         out4[k].wgs_per_cu = d[k]->occ == 2 ? 2 : 3;
+        out4[k].xcd_skew = d[k]->xskew;
         out4[k].tuned = c->ks_tuned ? 1 : 0;
     }
     return 0;
@@ -2325,6 +2341,7 @@ int gv_set_decomp(gv_ctx* c, int cls, const gv_decomp_info* in) {
     d.taper = in->taper; d.geo = in->geo;
     NEED(c, in->wgs_per_cu == 0 || in->wgs_per_cu == 2 || in->wgs_per_cu == 3, "gv_set_decomp: wgs_per_cu is 0 (default), 2 or 3");
     d.occ = in->wgs_per_cu == 2 ? 2 : 0;
+    d.xskew = in->balanced_cells > 0 ? 0.f : in->xcd_skew;
     if (d.skL > 0) d.ks = 1;
     NEED(c, decomp_ok(c, d, cls >> 1), "gv_set_decomp: the decomposition is not admissible for this shard (range, or too many pieces for the partial-sum buffer)");
     (cls >> 1 ? c->plan.dn : c->plan.dm)[cls & 1] = d;

@@ -20,6 +20,12 @@ struct Decomp {
                          // LDS to that end).  Fewer resident workgroups keep fewer K ranges and rows open at a time: the two-vector
                          // Ax of the 8-GPU shard on the tile layout streams 4 % faster with 512 than with 768 (profiles/r6_launch_dist_shard.txt),
                          // the 100 GB headline kernels 2-6 % slower -- one more thing the tuner measures
+    float xskew = 0.f;   // uniform split, ks >= 2: workgroups are dealt to the eight XCDs round-robin by block index and four of the XCDs
+                         // of an MI355X -- those that get the ODD block indices (hardware XCC ids 0, 2, 4, 6) -- finish equal shares
+                         // 4-6 % earlier than the other four (per-workgroup clocks, every box and round: profiles/r6_shard_wgtime.txt),
+                         // then idle for the rest of the launch.  The segments of a quad alternate between the two kinds; those with an
+                         // odd block index are made 1 + xskew, the others 1 - xskew times their nominal length.  Headline Ax: 15.09 ->
+                         // 14.90 ms at 0.025 (profiles/r6_xcd_skew.txt); the opposite sign loses as much.
 };
 // dynamic LDS bytes that cap a CU at d.occ workgroups of the streaming kernels (160 KiB per CU, <= 8 KiB static per workgroup)
 inline unsigned lds_pad_of(const Decomp& d) { return d.occ == 2 ? 60000u : 0u; }

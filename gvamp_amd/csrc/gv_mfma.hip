@@ -569,7 +569,9 @@ __device__ unsigned long long g_wgt[4 * 16384];   // development build only: per
 #endif
 // K-block boundaries of the segments of a uniform split (b[0] = 0 ... b[ks] = nkb; ks <= GV_MAX_KS)
 constexpr int GV_MAX_KS = 64;
-struct KBounds { uint32_t b[GV_MAX_KS + 1]; };
+// [c]: the boundaries of a quad of parity c = q & 1 (Decomp::xskew: segment j of quad q is run by a workgroup whose block index has
+// the parity of q + j; odd block indices land on the four XCDs that stream 4-6 % faster -- their segments are made that much longer)
+struct KBounds { uint32_t b[2][GV_MAX_KS + 1]; };
 
 // GO: the instantiation the device-resident CG loop launches (cg_run_device) -- it alone carries the `go` test, and it shows up
 // under its own name in kernel traces, so that the ~3 us launches of a dropped CG step do not dilute the statistics of the
@@ -604,9 +606,15 @@ __global__ __launch_bounds__(256, 3) void k_mfma_matvec(const u32x4* __restrict_
             uend = u + nkb32;
         }
     } else {
-        const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
-        u = q0 * nkb32 + kbnd.b[ks0];
-        uend = q0 * nkb32 + kbnd.b[ks0 + 1];
+        // workgroups are dealt to the eight XCDs round-robin by block index, so the parity of b decides whether a workgroup runs on one of
+        // the four faster or the four slower XCDs.  Segment ks0 of quad q0: with an odd number of quads b = q0 + nq ks0 has the parity
+        // of q0 + ks0; with an even one the quads are rotated by one per segment row so that it has, too -- a quad's segments
+        // alternate between the two kinds of XCD either way
+        const uint32_t ks0 = blockIdx.x / (uint32_t)nq;
+        uint32_t q0 = blockIdx.x % (uint32_t)nq;
+        if (!(nq & 1)) q0 = (q0 + ks0) % (uint32_t)nq;
+        u = q0 * nkb32 + kbnd.b[q0 & 1][ks0];
+        uend = q0 * nkb32 + kbnd.b[q0 & 1][ks0 + 1];
     }
     // Wave priority by remaining work (prio != 0).  The instruction arbiter favours the oldest wave of a SIMD, so the three
     // workgroups of a CU finish one after the other (measured: 245 / 320 / 385 us for equal work) and a launch ends on a
@@ -924,9 +932,15 @@ __global__ __launch_bounds__(256, 3) void k_mfma_tile(const u32x4* __restrict__ 
             uend = u + nkb32;
         }
     } else {
-        const uint32_t q0 = blockIdx.x % (uint32_t)nq, ks0 = blockIdx.x / (uint32_t)nq;
-        u = q0 * nkb32 + kbnd.b[ks0];
-        uend = q0 * nkb32 + kbnd.b[ks0 + 1];
+        // workgroups are dealt to the eight XCDs round-robin by block index, so the parity of b decides whether a workgroup runs on one of
+        // the four faster or the four slower XCDs.  Segment ks0 of quad q0: with an odd number of quads b = q0 + nq ks0 has the parity
+        // of q0 + ks0; with an even one the quads are rotated by one per segment row so that it has, too -- a quad's segments
+        // alternate between the two kinds of XCD either way
+        const uint32_t ks0 = blockIdx.x / (uint32_t)nq;
+        uint32_t q0 = blockIdx.x % (uint32_t)nq;
+        if (!(nq & 1)) q0 = (q0 + ks0) % (uint32_t)nq;
+        u = q0 * nkb32 + kbnd.b[q0 & 1][ks0];
+        uend = q0 * nkb32 + kbnd.b[q0 & 1][ks0 + 1];
     }
     const uint32_t p_quarter = (uend - u + 3) / 4;
     uint32_t p_thr = prio ? u + p_quarter : 0xffffffffu, p_lvl = 3;
@@ -1493,22 +1507,30 @@ static KBounds make_bounds(const gvm::Decomp& d, int64_t nkb) {
     KBounds kb{};
     if (d.skL <= 0) {
         const int ks = d.ks < 1 ? 1 : (d.ks > GV_MAX_KS ? GV_MAX_KS : d.ks);
-        // cumulative segment lengths, every segment at least one K-block (ks <= nkb): geometric (big first), tapered, or equal
-        double w[GV_MAX_KS], tot = 0.0, acc = 0.0;
+        // cumulative segment lengths, every segment at least one K-block (ks <= nkb): geometric (big first), tapered, or equal;
+        // then, per quad parity c, the segments whose workgroup has an ODD block index ((c + j) odd: the faster XCDs) stretched by
+        // 1 + xskew, the others shrunk by 1 - xskew
+        double w[GV_MAX_KS];
         for (int j = 0; j < ks; j++) {
             if (d.geo > 0.f && ks > 1) w[j] = j ? w[j - 1] * (double)d.geo : 1.0;
             else w[j] = ks > 1 ? 1.0 + (double)d.taper * (double)(ks - 1 - 2 * j) / (double)(ks - 1) : 1.0;
-            tot += w[j];
         }
-        kb.b[0] = 0;
-        for (int j = 0; j < ks; j++) {
-            acc += w[j];
-            int64_t e = (int64_t)((double)nkb * acc / tot + 0.5);
-            const int64_t lo = (int64_t)kb.b[j] + 1, hi = nkb - (ks - 1 - j);
-            e = e < lo ? lo : (e > hi ? hi : e);
-            kb.b[j + 1] = (uint32_t)e;
+        for (int c = 0; c < 2; c++) {
+            double tot = 0.0, acc = 0.0, v[GV_MAX_KS];
+            for (int j = 0; j < ks; j++) {
+                v[j] = w[j] * (((c + j) & 1) ? 1.0 + (double)d.xskew : 1.0 - (double)d.xskew);      // (c + j) odd <-> odd block index
+                tot += v[j];
+            }
+            kb.b[c][0] = 0;
+            for (int j = 0; j < ks; j++) {
+                acc += v[j];
+                int64_t e = (int64_t)((double)nkb * acc / tot + 0.5);
+                const int64_t lo = (int64_t)kb.b[c][j] + 1, hi = nkb - (ks - 1 - j);
+                e = e < lo ? lo : (e > hi ? hi : e);
+                kb.b[c][j + 1] = (uint32_t)e;
+            }
+            kb.b[c][ks] = (uint32_t)nkb;
         }
-        kb.b[ks] = (uint32_t)nkb;
     }
     return kb;
 }

@@ -30,7 +30,7 @@ typedef struct gv_vec gv_vec;
  * its version check instead of overrunning a buffer.  History: 1 rounds 1-2; 2 round 3 (gv_decomp_info grew by whole_quads,
  * the context defaults became kernel mode 1 / no raw rows / layout auto) and round 4 (gv_ingest_info2, gv_set_expected_passes);
  * 3 round 5 (gv_cg_solve_aat2w takes v_a as the in/out vector it is; layout auto takes ONE resident layout unless the caller
- * announces a long run -- gv_set_expected_passes; gv_debug_force_multi); 4 round 6 (gv_decomp_info grew by wgs_per_cu;
+ * announces a long run -- gv_set_expected_passes; gv_debug_force_multi); 4 round 6 (gv_decomp_info grew by wgs_per_cu and xcd_skew;
  * gv_set_kernel_mode accepts 2, the two-level fixed point).
  * A binding checks  gv_abi_version() == GV_ABI_VERSION  once, before anything else (INTEGRATION.md section B does). */
 #define GV_ABI_VERSION 4
@@ -403,6 +403,9 @@ typedef struct {
     float geo;               /* uniform split, 0 < geo < 1: segment j is geo^j times segment 0 (big first; replaces taper) */
     int wgs_per_cu;          /* ABI 4: workgroups of the streaming kernel a CU holds: 3 (what the registers allow; 0 on input means
                               * this) or 2 (the launch reserves LDS to that end: faster on some 12.5 GB shapes, slower at 100 GB) */
+    float xcd_skew;          /* ABI 4, uniform split with ks >= 2: segments whose workgroup lands on one of the four faster XCDs of the
+                              * part (odd block index) are 1 + xcd_skew, the others 1 - xcd_skew times their nominal length (equal
+                              * shares finish 4-6 % apart on an MI355X); 0 = equal, range -0.2 .. 0.2 */
 } gv_decomp_info;
 /* Wall time of the last ingest (gv_upload_bed / gv_upload_bed_file / gv_synth_bed), split into allocating the resident
  * layouts (hipMalloc of 100+ GB: the driver maps and wipes the pages; 0 when the buffers were reused) and filling them. */

@@ -36,11 +36,13 @@ with capi.Shard(a.N, a.M) as sh:
     def apply(spec):
         if spec == "tuned":
             kw = dict(ks=tuned.get("ks", 1), balanced_cells=tuned.get("balanced_cells", 0), whole_quads=tuned.get("whole_quads", 0),
-                      prio=tuned["prio"], taper=tuned.get("taper", 0.0), geo=tuned.get("geo", 0.0), wgs_per_cu=tuned.get("wgs_per_cu", 0))
+                      prio=tuned["prio"], taper=tuned.get("taper", 0.0), geo=tuned.get("geo", 0.0), wgs_per_cu=tuned.get("wgs_per_cu", 0),
+                      xcd_skew=tuned.get("xcd_skew", 0.0))
         else:
             d = dict(kv.split("=") for kv in spec.split(","))
             kw = dict(ks=int(d.get("ks", 1)), balanced_cells=int(d.get("cells", 0)), whole_quads=int(d.get("quads", 0)), prio=int(d.get("prio", 0)),
-                      taper=float(d.get("taper", 0)), geo=float(d.get("geo", 0)), wgs_per_cu=int(d.get("occ", 0)))
+                      taper=float(d.get("taper", 0)), geo=float(d.get("geo", 0)), wgs_per_cu=int(d.get("occ", 0)),
+                      xcd_skew=float(d.get("skew", 0)))
         sh.set_decomp(cls, **kw)
 
     f(); ref = w.download() if cls < 2 else p.download()

@@ -44,7 +44,7 @@ with capi.Shard(N, M) as sh:
                           wgs_per_cu=int(kw.get("occ", 0)))
         else:
             sh.set_decomp(which, ks=int(kw.get("ks", 1)), taper=kw.get("taper", 0.0), geo=kw.get("geo", 0.0), prio=int(kw.get("prio", 0)),
-                          wgs_per_cu=int(kw.get("occ", 0)))
+                          wgs_per_cu=int(kw.get("occ", 0)), xcd_skew=kw.get("skew", 0.0))
         for _ in range(2):
             f()
     sh.synchronize()
@@ -70,6 +70,9 @@ with capi.Shard(N, M) as sh:
     st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0          # wall_clock64: 100 MHz -> us
     dur = en - st
     xcc, cells = a[:, 2] & 0xf, a[:, 2] >> 8
+    blk = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)[:, 1] > 0)[0]
+    tab = {int(r): sorted(set(int(v) for v in xcc[blk % 8 == r])) for r in range(8)}
+    print("block index mod 8 -> hardware XCC id (HW_REG_XCC_ID): %s" % ", ".join("%d -> %s" % (r, "/".join(map(str, tab[r]))) for r in range(8)))
     wbytes = cells * CELL
     total = float(wbytes.sum())
     span = float(en.max())

@@ -244,7 +244,7 @@ int main(void) {
     printf("gv_aat_warm %zu %zu %zu\\n", sizeof(gv_aat_warm), offsetof(gv_aat_warm, accumulate_at_mu_a), offsetof(gv_aat_warm, have_ata_v_b));
     printf("gv_dot_spec %zu %zu %zu\\n", sizeof(gv_dot_spec), offsetof(gv_dot_spec, ya), offsetof(gv_dot_spec, sync));
     printf("gv_decomp_info %zu %zu %zu\\n", sizeof(gv_decomp_info), offsetof(gv_decomp_info, balanced_cells), offsetof(gv_decomp_info, whole_quads));
-    printf("gv_decomp_info_tail %zu %zu %zu\\n", offsetof(gv_decomp_info, geo), offsetof(gv_decomp_info, wgs_per_cu), sizeof(gv_decomp_info));
+    printf("gv_decomp_info_tail %zu %zu %zu\\n", offsetof(gv_decomp_info, geo), offsetof(gv_decomp_info, wgs_per_cu), offsetof(gv_decomp_info, xcd_skew));
     return 0;
 }
 """)
@@ -258,6 +258,6 @@ int main(void) {
         "gv_aat_warm": (C.sizeof(capi.AatWarm), capi.AatWarm.accumulate_at_mu_a.offset, capi.AatWarm.have_ata_v_b.offset),
         "gv_dot_spec": (C.sizeof(capi.DotSpec), capi.DotSpec.ya.offset, capi.DotSpec.sync.offset),
         "gv_decomp_info": (C.sizeof(capi.DecompInfo), capi.DecompInfo.balanced_cells.offset, capi.DecompInfo.whole_quads.offset),
-        "gv_decomp_info_tail": (capi.DecompInfo.geo.offset, capi.DecompInfo.wgs_per_cu.offset, C.sizeof(capi.DecompInfo)),
+        "gv_decomp_info_tail": (capi.DecompInfo.geo.offset, capi.DecompInfo.wgs_per_cu.offset, capi.DecompInfo.xcd_skew.offset),
     }
     assert got == want

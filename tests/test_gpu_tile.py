@@ -199,3 +199,42 @@ def test_reingest_under_the_automatic_choice_keeps_the_resident_layout():
     with capi.Shard(N, M) as sh:                    # nothing configured: the automatic choice, one tile layout
         sh.upload_bed(bed)
         assert sh.get_layout() == 2 and sh.get_kernel_mode() == 1
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_pinned_decompositions_with_xcd_skew_and_occupancy_cap_give_the_same_bits(layout):
+    """gv_set_decomp with the round-6 fields: xcd_skew (segment boundaries per quad parity: the workgroups with an odd block index
+    get longer K-segments; also on an EVEN number of quads, where the quads are rotated by one per segment row) and wgs_per_cu = 2
+    (dynamic LDS caps a CU at two workgroups).  Every product equals the library's own pick bit for bit."""
+    for N, M in ((9000, 20000), (2048, 30000)):      # quads per side: ATx 79 / 118 (odd / even), Ax tile 9 / 2, stripes 36 / 8
+        rng = np.random.default_rng(N)
+        bed = synth.synth_bed(N, M, seed=7, miss_ppm=8000)
+        x = rng.standard_normal(M)
+        with shard(bed, N, M, layout) as sh:
+            z0 = sh.Ax(x)
+            w0 = sh.ATx(z0)
+            xa, xb, za, zb, wa, wb = sh.vecM(x), sh.vecM(x[::-1].copy()), sh.vecN(), sh.vecN(), sh.vecM(), sh.vecM()
+            sh.ax2_dev(xa, xb, za, zb)
+            sh.atx2_dev(za, zb, wa, wb)
+            ref = (z0, w0, zb.download(), wb.download())
+            for kw in (dict(ks=2, xcd_skew=0.03), dict(ks=3, geo=0.5, prio=1, xcd_skew=0.2), dict(ks=5, taper=0.5, xcd_skew=-0.1),
+                       dict(ks=4, geo=0.6, prio=1, wgs_per_cu=2, xcd_skew=0.025), dict(ks=1, wgs_per_cu=2), dict(balanced_cells=16, prio=1, wgs_per_cu=2)):
+                took = 0
+                for cls in ("atx", "atx2", "ax", "ax2"):
+                    try:
+                        sh.set_decomp(cls, **kw)
+                    except capi.GvError:
+                        continue              # more pieces than this small shard's partial-sum buffer holds: the class keeps its pick
+                    took += 1
+                    v = sh.decomp()[cls]
+                    assert abs(v.get("xcd_skew", 0.0) - (kw.get("xcd_skew", 0.0) if "balanced_cells" not in kw else 0.0)) < 1e-6, (cls, v)
+                    assert v.get("wgs_per_cu", 3) == (2 if kw.get("wgs_per_cu") == 2 else 3), (cls, v)
+                assert took >= 2, kw
+                z1 = sh.Ax(x)
+                w1 = sh.ATx(z1)
+                sh.ax2_dev(xa, xb, za, zb)
+                sh.atx2_dev(za, zb, wa, wb)
+                for r, g in zip(ref, (z1, w1, zb.download(), wb.download())):
+                    assert np.array_equal(r, g), (N, M, kw)
+            with pytest.raises(capi.GvError):
+                sh.set_decomp("ax", ks=2, xcd_skew=0.5)
