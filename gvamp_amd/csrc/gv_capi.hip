@@ -722,11 +722,18 @@ int autotune_ks(gv_ctx* c) {
                 }
             }
         }
-        // ... then more work for the four faster XCDs (Decomp::xskew), on a winner whose quads have at least two segments
+        // ... then more work for four of the eight XCDs (Decomp::xskew), on a winner whose quads have at least two segments.  WHICH four
+        // finish equal shares first belongs to the box and to where the allocation landed (profiles/r6_xcd_skew.txt): both signs are
+        // measured on the resident data, and the better one is pushed once more if it beat the equal shares
         if (best.skL <= 0 && best.ks >= 2) {
             const gvm::Decomp base = best;
-            for (float sk : {0.015f, 0.025f, 0.04f}) {
+            const double t_base = best_t;
+            for (float sk : {0.02f, -0.02f}) {
                 gvm::Decomp t = base; t.xskew = sk;
+                if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
+            }
+            if (best.xskew != 0.f && best_t < t_base) {
+                gvm::Decomp t = best; t.xskew = best.xskew > 0.f ? 0.035f : -0.035f;
                 if (consider(t)) { d = cand[0]; KCHK(c); return done(1); }
             }
         }
