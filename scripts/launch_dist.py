@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gvamp_amd import capi
 
+if os.environ.get("GV_DBG_LIB"):          # a variant build of the library (scripts/build_variant.sh)
+    capi.LIB_PATH = os.environ["GV_DBG_LIB"]
 ap = argparse.ArgumentParser()
 ap.add_argument("N", type=int)
 ap.add_argument("M", type=int)
