@@ -4,7 +4,8 @@ Per case: random N, M around the tile / block boundaries (1, 4, 63..65, 255..257
 phenotypes, monomorphic / all-missing markers, vector magnitudes over 60 decades, a random work decomposition (uniform /
 tapered / balanced, wave priority on or off).  Checks: both resident layouts bit-identical in every product; Ax / ATx /
 statistics against the oracle (rel. l2 < 1e-12); two-vector passes = their one-vector passes bit for bit; pad and NA rows of
-Ax exactly zero; one CG solve (both layouts bit-identical, trace vs oracle 1e-9)."""
+Ax exactly zero; one CG solve (both layouts bit-identical, trace vs oracle 1e-9); a pinned decomposition with xcd_skew / wgs_per_cu
+(same bits); kernel mode 2 (two-level fixed point: both layouts bit-identical, oracle 1e-12, zeros at pad / NA rows)."""
 import os
 import sys
 import time
@@ -117,10 +118,22 @@ def run_case(k):
             vh = v.download()
             mu = sh.vecM()
             cgst, rr = sh.cg_solve(v, None, 1.7, 0.9, 1, 12, mu)
+            # round 6: a pinned decomposition with the new fields (longer segments for one block-index parity, two workgroups per CU):
+            # the same bits
+            for cls in ("ax", "atx", "ax2", "atx2"):
+                try:
+                    sh.set_decomp(cls, ks=int(rng.integers(2, 5)), geo=float(rng.choice([0.0, 0.5])), prio=int(rng.integers(2)),
+                                  wgs_per_cu=int(rng.choice([0, 2])), xcd_skew=float(rng.choice([-0.1, 0.02, 0.2])))
+                except capi.GvError:
+                    pass                          # fewer K-blocks than segments: the class keeps its decomposition
+            assert np.array_equal(sh.Ax(x), z) and np.array_equal(sh.ATx(p), w), "pinned decomposition (xcd_skew / wgs_per_cu) changed a bit"
+            # round 6: kernel mode 2 (two-level fixed point) on the same shard
+            sh.set_kernel_mode(2)
+            zw, ww = sh.Ax(x), sh.ATx(p)
             out[layout] = dict(mave=mave, msig=msig, z=z, w=w, z2=z2, w2=w2, za=za.download(), zb=zb.download(),
-                               wa=wa.download(), wb=wb.download(), lm=lm.download(), v=vh, mu=mu.download(), rr=rr)
+                               wa=wa.download(), wb=wb.download(), lm=lm.download(), v=vh, mu=mu.download(), rr=rr, zw=zw, ww=ww)
     a, b = out[1], out[2]
-    for key in ("mave", "msig", "z", "w", "z2", "w2", "za", "zb", "wa", "wb", "lm", "mu", "rr"):
+    for key in ("mave", "msig", "z", "w", "z2", "w2", "za", "zb", "wa", "wb", "lm", "mu", "rr", "zw", "ww"):
         assert np.array_equal(a[key], b[key], equal_nan=True), ("layouts differ", key)
     assert np.array_equal(a["z"], a["za"]) and np.array_equal(a["z2"], a["zb"]), "two-vector Ax != one-vector Ax"
     assert np.array_equal(a["w"], a["wa"]) and np.array_equal(a["w2"], a["wb"]), "two-vector ATx != one-vector ATx"
@@ -140,6 +153,10 @@ def run_case(k):
         assert ez < 1e-12 * sz, ("Ax vs oracle", info, ez / max(np.linalg.norm(oz), 1e-300), ez / sz)
         assert ew < 1e-12 * sw, ("ATx vs oracle", info, ew / max(np.linalg.norm(ow), 1e-300), ew / sw)
         assert np.all(a["z"][N:] == 0) and np.all(a["z"][:N][~present] == 0), "pad / NA rows of Ax"
+        ezw, eww = np.linalg.norm(a["zw"] - oz), np.linalg.norm(a["ww"] - ow)
+        assert ezw < 1e-12 * sz, ("kernel mode 2: Ax vs oracle", info, ezw / sz)
+        assert eww < 1e-12 * sw, ("kernel mode 2: ATx vs oracle", info, eww / sw)
+        assert np.all(a["zw"][N:] == 0) and np.all(a["zw"][:N][~present] == 0), "kernel mode 2: pad / NA rows of Ax"
     return info
 
 
