@@ -1,7 +1,8 @@
 """Randomised full VAMP runs against the oracle (development; run on a GPU box):   python scripts/fuzz_vamp.py [cases] [seed]
 Per case: a random small shard (N, M around tile / block boundaries), missing genotypes, a random prior (2-5 components),
 h2, rho, CG cap, 3-5 iterations; model linear / linear with --use-XXT-denoiser 1 / probit; kernel family (fp64 on raw rows, or
-fixed point on two stripe sets / the tile layout); --fuse-solves 0 ... 4.  Against the oracle's run of the same
+fixed point on two stripe sets / the tile layout, or kernel mode 2 -- the two-level fixed point -- at levels 0 and 4); --fuse-solves
+0 ... 4.  Against the oracle's run of the same
 configuration: x_hat to the north-star tolerance 1e-5 (relative l2), per-iteration CG and Onsager step counts, prior after
 EM.  Between fuse levels and layouts of the product: fixed-point layouts bit-identical, fuse levels to 1e-9."""
 import os
@@ -99,9 +100,9 @@ def run_case(seed0, k):
         extra["model"] = "bin_class"
     runs = {}
     y = None
-    for mode, layout in ((1, 1), (1, 2), (0, 0)):
+    for mode, layout in ((1, 1), (1, 2), (0, 0), (2, 2)):        # (2, 2): kernel mode 2, the two-level fixed point, on the tile layout
         with capi.Shard(N, M) as sh:
-            if mode == 1:
+            if mode != 0:
                 sh.set_layout(False, layout)
             else:
                 sh.set_layout(True, False)
@@ -110,7 +111,7 @@ def run_case(seed0, k):
             if y is None:
                 beta, yy = hostapi.sim_phen(sh, h2, CV, sseed)
                 y = (yy > 0).astype(float) if model == "probit" else yy
-            for fuse in ((0, 1, 2, 3, 4) if mode == 1 and layout == 1 else (2, 4) if mode == 1 else (0,)):
+            for fuse in ((0, 1, 2, 3, 4) if mode == 1 and layout == 1 else (2, 4) if mode == 1 else (0, 4) if mode == 2 else (0,)):
                 runs[(mode, layout, fuse)] = hostapi.infere_linear(sh, y, probs, vars_, true_signal=beta, fuse_solves=fuse,
                                                                    **kw, **extra)
     ref = oracle.infere(bed, N, M, y, probs, vars_, true_signal=beta, **kw, **extra)
