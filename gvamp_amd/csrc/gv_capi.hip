@@ -576,8 +576,8 @@ static void tune_cache_store(gv_ctx* c) {
 // the cache above.  Protocol, sized so that the cold cost stays a fraction of a second at 100 GB:
 //   stage A  the uniform splits short-listed by the cost model and the balanced grids, without / with their natural priority
 //            setting;  stage B  on the winner only: progress-based wave priority (uniform splits), then tapered segment
-//            lengths 0.5 / 0.9 (uniform splits with more than one segment), then two workgroups per CU instead of three.
-//            At most 16 timed candidates per class.
+//            lengths 0.5 / 0.9 (uniform splits with more than one segment), then longer segments for one set of four XCDs (both
+//            signs), then two workgroups per CU instead of three.  At most ~20 timed candidates per class.
 //   long kernels (>= 4 ms): ONE run of the product being tuned per candidate -- at that length neither the clocks nor what
 //            ran before move the result; short kernels: one untimed pair, then two batches of products of the side being tuned,
 //            each timed on its own inside the alternating Ax -> ATx sequence the solvers issue (the other side on its current
@@ -1145,8 +1145,6 @@ static int plan_decomps(gv_ctx* c) {
         // geo 0.5 0.424 ms with no launch above 0.431 against the hybrid's 0.441 with 4 of 30 at 0.49-0.56.
         if (prio_only != 0) {
             std::vector<std::pair<int, float>> gks;
-            const int64_t nq_ = (nrg + 3) / 4;
-            (void)nq_;
             for (const auto& gk : {std::pair<int, float>{2, 0.5f}, {2, 0.35f}, {3, 0.5f}, {4, 0.5f}}) gks.push_back(gk);
             if (geo_side || getenv("GV_TUNE_GEO")) for (const auto& gk : {std::pair<int, float>{6, 0.6f}, {8, 0.65f}, {8, 0.8f}}) gks.push_back(gk);
             for (const auto& gk : gks) {
