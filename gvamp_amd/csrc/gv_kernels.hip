@@ -915,44 +915,57 @@ __global__ __launch_bounds__(256) void k_cgx_decide(CgxDecide a, double gam2, in
     }
 }
 
-// vamp::g1 / g1d (vamp.cpp:805-869), same operation order per element
-__device__ __forceinline__ void g1_g1d(double y, double gam1, const gv_prior& pr, double eta_max, double& g1,
-                                       double& g1d) {
-    double sigma = 1 / gam1;
-    if (sigma < 1e-10 && sigma > -1e-10) {
-        g1 = y;
-        g1d = 1;
-        return;
-    }
-    double pk = 0, pkd = 0, pkdd = 0;
-    for (int i = 0; i < pr.L; i++) {
-        double vs = pr.vars[i] + sigma;
-        double expe_sum = -0.5 * (y * y) * (eta_max - pr.vars[i]) / vs / (eta_max + sigma);
-        double e = exp(expe_sum);
-        double z = pr.probs[i] / sqrt(vs) * e;
-        pk = pk + z;
-        z = z / vs * y;
-        pkd = pkd - z;
-        double z2 = z / vs * y;
-        pkdd = pkdd - pr.probs[i] / (vs * sqrt(vs)) * e + z2;
-    }
-    g1 = y + sigma * pkd / pk;
-    double q = pkd / pk;
-    g1d = 1 + sigma * (pkdd / pk - q * q);
-}
-
-// vamp.cpp:292-310 fused: x1 = g1(r1), d = g1d(r1), partials of sum d and sum (x1 - r1)^2
+// vamp.cpp:292-310 fused: x1 = g1(r1), d = g1d(r1), partials of sum d and sum (x1 - r1)^2.
+// vamp::g1 / g1d (vamp.cpp:805-869) in the reference's operation order per element -- with gam1 = 1e-8 (the first iteration of a run)
+// 1 + sigma (pkdd / pk - q^2) cancels ten digits, and only the same roundings give the reference's alpha1 (a re-associated form
+// with the divisions folded into per-component constants was 2.5 x faster and moved x2 of such an iteration by 1.6e-3:
+// tests/test_gpu_ld.py, tiny-variance prior).  What depends on the component only AND enters the element's arithmetic as the very
+// same double is computed once per block: vs = var + sigma, eta_max - var, prob / sqrt(vs), prob / (vs sqrt(vs)) -- the two square
+// roots and three of the seven divisions per (element, component).  Bit-identical to the formulas as written.
 __global__ __launch_bounds__(256) void k_denoise(const double* __restrict__ r1, int64_t n, double gam1, gv_prior pr,
                                                  double* __restrict__ x1, double* __restrict__ dd,
                                                  double* __restrict__ partial) {
     __shared__ double sh[4];
-    double eta_max = pr.vars[0];
-    for (int i = 1; i < pr.L; i++) eta_max = fmax(eta_max, pr.vars[i]);
+    __shared__ double c_vs[GV_LMAX], c_dv[GV_LMAX], c_a[GV_LMAX], c_d[GV_LMAX];
+    const double sigma = 1 / gam1;
+    const bool identity = sigma < 1e-10 && sigma > -1e-10;      // vamp.cpp:813,844
+    const int L = pr.L;
+    if (threadIdx.x < L) c_vs[threadIdx.x] = pr.vars[threadIdx.x];
+    __syncthreads();
+    double eta_max = c_vs[0];
+    for (int i = 1; i < L; i++) eta_max = fmax(eta_max, c_vs[i]);
+    __syncthreads();
+    if (threadIdx.x < L) {
+        const double var = pr.vars[threadIdx.x], vs = var + sigma;
+        c_vs[threadIdx.x] = vs;
+        c_dv[threadIdx.x] = eta_max - var;
+        c_a[threadIdx.x] = pr.probs[threadIdx.x] / sqrt(vs);
+        c_d[threadIdx.x] = pr.probs[threadIdx.x] / (vs * sqrt(vs));
+    }
+    __syncthreads();
+    const double es = eta_max + sigma;
     int64_t stride = (int64_t)gridDim.x * 256;
     double s0 = 0, s1 = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        double y = r1[i], g, gd;
-        g1_g1d(y, gam1, pr, eta_max, g, gd);
+        const double y = r1[i];
+        double g = y, gd = 1;
+        if (!identity) {
+            double pk = 0, pkd = 0, pkdd = 0;
+            const double h = -0.5 * (y * y);
+            for (int j = 0; j < L; j++) {
+                const double vs = c_vs[j];
+                const double e = exp(h * c_dv[j] / vs / es);
+                double z = c_a[j] * e;
+                pk = pk + z;
+                z = z / vs * y;
+                pkd = pkd - z;
+                const double z2 = z / vs * y;
+                pkdd = pkdd - c_d[j] * e + z2;
+            }
+            g = y + sigma * pkd / pk;
+            const double q = pkd / pk;
+            gd = 1 + sigma * (pkdd / pk - q * q);
+        }
         x1[i] = g;
         if (dd) dd[i] = gd;
         s0 += gd;
@@ -967,20 +980,30 @@ __global__ __launch_bounds__(256) void k_denoise(const double* __restrict__ r1, 
 }
 
 // vamp::updatePrior E-step (vamp.cpp:953-1013).  pr.probs[j] holds omegas[j] (j >= 1), pr.vars[j] the variances.
-// 64-thread blocks.  Everything that depends on the component only (the exponent coefficient, the Gaussian prefactor, the
-// posterior mean gain and variance) is computed once per block, so an element costs one exp and a few FMAs per component instead
-// of the nine divisions / square roots of the formulas as written (same values up to the rounding of the re-association).  The
-// per-thread accumulators live in registers, instantiated for priors of at most LC + 1 components; only the per-component
-// constants (uniform over the block) stay in LDS.  (An earlier form kept the accumulators in LDS columns: 47 KB per block, three
-// waves per CU, 32-53 us where this one takes 18-20; it produced the same bits and is gone.)
+// Everything that depends on the component only (the exponent coefficient, the Gaussian prefactor, the posterior mean gain and
+// variance) is computed once per block, so an element costs one exp and a few FMAs per component instead of the nine divisions /
+// square roots of the formulas as written (same values up to the rounding of the re-association).
+// Shape: the arithmetic is small (200k markers x 15 components: ~3 us of the chip's fp64 rate) and the kernel took 19 us, because
+// its three register arrays of LC doubles with LC unrolled exps in flight filled 256 VGPRs -- one-wave blocks, one or two waves per
+// SIMD, three elements per thread one after the other and 47 wave reductions at the end, nothing to hide any of it behind.  Now the
+// responsibilities' numerators wait in an LDS column per thread between the two loops over the components (the exp loop is
+// rolled), only the 2 LC accumulators stay in registers, and 256-thread blocks run four (LC <= 16), three (<= 24) or two waves per
+// SIMD: a thread takes one element up to 262k markers.
 template <int LC>
-__global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict__ r1, int64_t n, double gam1, double lambda,
-                                                        gv_prior pr, double* __restrict__ partial) {
+__global__ __launch_bounds__(256, LC <= 16 ? 4 : (LC <= 24 ? 3 : 2)) void k_prior_estep_reg(const double* __restrict__ r1, int64_t n,
+                                                                                            double gam1, double lambda, gv_prior pr,
+                                                                                            double* __restrict__ partial) {
     __shared__ double c_exp[GV_LMAX - 1], c_pre[GV_LMAX - 1], c_gain[GV_LMAX - 1], c_var[GV_LMAX - 1];
+    __shared__ double numL[LC][260];          // [component][thread] (+ 4: the row sums at the end read eight rows at once); re-used for those sums
     const int t = threadIdx.x, Lm1 = pr.L - 1, K = 1 + 2 * Lm1;
     const double noise_var = 1 / gam1;
-    double max_sigma = pr.vars[0];
-    for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, pr.vars[j]);
+    // (the largest variance: a loop over pr.vars is pr.L dependent scalar loads from the kernel arguments, ~2 us at the head of every
+    // block; one load per thread and a pass over LDS instead)
+    if (t < pr.L) numL[0][t] = pr.vars[t];
+    __syncthreads();
+    double max_sigma = numL[0][0];
+    for (int j = 1; j < pr.L; j++) max_sigma = fmax(max_sigma, numL[0][j]);
+    __syncthreads();
     if (t < Lm1) {
         const double v = pr.vars[t + 1];
         c_exp[t] = 0.5 * (max_sigma - v) / (v + noise_var) / (max_sigma + noise_var);
@@ -990,45 +1013,60 @@ __global__ __launch_bounds__(64) void k_prior_estep_reg(const double* __restrict
     }
     const double c0 = (1 - lambda) / sqrt(2 * M_PI * noise_var);
     const double e0 = 0.5 * max_sigma / noise_var / (noise_var + max_sigma);
-    double accR[LC], accG[LC], num[LC];
+    double accR[LC], accG[LC];
 #pragma unroll
     for (int j = 0; j < LC; j++) accR[j] = accG[j] = 0.0;
     __syncthreads();
     double acc_pin = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * 64;
-    for (int64_t i = (int64_t)blockIdx.x * 64 + t; i < n; i += stride) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n; i += stride) {
         const double r = r1[i], r2 = r * r;
         double sum_of_elems = 0.0;
-#pragma unroll
-        for (int j = 0; j < LC; j++)
-            if (j < Lm1) {
-                num[j] = c_pre[j] * exp(-r2 * c_exp[j]);
-                sum_of_elems += num[j];
-            }
+        __asm__ volatile("" ::: "memory");                 // the per-component constants are read where they are used, not hoisted into 4 LC registers
+#pragma unroll 4
+        for (int j = 0; j < Lm1; j++) {
+            const double v = c_pre[j] * exp(-r2 * c_exp[j]);
+            numL[j][t] = v;
+            sum_of_elems += v;
+        }
         const double inv = 1 / sum_of_elems;
         const double pin = 1 / (1 + c0 * exp(-r2 * e0) * inv);
         acc_pin += pin;
+        const double w = inv * pin;
 #pragma unroll
         for (int j = 0; j < LC; j++)
             if (j < Lm1) {
-                const double beta = num[j] * inv;
+                const double bp = numL[j][t] * w;          // beta * pin
                 const double gm = c_gain[j] * r;
-                accR[j] += beta * pin;
-                accG[j] += beta * (gm * gm + c_var[j]) * pin;
+                accR[j] += bp;
+                accG[j] = fma(bp, fma(gm, gm, c_var[j]), accG[j]);
             }
     }
-    double* o = partial + (int64_t)blockIdx.x * K;
-    const double s = wave_sum(acc_pin);
-    if (t == 0) o[0] = s;
+    // the sums over the block, through LDS: 2 LC + 1 wave reductions by shuffles are 6 x 2 ds_bpermute each -- 10 us of LDS traffic per
+    // CU with sixteen waves at it.  Instead every thread leaves its accumulator j in row j of the numerator array (free now), and
+    // eight threads per row add 32 entries each in a fixed order, then one another's sums
+    auto rows_sum = [&](const double (&acc)[LC], int slot0) {
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < LC; j++)
-        if (j < Lm1) {
-            const double a = wave_sum(accR[j]), b = wave_sum(accG[j]);
-            if (t == 0) {
-                o[1 + 2 * j] = a;
-                o[2 + 2 * j] = b;
-            }
+        for (int j = 0; j < LC; j++)
+            if (j < Lm1) numL[j][t] = acc[j];
+        __syncthreads();
+        const int row = t >> 3, part = t & 7;
+        double v = 0.0;
+        if (row < Lm1) {
+#pragma unroll 8
+            for (int i = 0; i < 32; i++) v += numL[row][i * 8 + part];
         }
+        v += __shfl_down(v, 4, 8);
+        v += __shfl_down(v, 2, 8);
+        v += __shfl_down(v, 1, 8);
+        if (row < Lm1 && part == 0) partial[(int64_t)blockIdx.x * K + slot0 + 2 * row] = v;
+    };
+    rows_sum(accR, 1);
+    rows_sum(accG, 2);
+    __shared__ double sh[4];
+    const double s = block_sum_256(acc_pin, sh);
+    if (t == 0) partial[(int64_t)blockIdx.x * K] = s;
 }
 
 // ---- p-values: the per-marker regression test (device functions in gv_pval_dev.h) ----------------------------------------
@@ -1360,10 +1398,10 @@ void denoise(hipStream_t s, const double* r1, int64_t n, double gam1, const gv_p
 
 void prior_estep(hipStream_t s, const double* r1, int64_t n, double gam1, double lambda, const gv_prior& pr,
                  double* partial, double* out) {
-    int nb = red_blocks(n, 64);
+    int nb = red_blocks(n, 256);
     int K = 1 + 2 * (pr.L - 1);
     const int Lm1 = pr.L - 1;
-#define GV_ESTEP(LCV) hipLaunchKernelGGL(k_prior_estep_reg<LCV>, dim3(nb), dim3(64), 0, s, r1, n, gam1, lambda, pr, partial)
+#define GV_ESTEP(LCV) hipLaunchKernelGGL(k_prior_estep_reg<LCV>, dim3(nb), dim3(256), 0, s, r1, n, gam1, lambda, pr, partial)
     if (Lm1 <= 4) GV_ESTEP(4);
     else if (Lm1 <= 8) GV_ESTEP(8);
     else if (Lm1 <= 16) GV_ESTEP(16);
