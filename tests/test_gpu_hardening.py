@@ -378,26 +378,20 @@ def test_stripe_sets_survive_a_reingest():
         assert np.array_equal(a1, a3) and np.array_equal(t1, t3) and not np.array_equal(a1, a2)
 
 
-@pytest.mark.parametrize("L", [2, 3, 5, 6, 9, 12, 17, 18, 23, 26, 32])
-def test_prior_estep_every_instantiation_vs_the_formulas(L):
-    """gv_prior_estep keeps its per-thread accumulators in registers, instantiated for up to 5, 9, 17, 25 and 32 components: each
-    against the E-step sums of vamp.cpp:953-1013 evaluated in numpy (SURVEY appendix A), and reproducible bit for bit."""
-    M = 70001
-    rng = np.random.default_rng(L)
+def _estep_case(M, L, seed):
+    rng = np.random.default_rng(seed)
     r1 = rng.standard_normal(M) * 0.3
     vars_ = np.concatenate([[0.0], np.sort(10.0 ** rng.uniform(-4, -1, L - 1))])
     probs = np.concatenate([[0.9], rng.dirichlet(np.ones(L - 1)) * 0.1])
     lam = 1 - probs[0]
     omegas = probs.copy()
     omegas[1:] /= lam
-    gam1 = 2.5
-    out = []
-    with capi.Shard(2000, M) as sh:
-        sh.synth_bed(1)
-        sh.compute_markers_statistics()
-        dr = sh.vecM(r1)
-        for _ in range(2):
-            out.append(np.array(sh.prior_estep(dr, gam1, lam, omegas, vars_)))
+    return r1, vars_, lam, omegas
+
+
+def _estep_formulas(r1, gam1, lam, omegas, vars_):
+    """the E-step sums of vamp.cpp:953-1013 evaluated in numpy"""
+    L = vars_.size
     nu, vmax = 1.0 / gam1, vars_.max()
     v = vars_[1:][None, :]
     num = lam * omegas[1:][None, :] * np.exp(-0.5 * r1[:, None] ** 2 * (vmax - v) / ((v + nu) * (vmax + nu))) / np.sqrt(v + nu) / np.sqrt(2 * np.pi)
@@ -409,9 +403,50 @@ def test_prior_estep_every_instantiation_vs_the_formulas(L):
     want[0] = pin.sum()
     want[1::2] = (beta * pin[:, None]).sum(axis=0)
     want[2::2] = (beta * (mean ** 2 + var) * pin[:, None]).sum(axis=0)
+    return want
+
+
+@pytest.mark.parametrize("L", [2, 3, 5, 6, 9, 12, 17, 18, 23, 26, 32])
+def test_prior_estep_every_instantiation_vs_the_formulas(L):
+    """gv_prior_estep keeps its per-thread accumulators in registers, instantiated for up to 5, 9, 17, 25 and 32 components: each
+    against the E-step sums of vamp.cpp:953-1013 evaluated in numpy (SURVEY appendix A), and reproducible bit for bit."""
+    M = 70001
+    r1, vars_, lam, omegas = _estep_case(M, L, L)
+    gam1 = 2.5
+    out = []
+    with capi.Shard(2000, M) as sh:
+        sh.synth_bed(1)
+        sh.compute_markers_statistics()
+        dr = sh.vecM(r1)
+        for _ in range(2):
+            out.append(np.array(sh.prior_estep(dr, gam1, lam, omegas, vars_)))
+    want = _estep_formulas(r1, gam1, lam, omegas, vars_)
     assert out[0].shape == (1 + 2 * (L - 1),) and np.all(np.isfinite(out[0]))
     assert np.allclose(out[0], want, rtol=1e-11, atol=1e-13 * want[0])
     assert [float(v).hex() for v in out[0]] == [float(v).hex() for v in out[1]]
+
+
+@pytest.mark.parametrize("M,L", [(1, 3), (255, 5), (257, 17), (262145, 23), (600001, 17), (600001, 32), (1000003, 23)])
+def test_prior_estep_and_denoiser_block_shapes_vs_the_formulas(oracle, M, L):
+    """The E-step runs in 256-thread blocks, one element per thread up to 262 144 markers and a strided loop beyond (1 024 blocks at
+    most), its numerators staged in LDS and its block sums taken through LDS rows; the denoiser keeps per-block component tables.
+    One marker, one block short of / past a block edge, the first size that loops, config 2's and the headline's sizes: the sums
+    against the formulas, x1 / g1d against the oracle's vamp::g1 / g1d, and bit-reproducible."""
+    r1, vars_, lam, omegas = _estep_case(M, L, 1000 + L)
+    probs = omegas.copy()
+    probs[1:] *= lam
+    gam1 = 2.5
+    with capi.Shard(256, M) as sh:
+        dr, x1, dd = sh.vecM(r1), sh.vecM(), sh.vecM()
+        e = [np.array(sh.prior_estep(dr, gam1, lam, omegas, vars_)) for _ in range(2)]
+        s = [np.array(sh.denoise(dr, gam1, probs, vars_, x1, dd)) for _ in range(2)]
+        gx, gd = x1.download(), dd.download()
+    want = _estep_formulas(r1, gam1, lam, omegas, vars_)
+    assert np.allclose(e[0], want, rtol=1e-11, atol=1e-13 * want[0])
+    ox, od = oracle.g1_g1d(r1, gam1, probs, vars_)
+    assert np.allclose(gx, ox, rtol=1e-13, atol=1e-15) and np.allclose(gd, od, rtol=1e-11, atol=1e-13)
+    assert np.isclose(s[0][0], od.sum(), rtol=1e-12) and np.isclose(s[0][1], ((ox - r1) ** 2).sum(), rtol=1e-12)
+    assert [float(v).hex() for v in e[0]] == [float(v).hex() for v in e[1]] and [float(v).hex() for v in s[0]] == [float(v).hex() for v in s[1]]
 
 
 def test_auto_layout_weighs_the_length_of_the_run_and_ingest_reports_its_parts(tmp_path):
